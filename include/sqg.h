@@ -1,0 +1,164 @@
+/*
+ * sqg.h -- C ABI of the MI355X-native per-read signal generator.
+ *
+ * Drop-in seam (reference file:line under the upstream tree):
+ *   the batch-level replacement of
+ *       process_db(core, db)                         src/sim.c:622-627
+ *         -> work_db(core, db, work_per_single_read) src/thread.c:119-131
+ *            -> gen_sig(core, read, len, &offset, &median_before,
+ *                       &len_raw_signal, rna, tid, aln)   src/gensig.c:346
+ *   A GPU wants a batch, not a read, so the unit handed over is one batch of
+ *   reads exactly as gen_read() returned them (src/genread.c:358, i.e. after
+ *   strand/revcomp and N substitution), plus the worker (tid) each read runs
+ *   on.  Results are what gen_sig returns per read: the int16 raw signal, its
+ *   length, `offset`, `median_before`, and -- for PAF/SAM -- the per-event
+ *   dwell array aln->ss (src/gensig.c:273-281).
+ *
+ * Determinism contract: output is a pure function of (cfg, the sequence of
+ * batches).  It equals the reference run with `-t T -K K --seed S` in the two
+ * regimes where the reference itself is deterministic: T==1, and T>=batch size
+ * (one read per worker per batch, no work stealing).  For
+ * 1<T<K the reference's static partition (src/thread.c:80-99) without stealing
+ * is used.
+ *
+ * Plain C, no torch types.  All functions return 0 on success or a negative
+ * SQG_E* code; nothing here calls exit() (the reference's ERROR()+exit paths,
+ * src/error.h:75-111, become return codes).
+ */
+#ifndef SQG_H
+#define SQG_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQG_ABI_VERSION 1
+
+/* option bits -- identical values to opt_t.flag, src/sq.h:32-42 */
+#define SQG_RNA         0x001u
+#define SQG_IDEAL       0x004u
+#define SQG_IDEAL_TIME  0x008u
+#define SQG_IDEAL_AMP   0x010u
+#define SQG_PREFIX      0x020u
+
+/* error codes */
+#define SQG_OK            0
+#define SQG_EINVAL       -1   /* bad argument / unsupported configuration     */
+#define SQG_ENOMEM       -2   /* host or device allocation failed             */
+#define SQG_EDEVICE      -3   /* HIP runtime error (see sqg_last_error)       */
+#define SQG_ESEQUENCE    -4   /* batches must be run in the order staged      */
+#define SQG_ENODEVICE    -5   /* no usable gfx950 device / HIP not available  */
+#define SQG_EOVERFLOW    -6   /* a read would exceed UINT32_MAX samples (src/sim.c:559-562) */
+
+/* arithmetic mode of the sample kernel */
+#define SQG_MODE_EXACT      0 /* every sample through the FP64 path                      */
+#define SQG_MODE_CERTIFIED  1 /* fp32 fast path + error-bounded test, FP64 for the rest  */
+
+/* profile_t, src/sq.h:47-58 -- same fields, same order */
+typedef struct {
+    double digitisation;
+    double sample_rate;
+    double bps;
+    double range;
+    double offset_mean;
+    double offset_std;
+    double median_before_mean;
+    double median_before_std;
+    double dwell_mean;
+    double dwell_std;
+} sqg_profile_t;
+
+/* model_t, src/sq.h:61-68 -- one pore-model row per k-mer rank */
+typedef struct {
+    float level_mean;
+    float level_stdv;
+} sqg_kmer_t;
+
+typedef struct {
+    uint32_t abi_version;       /* SQG_ABI_VERSION                                           */
+    sqg_profile_t profile;      /* core->profile                                             */
+    uint32_t flags;             /* SQG_* bits of core->opt.flag                              */
+    float amp_noise;            /* core->opt.amp_noise                                       */
+    uint32_t kmer_size;         /* core->kmer_size, 1..9                                     */
+    const sqg_kmer_t *model;    /* core->model, 4^k rows (host memory, copied)               */
+    int64_t seed;               /* core->opt.seed (must be != 0 as in the reference CLI)     */
+    int32_t num_workers;        /* T = core->opt.num_thread: virtual workers in the job      */
+    int32_t worker_lo;          /* this context owns workers [worker_lo, worker_hi):         */
+    int32_t worker_hi;          /*   0,T on one GPU; a shard of them per GPU otherwise       */
+    int32_t device;             /* HIP device ordinal                                        */
+    uint32_t mode;              /* SQG_MODE_*                                                */
+} sqg_cfg_t;
+
+typedef struct sqg_ctx sqg_ctx_t;
+typedef struct sqg_batch sqg_batch_t;
+
+/* per-batch results; host arrays are owned by the batch and stay valid until
+ * sqg_batch_free(); device pointers stay valid until the NEXT sqg_batch_run on
+ * the same context (outputs live in context-owned HBM slabs that are reused) */
+typedef struct {
+    int32_t n_reads;
+    int64_t n_events;           /* k-mer events incl. prefix/stall events                    */
+    int64_t n_samples;          /* int16 samples written                                     */
+    int64_t n_bases;            /* sequence bytes read by the kernels                        */
+    const int64_t *sig_off;     /* [n_reads+1] exclusive scan of len_raw_signal (host)       */
+    const int64_t *ev_off;      /* [n_reads+1] exclusive scan of per-read event counts (host)*/
+    const double *offset;       /* [n_reads] slow5 `offset` per read (host)                  */
+    const double *median_before;/* [n_reads] (host)                                          */
+    const int16_t *d_signal;    /* device: n_samples int16, read i at sig_off[i]             */
+    const uint16_t *d_dwell;    /* device: n_events samples-per-event (aln->ss order)        */
+} sqg_result_t;
+
+/* kernel timings of the last sqg_batch_run, from hipEvents on the context's stream */
+typedef struct {
+    float dwell_ms;             /* dwell_and_scan kernels                                    */
+    float signal_ms;            /* emit_samples kernel (the dominant, roofline-priced one)   */
+    float total_ms;             /* first launch to last completion                           */
+    int64_t fallback_samples;   /* CERTIFIED mode: samples recomputed on the FP64 path       */
+} sqg_timing_t;
+
+int  sqg_create(const sqg_cfg_t *cfg, sqg_ctx_t **out);
+void sqg_destroy(sqg_ctx_t *ctx);
+const char *sqg_last_error(const sqg_ctx_t *ctx);   /* "" if none */
+const char *sqg_strerror(int code);
+int  sqg_device_count(void);                        /* <0: HIP unusable */
+
+/* Stage one batch: sequences are the reads exactly as gen_read() returns them.
+ *   seqs     concatenated read bytes (ASCII; IUPAC handled as src/seq.h:14-27)
+ *   seq_off  [n_reads+1] byte offsets into seqs
+ *   worker   [n_reads] global worker id (tid) of each read, or NULL for the
+ *            reference's static partition of this batch over num_workers
+ * Host-side per-read draws (offset, median_before: src/gensig.c:311-317) are
+ * made here, in staging order; sequences are uploaded to HBM. */
+int  sqg_batch_stage(sqg_ctx_t *ctx, int32_t n_reads, const char *seqs,
+                     const int64_t *seq_off, const int32_t *worker, sqg_batch_t **out);
+/* Launch the kernels for a staged batch (asynchronous on the context stream).
+ * Batches must be run in the order they were staged. */
+int  sqg_batch_run(sqg_ctx_t *ctx, sqg_batch_t *b);
+/* Block until the batch has finished; fills *res. */
+int  sqg_batch_wait(sqg_ctx_t *ctx, sqg_batch_t *b, sqg_result_t *res);
+/* Copy results of the most recently run batch to host memory. */
+int  sqg_fetch_signal(sqg_ctx_t *ctx, sqg_batch_t *b, int16_t *dst /* n_samples */);
+int  sqg_fetch_dwell(sqg_ctx_t *ctx, sqg_batch_t *b, int32_t *dst /* n_events, as aln->ss */);
+void sqg_batch_free(sqg_ctx_t *ctx, sqg_batch_t *b);
+int  sqg_get_timing(sqg_ctx_t *ctx, sqg_timing_t *t);
+
+/* Convenience: stage + run + wait in one call (one process_db()). */
+int  sqg_submit(sqg_ctx_t *ctx, int32_t n_reads, const char *seqs, const int64_t *seq_off,
+                const int32_t *worker, sqg_batch_t **out, sqg_result_t *res);
+
+/* Worker id the reference's scheduler gives read i of a batch of n_rec reads
+ * under -t T when no work is stolen (src/thread.c:80-99,122-125). */
+int32_t sqg_worker_of(int32_t i, int32_t n_rec, int32_t T);
+
+/* HBM streaming-store probe used by bench.py to state the measured write
+ * ceiling next to the 8 TB/s spec figure: writes `bytes` of int16 `iters`
+ * times and returns the average milliseconds per pass. */
+int  sqg_probe_store_bandwidth(sqg_ctx_t *ctx, size_t bytes, int iters, float *ms_per_pass);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,237 @@
+"""ctypes binding of the C ABI in include/sqg.h (squigulator_amd/csrc/libsqg_hip.so).
+
+This is plumbing for tests and bench.py; the product is the shared library.  There is NO CPU
+fallback: if the HIP library is missing or no GPU is usable, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+from . import profiles as P
+
+ABI_VERSION = 1
+MODE_EXACT = 0
+MODE_CERTIFIED = 1
+
+_ERRORS = {-1: "SQG_EINVAL", -2: "SQG_ENOMEM", -3: "SQG_EDEVICE", -4: "SQG_ESEQUENCE",
+           -5: "SQG_ENODEVICE", -6: "SQG_EOVERFLOW"}
+
+
+class SqgError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where}: {_ERRORS.get(code, code)} {detail}".strip())
+
+
+class CProfile(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "digitisation", "sample_rate", "bps", "range", "offset_mean", "offset_std",
+        "median_before_mean", "median_before_std", "dwell_mean", "dwell_std")]
+
+
+class CKmer(C.Structure):
+    _fields_ = [("level_mean", C.c_float), ("level_stdv", C.c_float)]
+
+
+class CCfg(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("profile", CProfile), ("flags", C.c_uint32),
+                ("amp_noise", C.c_float), ("kmer_size", C.c_uint32), ("model", C.POINTER(CKmer)),
+                ("seed", C.c_int64), ("num_workers", C.c_int32), ("worker_lo", C.c_int32),
+                ("worker_hi", C.c_int32), ("device", C.c_int32), ("mode", C.c_uint32)]
+
+
+class CResult(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("n_events", C.c_int64), ("n_samples", C.c_int64),
+                ("n_bases", C.c_int64), ("sig_off", C.POINTER(C.c_int64)), ("ev_off", C.POINTER(C.c_int64)),
+                ("offset", C.POINTER(C.c_double)), ("median_before", C.POINTER(C.c_double)),
+                ("d_signal", C.c_void_p), ("d_dwell", C.c_void_p)]
+
+
+class CTiming(C.Structure):
+    _fields_ = [("dwell_ms", C.c_float), ("signal_ms", C.c_float), ("total_ms", C.c_float),
+                ("fallback_samples", C.c_int64)]
+
+
+EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_device_count",
+           "sqg_batch_stage", "sqg_batch_run", "sqg_batch_wait", "sqg_fetch_signal", "sqg_fetch_dwell",
+           "sqg_batch_free", "sqg_get_timing", "sqg_submit", "sqg_worker_of", "sqg_probe_store_bandwidth")
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """dlopen the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or _build.LIB
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `python -m squigulator_amd.build` "
+                           "(there is no CPU fallback for the signal path)")
+    L = C.CDLL(path)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    L.sqg_create.restype = C.c_int
+    L.sqg_create.argtypes = [C.POINTER(CCfg), C.POINTER(vp)]
+    L.sqg_destroy.restype = None
+    L.sqg_destroy.argtypes = [vp]
+    L.sqg_last_error.restype = C.c_char_p
+    L.sqg_last_error.argtypes = [vp]
+    L.sqg_strerror.restype = C.c_char_p
+    L.sqg_strerror.argtypes = [C.c_int]
+    L.sqg_device_count.restype = C.c_int
+    L.sqg_batch_stage.restype = C.c_int
+    L.sqg_batch_stage.argtypes = [vp, i32, C.c_char_p, C.POINTER(i64), C.POINTER(i32), C.POINTER(vp)]
+    L.sqg_batch_run.restype = C.c_int
+    L.sqg_batch_run.argtypes = [vp, vp]
+    L.sqg_batch_wait.restype = C.c_int
+    L.sqg_batch_wait.argtypes = [vp, vp, C.POINTER(CResult)]
+    L.sqg_fetch_signal.restype = C.c_int
+    L.sqg_fetch_signal.argtypes = [vp, vp, C.c_void_p]
+    L.sqg_fetch_dwell.restype = C.c_int
+    L.sqg_fetch_dwell.argtypes = [vp, vp, C.c_void_p]
+    L.sqg_batch_free.restype = None
+    L.sqg_batch_free.argtypes = [vp, vp]
+    L.sqg_get_timing.restype = C.c_int
+    L.sqg_get_timing.argtypes = [vp, C.POINTER(CTiming)]
+    L.sqg_submit.restype = C.c_int
+    L.sqg_submit.argtypes = [vp, i32, C.c_char_p, C.POINTER(i64), C.POINTER(i32), C.POINTER(vp), C.POINTER(CResult)]
+    L.sqg_worker_of.restype = i32
+    L.sqg_worker_of.argtypes = [i32, i32, i32]
+    L.sqg_probe_store_bandwidth.restype = C.c_int
+    L.sqg_probe_store_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
+    if path == _build.LIB:
+        _lib = L
+    return L
+
+
+class Batch:
+    """A staged batch (one process_db() worth of reads)."""
+
+    def __init__(self, gen, handle, n_reads):
+        self.gen, self.handle, self.n_reads = gen, handle, n_reads
+        self.res = None
+
+    def run(self):
+        self.gen._chk(self.gen.L.sqg_batch_run(self.gen.ctx, self.handle), "sqg_batch_run")
+        return self
+
+    def wait(self):
+        r = CResult()
+        self.gen._chk(self.gen.L.sqg_batch_wait(self.gen.ctx, self.handle, C.byref(r)), "sqg_batch_wait")
+        self.res = r
+        n = r.n_reads
+        self.n_samples, self.n_events, self.n_bases = r.n_samples, r.n_events, r.n_bases
+        self.sig_off = np.ctypeslib.as_array(r.sig_off, shape=(n + 1,)).copy()
+        self.ev_off = np.ctypeslib.as_array(r.ev_off, shape=(n + 1,)).copy()
+        self.offset = np.ctypeslib.as_array(r.offset, shape=(n,)).copy() if n else np.zeros(0)
+        self.median_before = np.ctypeslib.as_array(r.median_before, shape=(n,)).copy() if n else np.zeros(0)
+        return self
+
+    def signal(self) -> np.ndarray:
+        out = np.empty(self.n_samples, np.int16)
+        self.gen._chk(self.gen.L.sqg_fetch_signal(self.gen.ctx, self.handle, out.ctypes.data), "sqg_fetch_signal")
+        return out
+
+    def dwell(self) -> np.ndarray:
+        out = np.empty(self.n_events, np.int32)
+        self.gen._chk(self.gen.L.sqg_fetch_dwell(self.gen.ctx, self.handle, out.ctypes.data), "sqg_fetch_dwell")
+        return out
+
+    def free(self):
+        if self.handle:
+            self.gen.L.sqg_batch_free(self.gen.ctx, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            if self.gen.ctx:
+                self.free()
+        except Exception:
+            pass
+
+
+class SignalGenerator:
+    """One simulation context: the reference's core_t for (profile, flags, model, seed, -t)."""
+
+    def __init__(self, profile: P.Profile, flags: int, kmer_size: int, level_mean, level_stdv, seed: int,
+                 num_workers: int = 1, amp_noise: float = 1.0, device: int = 0, mode: int = MODE_EXACT,
+                 worker_lo: int = 0, worker_hi: int | None = None, lib_path: str | None = None):
+        self.L = load_library(lib_path)
+        self.ctx = None
+        n = 1 << (2 * kmer_size)
+        if len(level_mean) != n or len(level_stdv) != n:
+            raise ValueError("pore model must have 4^k rows")
+        self._model = (CKmer * n)()
+        a = np.frombuffer(self._model, dtype=np.float32).reshape(n, 2)
+        a[:, 0] = level_mean
+        a[:, 1] = level_stdv
+        cfg = CCfg(ABI_VERSION, CProfile(*profile.as_tuple()), flags & 0x3d, amp_noise, kmer_size,
+                   self._model, seed, num_workers, worker_lo,
+                   num_workers if worker_hi is None else worker_hi, device, mode)
+        h = C.c_void_p()
+        rc = self.L.sqg_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise SqgError(rc, "sqg_create", self.L.sqg_strerror(rc).decode())
+        self.ctx = h
+        self.num_workers, self.kmer_size, self.flags, self.profile = num_workers, kmer_size, flags, profile
+
+    def _chk(self, rc, where):
+        if rc != 0:
+            raise SqgError(rc, where, self.L.sqg_last_error(self.ctx).decode())
+
+    def stage(self, seqs, workers=None) -> Batch:
+        """seqs: list of bytes (reads as gen_read returns them)."""
+        n = len(seqs)
+        off = np.zeros(n + 1, np.int64)
+        if n:
+            off[1:] = np.cumsum([len(s) for s in seqs])
+        blob = b"".join(seqs)
+        wk = None
+        if workers is not None:
+            wk = np.ascontiguousarray(workers, np.int32)
+        h = C.c_void_p()
+        rc = self.L.sqg_batch_stage(self.ctx, n, blob, off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                    wk.ctypes.data_as(C.POINTER(C.c_int32)) if wk is not None else None,
+                                    C.byref(h))
+        self._chk(rc, "sqg_batch_stage")
+        return Batch(self, h, n)
+
+    def stage_packed(self, blob: bytes, off: np.ndarray, workers=None) -> Batch:
+        n = len(off) - 1
+        off = np.ascontiguousarray(off, np.int64)
+        wk = np.ascontiguousarray(workers, np.int32) if workers is not None else None
+        h = C.c_void_p()
+        rc = self.L.sqg_batch_stage(self.ctx, n, blob, off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                    wk.ctypes.data_as(C.POINTER(C.c_int32)) if wk is not None else None,
+                                    C.byref(h))
+        self._chk(rc, "sqg_batch_stage")
+        return Batch(self, h, n)
+
+    def submit(self, seqs, workers=None) -> Batch:
+        return self.stage(seqs, workers).run().wait()
+
+    def timing(self):
+        t = CTiming()
+        self._chk(self.L.sqg_get_timing(self.ctx, C.byref(t)), "sqg_get_timing")
+        return {"dwell_ms": t.dwell_ms, "signal_ms": t.signal_ms, "total_ms": t.total_ms,
+                "fallback_samples": t.fallback_samples}
+
+    def probe_store_bandwidth(self, nbytes=1 << 30, iters=10) -> float:
+        ms = C.c_float()
+        self._chk(self.L.sqg_probe_store_bandwidth(self.ctx, nbytes, iters, C.byref(ms)), "sqg_probe_store_bandwidth")
+        return nbytes / (ms.value * 1e-3)
+
+    def close(self):
+        if self.ctx:
+            self.L.sqg_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

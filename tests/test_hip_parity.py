@@ -1,0 +1,89 @@
+"""GPU parity: the HIP path, called through the C ABI, must reproduce
+  (a) the committed vectors of the COMPILED REFERENCE path (tests/golden/refvec), and
+  (b) the oracle on fresh seeded inputs,
+bit for bit (int16 samples, per-event dwell, len_raw_signal, offset, median_before)."""
+import os
+
+import numpy as np
+import pytest
+
+import hiprun
+import simrun
+from refvec_cases import REFVEC_CASES
+from squigulator_amd import api
+
+pytestmark = pytest.mark.gpu
+
+VEC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refvec")
+
+
+def _fixture_reads(v):
+    meta = v["meta"]
+    so = go = eo = 0
+    out = []
+    for i in range(len(meta)):
+        rlen, nsig, nss = int(meta[i][4]), int(meta[i][7]), int(meta[i][8])
+        out.append(dict(seq=v["seq"][so:so + rlen].tobytes(), sig=v["sig"][go:go + nsig], ss=v["ss"][eo:eo + nss],
+                        offset=float(v["offset"][i]), median=float(v["median"][i]), start_time=int(meta[i][6])))
+        so += rlen; go += nsig; eo += nss
+    return out
+
+
+def _compare(got, want, what):
+    assert len(got) == len(want)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert len(g["sig"]) == len(w["sig"]), f"{what} read {i}: len_raw_signal {len(g['sig'])} != {len(w['sig'])}"
+        np.testing.assert_array_equal(g["ss"], w["ss"], err_msg=f"{what} read {i}: per-event dwell")
+        bad = np.nonzero(g["sig"] != w["sig"])[0]
+        assert bad.size == 0, f"{what} read {i}: {bad.size} samples differ, first at {bad[:5]}: {g['sig'][bad[:5]]} vs {w['sig'][bad[:5]]}"
+        assert g["offset"] == w["offset"] and g["median"] == w["median"], f"{what} read {i}: offset/median_before"
+        assert g["start_time"] == w["start_time"]
+
+
+@pytest.mark.parametrize("mode", [api.MODE_EXACT], ids=["exact"])
+@pytest.mark.parametrize("cid,cmd", REFVEC_CASES, ids=[c[0] for c in REFVEC_CASES])
+def test_hip_matches_reference_vectors(cid, cmd, mode):
+    v = np.load(os.path.join(VEC, cid + ".npz"))
+    want = _fixture_reads(v)
+    got = hiprun.run_hip_on_reads(cmd, [w["seq"] for w in want], mode=mode)
+    _compare(got, want, cid)
+
+
+@pytest.mark.parametrize("cmd", [
+    "nCoV-2019.reference.fasta -x dna-r9-prom -n 300 --seed 42 -r 3000 -t 128 -K 128",
+    "nCoV-2019.reference.fasta -x dna-r9-prom -n 12 --seed 9 -r 8000 -t 5 -K 12",     # 1<T<K static partition
+    "nCoV-2019.reference.fasta -x dna-r10-prom -n 64 --seed 5 -r 2000 -t 32 -K 32",
+    "rnasequin_sequences_2.4.fa -x rna-r9-min -n 20 --seed 11 -t 20 -K 20 --prefix=yes",
+    "rnasequin_sequences_2.4.fa -x rna004-prom -n 24 --seed 13 -t 8 -K 8 --prefix=yes --dwell-std 5",
+    "nCoV-2019.reference.fasta -x dna-r9-min -n 6 --seed 3 -r 1000 -t1 --dwell-mean 20 --dwell-std 30",
+], ids=["r9_tk128", "r9_t5_k12", "r10_tk32", "rna9min_prefix", "rna004_prefix_dwellstd", "r9_wide_dwell"])
+def test_hip_matches_oracle(cmd):
+    o, k, names, lengths, reads, orac = simrun.run_oracle(cmd, nthreads=8)
+    orac.close()
+    want = [dict(seq=r.seq, sig=r.sig, ss=r.ss, offset=r.offset, median=r.median_before, start_time=r.start_time)
+            for r in reads]
+    got = hiprun.run_hip_on_reads(cmd, [w["seq"] for w in want])
+    _compare(got, want, cmd)
+
+
+def test_short_and_odd_reads():
+    """reads shorter than k (src/gensig.c:242-245), IUPAC/lower-case bases, a 1-event read, empty batch."""
+    import orc
+    from squigulator_amd import model, profiles
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    mean, stdv = model.synthetic_model(6)
+    seqs = [b"ACG", b"ACGTAC", b"acgtnnRYKMacgtacgtBDHVacgtuUwWsS", b"A" * 50, b"ACGTACGTACGTACGTTTGACCA" * 20]
+    orac = orc.Oracle(prof, fl, 6, mean, stdv, 77, num_workers=len(seqs))
+    want = orac.run_batch_seqs(seqs)
+    gen = api.SignalGenerator(prof, fl, 6, mean, stdv, 77, num_workers=len(seqs))
+    b = gen.submit(seqs)
+    sig, dw = b.signal(), b.dwell()
+    for i, w in enumerate(want):
+        np.testing.assert_array_equal(sig[b.sig_off[i]:b.sig_off[i + 1]], w.sig, err_msg=f"read {i}")
+        np.testing.assert_array_equal(dw[b.ev_off[i]:b.ev_off[i + 1]], w.ss)
+        assert b.offset[i] == w.offset and b.median_before[i] == w.median_before
+    b.free()
+    e = gen.submit([])
+    assert e.n_samples == 0 and e.n_reads == 0
+    e.free()
+    gen.close(); orac.close()
