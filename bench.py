@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- simulated raw samples/s of the per-read signal path on N MI355X.
+
+Workload (BASELINE.json configs[1]): nCoV-2019 reference, -x dna-r9-prom (R9 6-mer pore model),
+reads of gamma-distributed length (-r 10000) cut from the 29 903-nt genome, --seed 42.  One "step" is
+one batch (one process_db()) of --batch-reads reads in the T=K regime: read i of a batch runs on
+virtual worker i.  Steps x batch-reads reads in total; the default 12 x 8192 ~= the config's n=100000.
+Inputs (sequences, per-read descriptors) are resident in HBM before the timed region starts.
+
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL).  The job's T = N*K virtual workers
+are sharded contiguously over ranks; each rank stages and runs only its own workers' reads (no
+steady-state collective; one broadcast of the pore model at start-up) => weak scaling.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (k_signal) against HBM:
+achieved = algorithmic bytes (2*N_samples + N_bases + 24*N_reads per launch) / its
+average launch duration measured with hipEvents on the library's stream.  `cpu_baseline` is the
+oracle (a C restatement of the reference's path, oracle/) timed on this box's host cores on a bounded
+sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from squigulator_amd import api, model, profiles  # noqa: E402
+
+HBM_PEAK_BYTES_PER_S = 8.0e12   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+GENOME = os.path.join(ROOT, "tests", "golden", "inputs", "nCoV-2019.reference.fasta")
+
+
+def load_genome(path):
+    seq = []
+    with open(path) as f:
+        for line in f:
+            if not line.startswith(">"):
+                seq.append(line.strip())
+    return "".join(seq).encode()
+
+
+_COMP = bytes.maketrans(b"ACGTacgt", b"TGCATGCA")
+
+
+def sample_reads(genome: bytes, n: int, rlen: int, rng: np.random.Generator):
+    """Reads with the reference sampler's distribution (src/genread.c:243-281): length ~ Erlang-2 with
+    scale rlen/2, start uniform over the genome, clipped at the contig end, >=200 nt, random strand."""
+    out = []
+    G = len(genome)
+    while len(out) < n:
+        m = n - len(out)
+        lens = rng.gamma(2.0, rlen / 2, size=m).astype(np.int64)
+        pos = rng.integers(0, G, size=m)
+        strand = rng.integers(0, 2, size=m)
+        for L, p, s in zip(lens, pos, strand):
+            r = genome[p:p + L]
+            if len(r) < 200:
+                continue
+            out.append(r if s else r.translate(_COMP)[::-1])
+    return out[:n]
+
+
+def pack(reads):
+    off = np.zeros(len(reads) + 1, np.int64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    return b"".join(reads), off
+
+
+def cpu_baseline(prof, flags, k, mean, stdv, genome, rlen, target_cpu_seconds=20.0):
+    """Oracle (oracle/libsqg_oracle.so) on the host cores, T=K regime, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(1234)
+    # calibrate on a small batch, then size the timed sample for ~target_cpu_seconds of CPU work
+    probe = sample_reads(genome, 64, rlen, rng)
+    o = orc.Oracle(prof, flags, k, mean, stdv, 42, num_workers=len(probe))
+    t0 = time.perf_counter()
+    res = o.run_batch_seqs(probe, want_ss=False, nthreads=cores)
+    dt = time.perf_counter() - t0
+    o.close()
+    ns = sum(len(r.sig) for r in res)
+    rate = ns / dt                                    # all-core rate, samples/s
+    mean_len = ns / len(probe)
+    n = int(min(max(target_cpu_seconds / cores * rate / mean_len, 64), 20000))
+    reads = sample_reads(genome, n, rlen, rng)
+    o = orc.Oracle(prof, flags, k, mean, stdv, 42, num_workers=n)
+    t0 = time.perf_counter()
+    res = o.run_batch_seqs(reads, want_ss=False, nthreads=cores)
+    dt = time.perf_counter() - t0
+    o.close()
+    ns = sum(len(r.sig) for r in res)
+    return {"value": ns / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} reads / {ns} samples of the same workload, generation only (no BLOW5 encode), "
+                      f"-t {n} -K {n} on {cores} host threads, {dt:.2f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch-reads", type=int, default=8192, help="reads per step per GPU (= workers per GPU)")
+    ap.add_argument("--rlen", type=int, default=10000)
+    ap.add_argument("--profile", default="dna-r9-prom")
+    ap.add_argument("--mode", default="certified", choices=["exact", "certified"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-store-probe", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the signal path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    prof, flags = profiles.get_profile(args.profile)
+    k = profiles.default_kmer_size(flags)
+    n_k = 1 << (2 * k)
+    # pore model: rank 0 owns it; RCCL broadcast to the other GPUs (the only collective on this path)
+    tbl = torch.empty((n_k, 2), dtype=torch.float32, device="cuda")
+    if rank == 0:
+        mean, stdv = model.synthetic_model(k)
+        tbl.copy_(torch.from_numpy(np.stack([mean, stdv], 1)))
+    if world > 1:
+        dist.broadcast(tbl, src=0)
+    tbl_h = tbl.cpu().numpy()
+    mean, stdv = np.ascontiguousarray(tbl_h[:, 0]), np.ascontiguousarray(tbl_h[:, 1])
+
+    K = args.batch_reads
+    T = K * world
+    gen = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=T, device=local_rank,
+                              mode=api.MODE_EXACT if args.mode == "exact" else api.MODE_CERTIFIED,
+                              worker_lo=rank * K, worker_hi=(rank + 1) * K)
+    genome = load_genome(GENOME)
+    rng = np.random.default_rng(42 + rank)
+    workers = np.arange(rank * K, (rank + 1) * K, dtype=np.int32)
+
+    nsteps = args.warmup + args.steps
+    batches = []
+    for _ in range(nsteps):
+        blob, off = pack(sample_reads(genome, K, args.rlen, rng))
+        batches.append(gen.stage_packed(blob, off, workers))      # H2D happens here, outside the timed region
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for b in batches[:args.warmup]:
+        b.run().wait()
+    sync_all()
+    t0 = time.perf_counter()
+    sig_ms, dwell_ms = [], []
+    samples = bases = reads = 0
+    for b in batches[args.warmup:]:
+        b.run().wait()
+        tm = gen.timing()
+        sig_ms.append(tm["signal_ms"]); dwell_ms.append(tm["dwell_ms"])
+        samples += b.n_samples; bases += b.n_bases; reads += b.n_reads
+    sync_all()
+    dt = time.perf_counter() - t0
+
+    tot = torch.tensor([float(samples), float(reads), dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt_max = float(mx[2])
+    else:
+        dt_max = dt
+    tot_samples, tot_reads = float(tot[0]), float(tot[1])
+
+    if rank == 0:
+        steps = max(args.steps, 1)
+        alg_bytes = (2 * samples + bases + 24 * reads) / steps           # per k_signal launch (this rank)
+        k_ms = float(np.mean(sig_ms)) if sig_ms else float("nan")
+        achieved = alg_bytes / (k_ms * 1e-3)
+        out = {
+            "metric": "simulated raw samples/sec",
+            "value": tot_samples / dt_max,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if args.mode == "exact" else "f32+f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"nCoV-2019.reference.fasta -x {args.profile} --seed 42 -r {args.rlen}, "
+                            f"-t {T} -K {T} (T=K virtual workers, {K} per GPU), {args.steps} batches "
+                            f"(BASELINE.json configs[1], n~100000)",
+                "reads_per_step_per_gpu": K, "kmer_size": k, "mode": args.mode,
+                "pore_model": "synthetic stand-in table (built-in ONT tables absent from the reference mount)",
+            },
+            "reads_per_s": tot_reads / dt_max,
+            "samples_per_step_per_gpu": samples / steps,
+            "kernel_ms": {"k_signal": k_ms, "k_dwell+k_scan": float(np.mean(dwell_ms)) if dwell_ms else None},
+            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S, "traffic": None,
+                         "kernel": "k_signal", "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if not args.no_store_probe:
+            out["roofline"]["measured_store_peak_GBps"] = gen.probe_store_bandwidth(1 << 30, 10) / 1e9
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prof, flags, k, mean, stdv, genome, args.rlen)
+        print(json.dumps(out))
+    for b in batches:
+        b.free()
+    gen.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

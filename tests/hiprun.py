@@ -6,6 +6,9 @@ import numpy as np
 from squigulator_amd import api, model, options
 
 
+LAST_FALLBACK = 0
+
+
 def run_hip_on_reads(cmdline, seqs, mode=api.MODE_EXACT, model_override=None, want_dwell=True):
     """seqs: the reads (bytes) in read order, as gen_read produced them.  Returns per-read dicts."""
     o = options.parse_args(cmdline)
@@ -16,12 +19,15 @@ def run_hip_on_reads(cmdline, seqs, mode=api.MODE_EXACT, model_override=None, wa
         mean, stdv = model.synthetic_model(k)
     gen = api.SignalGenerator(o.profile, o.flags, k, mean, stdv, o.seed, num_workers=o.threads,
                               amp_noise=o.amp_noise, mode=mode)
+    global LAST_FALLBACK
+    LAST_FALLBACK = 0
     out = []
     done, n = 0, len(seqs)
     start_time = 0
     while done < n:
         nb = min(o.batch, n - done)
         b = gen.stage(seqs[done:done + nb]).run().wait()
+        LAST_FALLBACK += gen.timing()["fallback_samples"]
         sig = b.signal()
         dw = b.dwell() if want_dwell else None
         for i in range(nb):

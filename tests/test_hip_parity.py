@@ -40,7 +40,7 @@ def _compare(got, want, what):
         assert g["start_time"] == w["start_time"]
 
 
-@pytest.mark.parametrize("mode", [api.MODE_EXACT], ids=["exact"])
+@pytest.mark.parametrize("mode", [api.MODE_EXACT, api.MODE_CERTIFIED], ids=["exact", "certified"])
 @pytest.mark.parametrize("cid,cmd", REFVEC_CASES, ids=[c[0] for c in REFVEC_CASES])
 def test_hip_matches_reference_vectors(cid, cmd, mode):
     v = np.load(os.path.join(VEC, cid + ".npz"))
@@ -57,13 +57,41 @@ def test_hip_matches_reference_vectors(cid, cmd, mode):
     "rnasequin_sequences_2.4.fa -x rna004-prom -n 24 --seed 13 -t 8 -K 8 --prefix=yes --dwell-std 5",
     "nCoV-2019.reference.fasta -x dna-r9-min -n 6 --seed 3 -r 1000 -t1 --dwell-mean 20 --dwell-std 30",
 ], ids=["r9_tk128", "r9_t5_k12", "r10_tk32", "rna9min_prefix", "rna004_prefix_dwellstd", "r9_wide_dwell"])
-def test_hip_matches_oracle(cmd):
+@pytest.mark.parametrize("mode", [api.MODE_EXACT, api.MODE_CERTIFIED], ids=["exact", "certified"])
+def test_hip_matches_oracle(cmd, mode):
     o, k, names, lengths, reads, orac = simrun.run_oracle(cmd, nthreads=8)
     orac.close()
     want = [dict(seq=r.seq, sig=r.sig, ss=r.ss, offset=r.offset, median=r.median_before, start_time=r.start_time)
             for r in reads]
-    got = hiprun.run_hip_on_reads(cmd, [w["seq"] for w in want])
+    got = hiprun.run_hip_on_reads(cmd, [w["seq"] for w in want], mode=mode)
     _compare(got, want, cmd)
+
+
+@pytest.mark.parametrize("delta", ["1.0", "3e-4"], ids=["all_fp64", "many_fp64"])
+def test_certified_fallback_branch_is_exact(delta, monkeypatch):
+    """The rare FP64 fix-up branch, FORCED: with an inflated error bound every (or ~1%) sample is
+    rejected by the fp32 acceptance test and recomputed by k_fixup; output must not change."""
+    cmd = "rnasequin_sequences_2.4.fa -x rna004-prom -n 12 --seed 21 -t 12 -K 12 --prefix=yes --dwell-std 4"
+    o, k, names, lengths, reads, orac = simrun.run_oracle(cmd, nthreads=8)
+    orac.close()
+    want = [dict(seq=r.seq, sig=r.sig, ss=r.ss, offset=r.offset, median=r.median_before, start_time=r.start_time)
+            for r in reads]
+    monkeypatch.setenv("SQG_TEST_DELTA_X", delta)
+    got = hiprun.run_hip_on_reads(cmd, [w["seq"] for w in want], mode=api.MODE_CERTIFIED)
+    _compare(got, want, cmd)
+    assert hiprun.LAST_FALLBACK > (0.5 if delta == "1.0" else 0.001) * sum(len(w["sig"]) for w in want)
+
+
+def test_certified_fallback_rate_is_small():
+    cmd = "nCoV-2019.reference.fasta -x dna-r9-prom -n 64 --seed 4 -r 4000 -t 64 -K 64"
+    o, k, names, lengths, reads, orac = simrun.run_oracle(cmd, nthreads=8)
+    orac.close()
+    want = [dict(seq=r.seq, sig=r.sig, ss=r.ss, offset=r.offset, median=r.median_before, start_time=r.start_time)
+            for r in reads]
+    got = hiprun.run_hip_on_reads(cmd, [w["seq"] for w in want], mode=api.MODE_CERTIFIED)
+    _compare(got, want, cmd)
+    total = sum(len(w["sig"]) for w in want)
+    assert 0 < hiprun.LAST_FALLBACK < 2e-3 * total, (hiprun.LAST_FALLBACK, total)
 
 
 def test_short_and_odd_reads():
