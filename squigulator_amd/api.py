@@ -68,7 +68,7 @@ def load_library(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or _build.LIB
+    path = path or os.environ.get("SQG_LIB") or _build.LIB   # SQG_LIB: A/B testing of kernel build variants
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build it with `python -m squigulator_amd.build` "
                            "(there is no CPU fallback for the signal path)")

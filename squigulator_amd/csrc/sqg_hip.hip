@@ -20,6 +20,9 @@
 
 #include "../../include/sqg.h"
 
+#ifndef SQG_SIGNAL_THREADS
+#define SQG_SIGNAL_THREADS 512   // events per segment = threads per workgroup of k_signal
+#endif
 #include "sqg_kernels.h"
 
 static uint32_t lcg_pow(uint32_t base, unsigned long long e) {
@@ -490,11 +493,12 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
             int32_t t = (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000u;
             P.shift = (int)(int16_t)(uint16_t)((uint32_t)t & 0xffffu);
         }
+        constexpr int NT = SQG_SIGNAL_THREADS;
         if (certified) {
-            hipLaunchKernelGGL(k_signal<1>, dim3((unsigned)b->n_chains), dim3(64), 0, c->stream, P);
+            hipLaunchKernelGGL((k_signal<1, NT>), dim3((unsigned)b->n_chains), dim3(NT), 0, c->stream, P);
             if (c->use_kmer_streams) hipLaunchKernelGGL(k_fixup, dim3(512), dim3(256), 0, c->stream, P);
         } else {
-            hipLaunchKernelGGL(k_signal<0>, dim3((unsigned)b->n_chains), dim3(64), 0, c->stream, P);
+            hipLaunchKernelGGL((k_signal<0, NT>), dim3((unsigned)b->n_chains), dim3(NT), 0, c->stream, P);
         }
         HIPCHK(c, hipGetLastError());
     }

@@ -116,10 +116,11 @@ struct ReadDesc {
 
 struct FixEntry {         // one sample handed to the FP64 path
     long long at;         // absolute index into the signal slab
+    long long ev;         // batch-wide event index (k-mer recomputed from the bases)
     uint32_t c1;          // first draw of the sample
-    uint32_t rank;
     int read;
     int shifted;          // inside the RNA adaptor level-shift window
+    int pad;
 };
 
 struct SigParams {
@@ -248,40 +249,190 @@ __global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restr
 }
 
 // ---- k_signal ------------------------------------------------------------------------------
-// One wavefront (workgroup of 64) per worker chain; everything is wave-synchronous.  A chain's
-// reads are walked in batch order, each read in tiles of 64 consecutive events:
-//   event phase : k-mer rank, dwell, exclusive scan -> first sample of each event; each k-mer
-//                 stream is handed out in event order (hashed last-writer tags find the rare
-//                 tiles in which two events share a k-mer; those are resolved lane-serially);
-//                 the stream state lives in HBM/L2 (rows[worker][rank]), read and advanced once
-//                 per event by an O(1) jump a^(2*sps).
-//   sample phase: 64 samples per step, contiguous int16 stores.  sample -> event by start-marker
-//                 bytes in LDS + ballot/mbcnt; draws by two modular multiplications with the
-//                 per-slot jump constants a^(2j+1), a^(2j+2) held in LDS.
-#define TAG_N 512
-#define MK_W 1024
-#define MULT_N 256
+// One workgroup of NT threads per worker chain (a worker's reads of this batch, in batch order).
+// A read is walked in segments of NT consecutive events, one event per thread:
+//   event phase  (whole workgroup): k-mer rank, dwell, block scan -> first sample of each event;
+//                hand-out of the per-(worker,k-mer) Lehmer streams IN EVENT ORDER: events are
+//                binned by k-mer in an LDS hash table, bin members listed via a block scan, and
+//                each event sums the dwell of the same-k-mer events before it (bins hold 1-3
+//                events).  Stream states live in HBM/L2 (rows[worker][rank]); one load and, for
+//                the last event of a bin, one store per event, by an O(1) jump a^(2*samples).
+//   sample phase (per wavefront, no block barriers): wave w emits the samples of events
+//                [64w, 64w+64) of the segment, 64 consecutive samples per step (contiguous int16
+//                stores).  sample -> event through start-marker bytes in LDS + ballot/mbcnt; the
+//                two draws of a sample are two modular multiplications of the event's state with
+//                per-slot constants a^(2j+1), a^(2j+2) held in LDS.
+#ifndef SQG_SIGNAL_WAVES_PER_SIMD
+#define SQG_SIGNAL_WAVES_PER_SIMD 4
+#endif
+#define MK_W 1024          // marker window (samples) per wavefront
+#define MULT_N 256         // LDS jump constants cover events of up to 256 samples
+#define BIN_EMPTY 0xffffffffu
 
+template <int NT>
 struct SigLds {
-    uint4 rec_a[64];          // {c_ev, first sample in tile, F | rank, sdk}
-    uint4 rec_b[64];          // {I, thr, rank, 0}
-    uint2 mult[MULT_N];       // {a^(2j+1), a^(2j+2)}
-    uint8_t mk[MK_W];         // event-start markers of the current sample window
-    uint8_t tag[TAG_N];       // hashed last-writer lane per k-mer
+    uint4 rec_a[NT];            // {c_ev, first sample in segment, F | level_mean, sdk | sd}
+    uint2 rec_b[NT];            // {I | constant sample, thr | rank}
+    uint32_t keys[2 * NT];      // hash bins: k-mer rank
+    uint32_t bins[2 * NT];      // events per bin; after the scan (first member slot << 16) | count
+    uint32_t mem[NT];           // bin members: (event index in segment << 16) | dwell
+    uint2 mult[MULT_N];         // {a^(2j+1), a^(2j+2)}
+    uint32_t jump[MULT_N];      // a^(2j)
+    uint8_t mk[NT / 64][MK_W];  // event-start markers, one window per wavefront
+    uint8_t lut[256];           // base -> 2-bit code
+    int wsum[NT / 64];
+    int wsum2[NT / 64];
 };
 
-template <int MODE>
-__global__ __launch_bounds__(64) void k_signal(const SigParams P) {
-    __shared__ SigLds L;
-    const int lane = threadIdx.x;
-    for (int i = lane; i < MULT_N; i += 64) L.mult[i] = make_uint2(P.pw[i], P.pw[POW_N + i]);
+__device__ static inline int wave_incl_scan(int v, int lane) {
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(v, o); if (lane >= o) v += y; }
+    return v;
+}
+
+template <int NT>
+__device__ static inline uint32_t jump2_lds(const SigLds<NT>& L, const uint32_t* __restrict__ pw, uint32_t n) {
+    return n < MULT_N ? L.jump[n] : lcg_jump2(pw, n);
+}
+
+// generic per-sample emitter: every option, both modes (used for tiles the fast loop excludes)
+template <int MODE, int NT>
+__device__ static void emit_generic(const SigParams& P, SigLds<NT>& L, int lane, int ev0, uint8_t* mk, bool valid,
+                                    int so_w, int wave_total, uint32_t base_pos, uint32_t read_len, int16_t* out,
+                                    long long sig_base, int r, long long ev_first, double offset,
+                                    long long shift_lo, long long n1, bool shift_tile) {
+    const unsigned long long lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);
+    for (int w0 = 0; w0 < wave_total; w0 += MK_W) {
+        ((uint4*)mk)[lane] = make_uint4(0, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (valid && so_w >= w0 && so_w < w0 + MK_W) mk[so_w - w0] = 1;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        int base_ev = __popcll(__ballot(valid && so_w < w0));
+        const int w_end = min(w0 + MK_W, wave_total);
+        for (int c0 = w0; c0 < w_end; c0 += 64) {
+            const int idx = c0 + lane;
+            const unsigned long long sm = __ballot(mk[idx - w0] != 0);
+            const int ev = ev0 + base_ev + __popcll(sm & lane_le) - 1;
+            base_ev += __popcll(sm);
+            if (idx < w_end) {
+                const uint4 ra = L.rec_a[ev];
+                const uint2 rb = L.rec_b[ev];
+                const uint32_t j = (uint32_t)idx - (ra.y - (uint32_t)(L.rec_a[ev0].y));   // sample within event
+                const uint32_t pos = base_pos + (uint32_t)idx;
+                const uint32_t at = P.rna ? (read_len - 1 - pos) : pos;
+                const bool in_shift = shift_tile && (long long)pos >= shift_lo && (long long)pos < n1;
+                int16_t q;
+                bool ok = true;
+                uint32_t c1 = 1;
+                if (!P.use_streams) {
+                    q = (int16_t)(uint16_t)rb.x;
+                } else {
+                    if (j < MULT_N) c1 = lcg_mul(ra.x, L.mult[j].x);
+                    else c1 = lcg_mul(lcg_mul(ra.x, lcg_jump2(P.pw, j)), LCG_A);
+                    if (MODE == 1) {
+                        const float x = box_muller_fast(c1, lcg_mul_lazy(c1, LCG_A));
+                        const float v = __builtin_fmaf(x, __uint_as_float(ra.w), __uint_as_float(ra.z));
+                        const float fl = floorf(v);
+                        const float fr = v - fl;
+                        ok = fabsf(fr - 0.5f) < __uint_as_float(rb.y) && c1 <= LCG_M - (1u << NEAR_ONE_BITS);
+                        int n = (int)rb.x + (int)fl;
+                        n -= n >> 31;                                      // truncation toward zero (value is not an integer)
+                        q = (int16_t)(uint16_t)((uint32_t)n & 0xffffu);
+                    } else {
+                        const double z = box_muller_exact(c1, lcg_mul(c1, LCG_A));
+                        const float sv = (float)((z * (double)__uint_as_float(ra.w)) + (double)__uint_as_float(ra.z));   // src/gensig.c:268
+                        q = to_i16((double)sv * P.dig / P.range - offset);                                             // src/gensig.c:270
+                    }
+                }
+                if (in_shift) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);
+                if (ok) out[at] = q;
+                if (MODE == 1) {
+                    const unsigned long long am = __ballot(!ok);
+                    if (am) {                                              // hand the undecided samples to k_fixup
+                        unsigned int slot0 = 0;
+                        const int leader = __ffsll((long long)am) - 1;
+                        if (lane == leader) slot0 = atomicAdd(P.fix_count, (unsigned int)__popcll(am));
+                        slot0 = __shfl(slot0, leader);
+                        if (!ok) {
+                            const unsigned int slot = slot0 + (unsigned int)__popcll(am & lane_le) - 1u;
+                            if (slot < P.fix_cap) {
+                                FixEntry fe; fe.at = sig_base + at; fe.c1 = c1; fe.ev = ev_first + ev; fe.read = r; fe.shifted = in_shift;
+                                P.fix[slot] = fe;
+                            } else atomicOr(P.err, 8u);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// the hot loop: certified mode, events of <= MULT_N samples, no level-shift window, positive ADC values
+template <int NT>
+__device__ static inline void emit_fast(const SigParams& P, SigLds<NT>& L, int lane, int ev0, uint8_t* mk, bool valid,
+                                        int so_w, int wave_total, uint32_t base_pos, uint32_t read_len, int16_t* out,
+                                        long long sig_base, int r, long long ev_first, float thr, uint32_t so_first) {
+    const unsigned long long lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);
+    const bool rna = P.rna != 0;
+    const uint32_t a_top = read_len - 1 - base_pos;
+    for (int w0 = 0; w0 < wave_total; w0 += MK_W) {
+        ((uint4*)mk)[lane] = make_uint4(0, 0, 0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (valid && so_w >= w0 && so_w < w0 + MK_W) mk[so_w - w0] = 1;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        int base_ev = ev0 - 1 + __popcll(__ballot(valid && so_w < w0));
+        const int w_end = min(w0 + MK_W, wave_total);
+        for (int c0 = w0; c0 < w_end; c0 += 64) {
+            const int idx = c0 + lane;
+            const unsigned long long sm = __ballot(mk[idx - w0] != 0);
+            const int ev = base_ev + __popcll(sm & lane_le);
+            base_ev += __popcll(sm);
+            const uint4 ra = L.rec_a[ev];
+            const int I = (int)L.rec_b[ev].x;
+            const uint32_t j = ((uint32_t)idx + so_first - ra.y) & (MULT_N - 1);
+            const uint2 mu = L.mult[j];
+            const uint32_t c1 = lcg_mul(ra.x, mu.x);
+            const uint32_t r2 = lcg_mul_lazy(ra.x, mu.y);
+            const float x = box_muller_fast(c1, r2);
+            const float v = __builtin_fmaf(x, __uint_as_float(ra.w), __uint_as_float(ra.z));
+            const float fl = floorf(v);
+            const float fr = v - fl;
+            const bool act = idx < w_end;
+            const bool ok = fabsf(fr - 0.5f) < thr && c1 <= LCG_M - (1u << NEAR_ONE_BITS);
+            const int n = I + (int)fl;
+            const uint32_t at = rna ? (a_top - (uint32_t)idx) : (base_pos + (uint32_t)idx);
+            if (act && ok) out[at] = (int16_t)(uint16_t)((uint32_t)n & 0xffffu);
+            const unsigned long long am = __ballot(act && !ok);
+            if (am) {
+                unsigned int slot0 = 0;
+                const int leader = __ffsll((long long)am) - 1;
+                if (lane == leader) slot0 = atomicAdd(P.fix_count, (unsigned int)__popcll(am));
+                slot0 = __shfl(slot0, leader);
+                if (act && !ok) {
+                    const unsigned int slot = slot0 + (unsigned int)__popcll(am & lane_le) - 1u;
+                    if (slot < P.fix_cap) {
+                        FixEntry fe; fe.at = sig_base + at; fe.c1 = c1; fe.ev = ev_first + ev; fe.read = r; fe.shifted = 0;
+                        P.fix[slot] = fe;
+                    } else atomicOr(P.err, 8u);
+                }
+            }
+        }
+    }
+}
+
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT, SQG_SIGNAL_WAVES_PER_SIMD) void k_signal(const SigParams P) {
+    __shared__ SigLds<NT> L;
+    constexpr int NW = NT / 64, HT = 2 * NT;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < MULT_N; i += NT) { L.mult[i] = make_uint2(P.pw[i], P.pw[POW_N + i]); L.jump[i] = P.pw[2 * POW_N + i]; }
+    for (int i = tid; i < 256; i += NT) L.lut[i] = (uint8_t)base_code((uint8_t)i);
 
     const int chain = P.chain_order[blockIdx.x];
     const int c_lo = P.chain_off[chain], c_hi = P.chain_off[chain + 1];
     uint32_t* row = P.rows ? P.rows + (size_t)P.reads[P.chain_reads[c_lo]].worker * P.num_kmer : nullptr;
     const int k = P.k;
-    const double dig = P.dig, range = P.range, kd = P.kd;
-    const unsigned long long lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);   // lanes <= me
+    const double kd = P.kd;
+    uint8_t* mk = L.mk[wid];
     __syncthreads();
 
     for (int ci = c_lo; ci < c_hi; ci++) {
@@ -296,61 +447,83 @@ __global__ __launch_bounds__(64) void k_signal(const SigParams P) {
         int16_t* out = P.sig + sig_base;
         uint32_t done = 0;                                            // samples emitted so far in this read
 
-        for (int t0 = 0; t0 < ne; t0 += 64) {
-            // ---------------- event phase ----------------
-            const int e = t0 + lane;
+        for (int s0 = 0; s0 < ne; s0 += NT) {
+            // ================= event phase =================
+            const int e = s0 + tid;
             const bool valid = e < ne;
             uint32_t rank = 0;
             int sps = 0;
             if (valid) {
-                const long long bp = rd.base_off + (e < rd.ne0 ? (long long)e : (long long)rd.len0 + (e - rd.ne0));
-                for (int i = 0; i < k; i++) rank = (rank << 2) | base_code(P.bases[bp + i]);   // src/seq.h:31-42
+                const uint8_t* bp = P.bases + rd.base_off + (e < rd.ne0 ? (long long)e : (long long)rd.len0 + (e - rd.ne0));
+                for (int i = 0; i < k; i++) rank = (rank << 2) | L.lut[bp[i]];                 // src/seq.h:31-42
                 sps = P.dwell ? (int)P.dwell[rd.ev_off + e] : P.const_sps;
             }
-            int incl = sps;
-            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
-            const int tile_total = __shfl(incl, 63);
-            const int so = incl - sps;
+            const float2 md = valid ? P.model[rank] : make_float2(0.f, 0.f);
+            const int incl = wave_incl_scan(sps, lane);
+            if (lane == 63) L.wsum[wid] = incl;
+            if (P.use_streams) for (int i = tid; i < HT; i += NT) { L.keys[i] = BIN_EMPTY; L.bins[i] = 0; }
+            __syncthreads();                                                                  // (1)
+            int woff = 0, seg_total = 0;
+            for (int w = 0; w < NW; w++) { const int x = L.wsum[w]; if (w < wid) woff += x; seg_total += x; }
+            const int so = woff + incl - sps;                 // first sample of my event within the segment
+            const int wave_total = __shfl(incl, 63);
 
             uint32_t c_ev = 0;
             if (P.use_streams) {
-                const uint32_t h = (rank ^ (rank >> 9)) & (TAG_N - 1);
-                if (valid) L.tag[h] = (uint8_t)lane;
-                __syncthreads();
-                const bool loser = valid && L.tag[h] != (uint8_t)lane;
-                unsigned long long lm = __ballot(loser);
-                int prior = 0;            // samples earlier events of this tile drew from my stream
-                bool last = true;         // last event of my k-mer in this tile: I store the new state
-                while (lm) {
-                    const int l = __ffsll((long long)lm) - 1;
-                    const uint32_t rl = __shfl(rank, l);
-                    const bool in_g = valid && rank == rl;
-                    const unsigned long long g = __ballot(in_g);
-                    unsigned long long gg = g;
-                    while (gg) {
-                        const int j = __ffsll((long long)gg) - 1;
-                        gg &= gg - 1;
-                        const int sj = __shfl(sps, j);
-                        if (in_g && lane > j) prior += sj;
+                uint32_t h = (rank * 2654435761u) >> (32 - (31 - __builtin_clz(HT)));
+                uint32_t ord = 0;
+                if (valid) {
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&L.keys[h], BIN_EMPTY, rank);
+                        if (old == BIN_EMPTY || old == rank) break;
+                        h = (h + 1) & (HT - 1);
                     }
-                    if (in_g) last = (lane == 63 - __clzll((long long)g));
-                    lm &= ~g;
+                    ord = atomicAdd(&L.bins[h], 1u);
+                }
+                __syncthreads();                                                              // (2)
+                const uint32_t b0 = L.bins[2 * tid], b1 = L.bins[2 * tid + 1];
+                const int local = (int)(b0 + b1);
+                const int incl2 = wave_incl_scan(local, lane);
+                if (lane == 63) L.wsum2[wid] = incl2;
+                __syncthreads();                                                              // (3)
+                int woff2 = 0;
+                for (int w = 0; w < wid; w++) woff2 += L.wsum2[w];
+                const uint32_t ex = (uint32_t)(woff2 + incl2 - local);
+                L.bins[2 * tid] = (ex << 16) | b0;
+                L.bins[2 * tid + 1] = ((ex + b0) << 16) | b1;
+                __syncthreads();                                                              // (4)
+                uint32_t bv = 0;
+                if (valid) { bv = L.bins[h]; L.mem[(bv >> 16) + ord] = ((uint32_t)tid << 16) | (uint32_t)sps; }
+                __syncthreads();                                                              // (5)
+                uint32_t prior = 0, total = (uint32_t)sps;
+                bool last = true;
+                if (valid && (bv & 0xffffu) > 1u) {
+                    total = 0;
+                    const uint32_t m0 = bv >> 16, mc = bv & 0xffffu;
+                    for (uint32_t m = 0; m < mc; m++) {
+                        const uint32_t v = L.mem[m0 + m];
+                        const uint32_t t2 = v >> 16, s2 = v & 0xffffu;
+                        total += s2;
+                        if (t2 < (uint32_t)tid) prior += s2;
+                        if (t2 > (uint32_t)tid) last = false;
+                    }
                 }
                 uint32_t c_row = 0;
                 if (valid) c_row = __hip_atomic_load(&row[rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();          // every lane has its state before any lane advances a stream
+                __syncthreads();                                                              // (6) all states read before any is advanced
                 if (valid) {
-                    c_ev = prior ? lcg_mul(c_row, lcg_jump2(P.pw, (uint32_t)prior)) : c_row;
-                    if (last) __hip_atomic_store(&row[rank], lcg_mul(c_ev, lcg_jump2(P.pw, (uint32_t)sps)),
+                    c_ev = prior ? lcg_mul(c_row, jump2_lds(L, P.pw, prior)) : c_row;
+                    if (last) __hip_atomic_store(&row[rank], lcg_mul(c_row, jump2_lds(L, P.pw, total)),
                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-            const float2 md = valid ? P.model[rank] : make_float2(0.f, 0.f);
+            float thr = 1.0f;
+            bool fast_ok = true;
             if (!P.use_streams) {
                 // no amplitude noise (--ideal / --ideal-amp): s = level_mean, one digitisation per event (src/gensig.c:266,270)
-                const int16_t qc = to_i16((double)md.x * dig / range - offset);
-                L.rec_a[lane] = make_uint4(0u, valid ? (uint32_t)so : 0xffffffffu, 0u, 0u);
-                L.rec_b[lane] = make_uint4((uint32_t)(uint16_t)qc, 0u, rank, 0u);
+                const int16_t qc = to_i16((double)md.x * P.dig / P.range - offset);
+                L.rec_a[tid] = make_uint4(0u, (uint32_t)so, 0u, 0u);
+                L.rec_b[tid] = make_uint2((uint32_t)(uint16_t)qc, 0u);
             } else if (MODE == 1) {
                 // v = s_f*dig/range - offset  ~  x*(sd*kd) + (m*kd - offset) = x*sdk + (I + F)
                 const double mkd = (double)md.x * kd;
@@ -358,97 +531,45 @@ __global__ __launch_bounds__(64) void k_signal(const SigParams P) {
                 const double fl = floor(mk);
                 const float F = (float)(mk - fl);
                 const float sdk = (float)((double)md.y * kd);
+                const float asdk = fabsf(sdk);
                 // error budget (DESIGN.md "Certified fast path"): swept |x'-x| * sdk; float narrowing of s
                 // (2^-24 (|m| kd + 6.56 sdk)); roundings of sdk (x6.56), of F (2^-25) and of the fma
                 // (2^-24 (6.56 sdk + 1)); FP64 roundings and the fp32 evaluation of eps itself in the slack
-                const float asdk = fabsf(sdk);
                 const float eps = P.delta_x * asdk + 5.9604645e-8f * ((float)fabs(mkd) + 21.0f * asdk + 3.0f) + 2.0e-7f;
-                float thr = 0.5f - eps;
+                thr = 0.5f - eps;
                 if (!(fabs(fl) < 1.0e9)) thr = -1.0f;                     // absurd profile: everything goes to FP64
-                L.rec_a[lane] = make_uint4(c_ev, valid ? (uint32_t)so : 0xffffffffu, __float_as_uint(F), __float_as_uint(sdk));
-                L.rec_b[lane] = make_uint4((uint32_t)(int)fl, __float_as_uint(thr), rank, 0u);
+                fast_ok = !valid || (sps <= MULT_N && fl - 7.0 * (double)asdk > 2.0 && fl < 1.0e9);
+                L.rec_a[tid] = make_uint4(c_ev, (uint32_t)so, __float_as_uint(F), __float_as_uint(sdk));
+                L.rec_b[tid] = make_uint2((uint32_t)(int)fl, __float_as_uint(thr));
             } else {
-                L.rec_a[lane] = make_uint4(c_ev, valid ? (uint32_t)so : 0xffffffffu, __float_as_uint(md.x), __float_as_uint(md.y));
+                L.rec_a[tid] = make_uint4(c_ev, (uint32_t)so, __float_as_uint(md.x), __float_as_uint(md.y));
+                L.rec_b[tid] = make_uint2(0u, 0u);
             }
+            __syncthreads();                                                                  // (7)
 
-            // ---------------- sample phase ----------------
-            const bool shift_tile = P.shift_len > 0 && (long long)done + tile_total > shift_lo && (long long)done < n1;
-            for (int w0 = 0; w0 < tile_total; w0 += MK_W) {
-                __syncthreads();
-                ((uint4*)L.mk)[lane] = make_uint4(0, 0, 0, 0);
-                __syncthreads();
-                if (valid && so >= w0 && so < w0 + MK_W) L.mk[so - w0] = 1;
-                __syncthreads();
-                int base_ev = __popcll(__ballot(valid && so < w0));     // events begun before this window
-                const int w_end = min(w0 + MK_W, tile_total);
-                for (int s0 = w0; s0 < w_end; s0 += 64) {
-                    const int idx = s0 + lane;
-                    const bool act = idx < w_end;
-                    const unsigned long long sm = __ballot(act && L.mk[idx - w0] != 0);
-                    const int ev = base_ev + __popcll(sm & lane_le) - 1;
-                    base_ev += __popcll(sm);
-                    if (act) {
-                        const uint4 ra = L.rec_a[ev];
-                        const uint32_t j = (uint32_t)idx - ra.y;
-                        uint32_t c1, r2;
-                        if (P.use_streams) {
-                            if (j < MULT_N) {
-                                const uint2 mu = L.mult[j];
-                                c1 = lcg_mul(ra.x, mu.x);
-                                r2 = MODE == 1 ? lcg_mul_lazy(ra.x, mu.y) : 0u;
-                            } else {
-                                c1 = lcg_mul(lcg_mul(ra.x, lcg_jump2(P.pw, j)), LCG_A);
-                                r2 = lcg_mul(c1, LCG_A);
-                            }
-                        } else { c1 = 1; r2 = 1; }
-                        (void)r2;
-                        const uint32_t pos = done + (uint32_t)idx;                 // index within the read, generation order
-                        const uint32_t at = P.rna ? (read_len - 1 - pos) : pos;
-                        const bool in_shift = shift_tile && (long long)pos >= shift_lo && (long long)pos < n1;
-                        if (!P.use_streams) {
-                            int16_t q = (int16_t)(uint16_t)L.rec_b[ev].x;
-                            if (in_shift) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);
-                            out[at] = q;
-                        } else if (MODE == 1) {
-                            const uint4 rb = L.rec_b[ev];
-                            const float x = box_muller_fast(c1, r2);
-                            const float v = __builtin_fmaf(x, __uint_as_float(ra.w), __uint_as_float(ra.z));
-                            const float fl = floorf(v);
-                            const float fr = v - fl;
-                            const bool ok = fabsf(fr - 0.5f) < __uint_as_float(rb.y) && c1 <= LCG_M - (1u << NEAR_ONE_BITS);
-                            int n = (int)rb.x + (int)fl;
-                            n -= n >> 31;                                          // truncation toward zero (value is not an integer)
-                            int16_t q = (int16_t)(uint16_t)((uint32_t)n & 0xffffu);
-                            if (in_shift) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);
-                            if (ok) out[at] = q;
-                            const unsigned long long am = __ballot(!ok);
-                            if (am) {                                              // hand the undecided samples to k_fixup
-                                unsigned int slot0 = 0;
-                                const int leader = __ffsll((long long)am) - 1;
-                                if (lane == leader) slot0 = atomicAdd(P.fix_count, (unsigned int)__popcll(am));
-                                slot0 = __shfl(slot0, leader);
-                                if (!ok) {
-                                    const unsigned int slot = slot0 + (unsigned int)__popcll(am & lane_le) - 1u;
-                                    if (slot < P.fix_cap) {
-                                        FixEntry fe; fe.at = sig_base + at; fe.c1 = c1; fe.rank = rb.z; fe.read = r; fe.shifted = in_shift;
-                                        P.fix[slot] = fe;
-                                    } else atomicOr(P.err, 8u);
-                                }
-                            }
-                        } else {
-                            const double z = box_muller_exact(c1, lcg_mul(c1, LCG_A));
-                            const float sv = (float)((z * (double)__uint_as_float(ra.w)) + (double)__uint_as_float(ra.z));   // src/gensig.c:268
-                            int16_t q = to_i16((double)sv * dig / range - offset);                                        // src/gensig.c:270
-                            if (in_shift) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);
-                            out[at] = q;
-                        }
+            // ================= sample phase (wave-local) =================
+            if (wave_total > 0) {
+                const uint32_t base_pos = done + (uint32_t)woff;
+                const bool shift_tile = P.shift_len > 0 && (long long)base_pos + wave_total > shift_lo && (long long)base_pos < n1;
+                const int so_w = so - woff;
+                bool use_fast = false;
+                if (MODE == 1 && P.use_streams && !shift_tile) {
+                    use_fast = __all(fast_ok);
+                    if (use_fast) {
+                        float t = valid ? thr : 1.0f;
+                        for (int o = 32; o > 0; o >>= 1) t = fminf(t, __shfl_xor(t, o));
+                        thr = t;
                     }
                 }
+                if (use_fast) emit_fast<NT>(P, L, lane, wid * 64, mk, valid, so_w, wave_total, base_pos, read_len, out,
+                                            sig_base, r, rd.ev_off + s0, thr, (uint32_t)woff);
+                else emit_generic<MODE, NT>(P, L, lane, wid * 64, mk, valid, so_w, wave_total, base_pos, read_len, out,
+                                            sig_base, r, rd.ev_off + s0, offset, shift_lo, n1, shift_tile);
             }
-            done += (uint32_t)tile_total;
-            __syncthreads();
+            done += (uint32_t)seg_total;
+            __syncthreads();                                                                  // (8)
         }
-        if (done != read_len && lane == 0) atomicOr(P.err, 4u);
+        if (done != read_len && tid == 0) atomicOr(P.err, 4u);
     }
 }
 
@@ -457,8 +578,13 @@ __global__ __launch_bounds__(256) void k_fixup(const SigParams P) {
     const unsigned int n = min(*P.fix_count, P.fix_cap);
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const FixEntry fe = P.fix[i];
-        const float2 md = P.model[fe.rank];
-        int16_t q = sample_exact(fe.c1, md.x, md.y, P.dig, P.range, P.reads[fe.read].offset);
+        const ReadDesc rd = P.reads[fe.read];
+        const int e = (int)(fe.ev - rd.ev_off);
+        const uint8_t* bp = P.bases + rd.base_off + (e < rd.ne0 ? (long long)e : (long long)rd.len0 + (e - rd.ne0));
+        uint32_t rank = 0;
+        for (int q = 0; q < P.k; q++) rank = (rank << 2) | base_code(bp[q]);
+        const float2 md = P.model[rank];
+        int16_t q = sample_exact(fe.c1, md.x, md.y, P.dig, P.range, rd.offset);
         if (fe.shifted) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);
         P.sig[fe.at] = q;
     }
