@@ -113,8 +113,9 @@ typedef struct {
 
 /* kernel timings of the last sqg_batch_run, from hipEvents on the context's stream */
 typedef struct {
-    float dwell_ms;             /* dwell_and_scan kernels                                    */
-    float signal_ms;            /* emit_samples kernel (the dominant, roofline-priced one)   */
+    float dwell_ms;             /* k_dwell + k_scan                                          */
+    float events_ms;            /* k_events (k-mer ranks, stream hand-out)                   */
+    float samples_ms;           /* k_samples (+ k_fixup): the dominant, roofline-priced part */
     float total_ms;             /* first launch to last completion                           */
     int64_t fallback_samples;   /* CERTIFIED mode: samples recomputed on the FP64 path       */
 } sqg_timing_t;

@@ -52,8 +52,8 @@ class CResult(C.Structure):
 
 
 class CTiming(C.Structure):
-    _fields_ = [("dwell_ms", C.c_float), ("signal_ms", C.c_float), ("total_ms", C.c_float),
-                ("fallback_samples", C.c_int64)]
+    _fields_ = [("dwell_ms", C.c_float), ("events_ms", C.c_float), ("samples_ms", C.c_float),
+                ("total_ms", C.c_float), ("fallback_samples", C.c_int64)]
 
 
 EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_device_count",
@@ -217,8 +217,8 @@ class SignalGenerator:
     def timing(self):
         t = CTiming()
         self._chk(self.L.sqg_get_timing(self.ctx, C.byref(t)), "sqg_get_timing")
-        return {"dwell_ms": t.dwell_ms, "signal_ms": t.signal_ms, "total_ms": t.total_ms,
-                "fallback_samples": t.fallback_samples}
+        return {"dwell_ms": t.dwell_ms, "events_ms": t.events_ms, "samples_ms": t.samples_ms,
+                "total_ms": t.total_ms, "fallback_samples": t.fallback_samples}
 
     def probe_store_bandwidth(self, nbytes=1 << 30, iters=10) -> float:
         ms = C.c_float()

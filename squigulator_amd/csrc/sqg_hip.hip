@@ -20,9 +20,6 @@
 
 #include "../../include/sqg.h"
 
-#ifndef SQG_SIGNAL_THREADS
-#define SQG_SIGNAL_THREADS 512   // events per segment = threads per workgroup of k_signal
-#endif
 #include "sqg_kernels.h"
 
 static uint32_t lcg_pow(uint32_t base, unsigned long long e) {
@@ -38,7 +35,6 @@ struct sqg_ctx {
     sqg_cfg_t cfg;
     int k = 0, num_kmer = 0, T = 0, wlo = 0, whi = 0, nw = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t* d_rows = nullptr;
     float2* d_model = nullptr;
     uint32_t* d_pow = nullptr;
@@ -49,13 +45,16 @@ struct sqg_ctx {
     std::vector<uint32_t> time_c;          // canonical time-stream state per local worker
     std::vector<long long> off_x, med_x;   // raw Schrage states (as the reference keeps them)
     unsigned long long next_stage = 0, next_run = 0;
-    sqg_timing_t timing = {0, 0, 0, 0};
+    sqg_timing_t timing = {0, 0, 0, 0, 0};
     bool use_dwell_stream = true, use_kmer_streams = true;
     float delta_x = 0.f;                   // certified mode: swept |x_fast - x_exact| bound incl. margin
     float delta_x_measured = 0.f;
     bool force_fix = false;
     FixEntry* d_fix = nullptr; size_t fix_cap = 0;
-    unsigned int* d_fix_count = nullptr;
+    unsigned int* d_fix_count = nullptr;       // [0] fix-up entries, [1] slow tiles
+    uint2* d_evrec = nullptr; size_t evrec_cap = 0;
+    uint32_t* d_tile_so = nullptr; size_t tile_cap = 0;
+    int* d_slow = nullptr; size_t slow_cap = 0;
     std::string err;
 };
 
@@ -73,8 +72,10 @@ struct sqg_batch {
     int* d_chain_off = nullptr;
     int* d_chain_reads = nullptr;
     int* d_chain_order = nullptr;
-    unsigned int fix_used = 0;
+    int* d_tile_read = nullptr;
+    long long n_tiles = 0;
     long long* h_sigoff = nullptr;   // pinned
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel-phase boundaries on the stream
     bool ran = false, waited = false;
 };
 
@@ -144,7 +145,7 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err);
     (void)hipFree(ctx->d_sig); (void)hipFree(ctx->d_dwell); (void)hipFree(ctx->d_seglen); (void)hipFree(ctx->d_sigoff);
     (void)hipFree(ctx->d_fix); (void)hipFree(ctx->d_fix_count);
-    for (auto& e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    (void)hipFree(ctx->d_evrec); (void)hipFree(ctx->d_tile_so); (void)hipFree(ctx->d_slow);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -181,7 +182,6 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
 #define CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = (e_ == hipErrorOutOfMemory) ? SQG_ENOMEM : SQG_EDEVICE; fprintf(stderr, "[sqg] %s: %s\n", #call, hipGetErrorString(e_)); return fail(rc); } } while (0)
     CHK(hipSetDevice(cfg->device));
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (auto& e : c->ev) CHK(hipEventCreate(&e));
 
     // pore model: {level_mean, (float)(level_stdv*amp_noise)}  (src/sim.c:249)
     std::vector<float2> hm((size_t)nk);
@@ -214,8 +214,8 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     CHK(hipMemcpy(c->d_pow, pw.data(), pw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     CHK(hipMalloc(&c->d_err, sizeof(unsigned int)));
     CHK(hipMemset(c->d_err, 0, sizeof(unsigned int)));
-    CHK(hipMalloc(&c->d_fix_count, sizeof(unsigned int)));
-    CHK(hipMemset(c->d_fix_count, 0, sizeof(unsigned int)));
+    CHK(hipMalloc(&c->d_fix_count, 2 * sizeof(unsigned int)));
+    CHK(hipMemset(c->d_fix_count, 0, 2 * sizeof(unsigned int)));
     if (cfg->mode == SQG_MODE_CERTIFIED) {
         // exhaustive sweep of the fp32 deviate against the FP64 one on THIS device (~25 ms):
         // the bound the acceptance test uses is measured, not assumed
@@ -260,7 +260,7 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
 
 static int ensure(sqg_ctx* c, void** p, size_t* cap, size_t need, size_t elem) {
     if (need <= *cap) return SQG_OK;
-    size_t ncap = std::max(need, *cap + *cap / 2);
+    size_t ncap = std::max(need + need / 4, *cap + *cap / 2);     // slack: batches of similar size never re-allocate
     if (*p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(*p)); *p = nullptr; *cap = 0; }
     HIPCHK(c, hipMalloc(p, ncap * elem));
     *cap = ncap;
@@ -278,8 +278,9 @@ extern "C" void sqg_batch_free(sqg_ctx_t* ctx, sqg_batch_t* b) {
     if (!b) return;
     if (ctx) { (void)hipSetDevice(ctx->cfg.device); if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); }
     (void)hipFree(b->d_bases); (void)hipFree(b->d_reads); (void)hipFree(b->d_blk_read);
-    (void)hipFree(b->d_chain_off); (void)hipFree(b->d_chain_reads); (void)hipFree(b->d_chain_order);
+    (void)hipFree(b->d_chain_off); (void)hipFree(b->d_chain_reads); (void)hipFree(b->d_chain_order); (void)hipFree(b->d_tile_read);
     if (b->h_sigoff) (void)hipHostFree(b->h_sigoff);
+    for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -321,6 +322,16 @@ extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const 
         nb += l0 + l1; nev += ne0 + ne1;
     }
     b->ev_off[(size_t)n] = nev; b->n_events = nev; b->n_bases = nb;
+    // 64-event tiles (the work unit of k_samples); a tile never spans two reads
+    long long ntile = 0;
+    for (int i = 0; i < n; i++) { rd[(size_t)i].tile_off = (int)ntile; rd[(size_t)i].pad = 0; ntile += (rd[(size_t)i].ne0 + rd[(size_t)i].ne1 + 63) / 64; }
+    if (ntile > 2000000000LL) { delete b; c->err = "batch too large"; return SQG_EINVAL; }
+    b->n_tiles = ntile;
+    std::vector<int> tile_read((size_t)std::max<long long>(ntile, 1));
+    for (int i = 0; i < n; i++) {
+        const int t1 = (i + 1 < n) ? rd[(size_t)i + 1].tile_off : (int)ntile;
+        for (int t = rd[(size_t)i].tile_off; t < t1; t++) tile_read[(size_t)t] = i;
+    }
 
     // pass 2: base buffer (prefix/stall attached as src/genread.c:95-123 does)
     std::vector<uint8_t> hb((size_t)nb + 16, (uint8_t)'A');
@@ -410,9 +421,12 @@ extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const 
     CHKB(hipMemcpyAsync(b->d_chain_off, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     CHKB(hipMalloc(&b->d_chain_reads, std::max<size_t>(1, chain_reads.size()) * sizeof(int)));
     if (n) CHKB(hipMemcpyAsync(b->d_chain_reads, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    CHKB(hipMalloc(&b->d_tile_read, tile_read.size() * sizeof(int)));
+    CHKB(hipMemcpyAsync(b->d_tile_read, tile_read.data(), tile_read.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     CHKB(hipMalloc(&b->d_chain_order, std::max<size_t>(1, chain_order.size()) * sizeof(int)));
     if (b->n_chains) CHKB(hipMemcpyAsync(b->d_chain_order, chain_order.data(), chain_order.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     CHKB(hipHostMalloc(&b->h_sigoff, ((size_t)n + 1) * sizeof(long long), hipHostMallocDefault));
+    for (auto& e : b->ev) CHKB(hipEventCreate(&e));
     CHKB(hipStreamSynchronize(c->stream));     // staging buffers above are stack-owned
 #undef CHKB
     c->next_stage++;
@@ -437,8 +451,11 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
         c->reads_cap = cap;
     }
     if ((rc = ensure(c, (void**)&c->d_dwell, &c->dwell_cap, (size_t)b->n_events + 64, sizeof(uint16_t)))) return rc;
+    if ((rc = ensure(c, (void**)&c->d_evrec, &c->evrec_cap, (size_t)b->n_events + 64, sizeof(uint2)))) return rc;
+    if ((rc = ensure(c, (void**)&c->d_tile_so, &c->tile_cap, (size_t)b->n_tiles + 64, sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(c, (void**)&c->d_slow, &c->slow_cap, (size_t)b->n_tiles + 64, sizeof(int)))) return rc;
 
-    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(c, hipEventRecord(b->ev[0], c->stream));
     if (n > 0) {
         if (c->use_dwell_stream) {
             HIPCHK(c, hipMemsetAsync(c->d_seglen, 0, (size_t)2 * n * sizeof(unsigned long long), c->stream));
@@ -458,23 +475,34 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_seglen, n, c->d_sigoff, c->d_err);
         HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    // output size is data-dependent: read the scan back (tiny), size the slab, then emit
-    if (n > 0) {
-        HIPCHK(c, hipMemcpyAsync(b->h_sigoff, c->d_sigoff, ((size_t)n + 1) * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    } else {
-        b->h_sigoff[0] = 0;
+    HIPCHK(c, hipEventRecord(b->ev[1], c->stream));
+    // Output size is data-dependent.  A hard bound exists (|z| <= sqrt(2 ln(2^31-1)) = 6.5546 for any
+    // draw), so the slab is sized by it and the launches continue without a host round trip; only
+    // if that bound is unreasonable (huge dwell spread) is the scan read back first.
+    if (n > 0) HIPCHK(c, hipMemcpyAsync(b->h_sigoff, c->d_sigoff, ((size_t)n + 1) * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
+    else b->h_sigoff[0] = 0;
+    size_t need_samples;
+    {
+        double hi = 1.0;
+        if (c->use_dwell_stream) {
+            const double a = std::floor(p.dwell_mean + 6.5546 * std::fabs(p.dwell_std) + 0.5);
+            const double z = std::floor(std::fabs(p.dwell_mean - 6.5546 * std::fabs(p.dwell_std)) + 0.5) + 1.0;
+            hi = std::max(std::max(a, z), 1.0) + 1.0;
+        } else hi = (double)(int)p.dwell_mean;
+        const double bound = hi * (double)b->n_events;
+        if (bound <= 4.0e10) need_samples = (size_t)bound;
+        else {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            need_samples = (size_t)b->h_sigoff[n];
+        }
     }
-    b->n_samples = b->h_sigoff[n];
-    for (int i = 0; i <= n; i++) b->sig_off[(size_t)i] = b->h_sigoff[i];
-    if ((rc = ensure(c, (void**)&c->d_sig, &c->sig_cap, (size_t)b->n_samples + 64, sizeof(int16_t)))) return rc;
+    if ((rc = ensure(c, (void**)&c->d_sig, &c->sig_cap, need_samples + 64, sizeof(int16_t)))) return rc;
     if (certified && c->use_kmer_streams) {
-        if ((rc = ensure(c, (void**)&c->d_fix, &c->fix_cap, (c->force_fix ? (size_t)b->n_samples : (size_t)b->n_samples / 128) + 65536, sizeof(FixEntry)))) return rc;
-        HIPCHK(c, hipMemsetAsync(c->d_fix_count, 0, sizeof(unsigned int), c->stream));
+        if ((rc = ensure(c, (void**)&c->d_fix, &c->fix_cap, (c->force_fix ? need_samples : need_samples / 256) + 65536, sizeof(FixEntry)))) return rc;
     }
+    HIPCHK(c, hipMemsetAsync(c->d_fix_count, 0, 2 * sizeof(unsigned int), c->stream));
 
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(c, hipEventRecord(b->ev[2], c->stream));
     if (n > 0 && b->n_chains > 0) {
         SigParams P;
         P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
@@ -493,16 +521,27 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
             int32_t t = (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000u;
             P.shift = (int)(int16_t)(uint16_t)((uint32_t)t & 0xffffu);
         }
-        constexpr int NT = SQG_SIGNAL_THREADS;
-        if (certified) {
-            hipLaunchKernelGGL((k_signal<1, NT>), dim3((unsigned)b->n_chains), dim3(NT), 0, c->stream, P);
-            if (c->use_kmer_streams) hipLaunchKernelGGL(k_fixup, dim3(512), dim3(256), 0, c->stream, P);
+        P.evrec = c->d_evrec; P.tile_so = c->d_tile_so; P.tile_read = b->d_tile_read;
+        P.slow_tiles = nullptr; P.slow_count = c->d_fix_count + 1;
+        constexpr int NT = SQG_EVENT_THREADS;
+        const int n_tiles = (int)b->n_tiles;
+        const unsigned sgrid = (unsigned)((n_tiles + 3) / 4);
+        hipLaunchKernelGGL((k_events<NT>), dim3((unsigned)b->n_chains), dim3(NT), 0, c->stream, P);
+        HIPCHK(c, hipEventRecord(b->ev[3], c->stream));
+        if (certified && c->use_kmer_streams) {
+            P.slow_tiles = c->d_slow;
+            hipLaunchKernelGGL((k_samples<1, false>), dim3(sgrid), dim3(256), 0, c->stream, P, n_tiles);
+            hipLaunchKernelGGL((k_samples<1, true>), dim3(std::min(sgrid, 4096u)), dim3(256), 0, c->stream, P, n_tiles);
+            hipLaunchKernelGGL(k_fixup, dim3(512), dim3(256), 0, c->stream, P);
+        } else if (certified) {
+            hipLaunchKernelGGL((k_samples<1, true>), dim3(sgrid), dim3(256), 0, c->stream, P, n_tiles);
         } else {
-            hipLaunchKernelGGL((k_signal<0, NT>), dim3((unsigned)b->n_chains), dim3(NT), 0, c->stream, P);
+            hipLaunchKernelGGL((k_samples<0, true>), dim3(sgrid), dim3(256), 0, c->stream, P, n_tiles);
         }
         HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    else HIPCHK(c, hipEventRecord(b->ev[3], c->stream));
+    HIPCHK(c, hipEventRecord(b->ev[4], c->stream));
     b->ran = true;
     c->next_run++;
     return SQG_OK;
@@ -513,6 +552,8 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (!b->waited) {
+        b->n_samples = b->h_sigoff[b->n];
+        for (int i = 0; i <= b->n; i++) b->sig_off[(size_t)i] = b->h_sigoff[i];
         unsigned int e = 0;
         HIPCHK(c, hipMemcpy(&e, c->d_err, sizeof e, hipMemcpyDeviceToHost));
         if (e) {
@@ -520,13 +561,15 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
             c->err = "device reported: " + std::string((e & 1) ? "dwell>65535 " : "") + ((e & 2) ? "read>=UINT32_MAX samples " : "") + ((e & 4) ? "internal length mismatch " : "") + ((e & 8) ? "FP64 fix-up list overflow" : "");
             return (e & 12) ? SQG_EDEVICE : SQG_EOVERFLOW;
         }
-        float d = 0, s = 0, t = 0;
-        HIPCHK(c, hipEventElapsedTime(&d, c->ev[0], c->ev[1]));
-        HIPCHK(c, hipEventElapsedTime(&s, c->ev[2], c->ev[3]));
-        HIPCHK(c, hipEventElapsedTime(&t, c->ev[0], c->ev[3]));
+        float d = 0, s = 0, t = 0, ee = 0;
+        HIPCHK(c, hipEventElapsedTime(&d, b->ev[0], b->ev[1]));
+        HIPCHK(c, hipEventElapsedTime(&ee, b->ev[2], b->ev[3]));
+        HIPCHK(c, hipEventElapsedTime(&s, b->ev[3], b->ev[4]));
+        HIPCHK(c, hipEventElapsedTime(&t, b->ev[0], b->ev[4]));
+        c->timing.events_ms = ee;
         unsigned int nfix = 0;
         if (c->cfg.mode == SQG_MODE_CERTIFIED) HIPCHK(c, hipMemcpy(&nfix, c->d_fix_count, sizeof nfix, hipMemcpyDeviceToHost));
-        c->timing.dwell_ms = d; c->timing.signal_ms = s; c->timing.total_ms = t; c->timing.fallback_samples = nfix;
+        c->timing.dwell_ms = d; c->timing.samples_ms = s; c->timing.total_ms = t; c->timing.fallback_samples = nfix;
         b->waited = true;
     }
     if (res) {

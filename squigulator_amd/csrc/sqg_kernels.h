@@ -3,8 +3,8 @@
 //   k_init_rows   per-(worker,k-mer) stream seeds                       (src/sim.c:238-257)
 //   k_dwell       per-event dwell draw from the worker's time stream   (src/gensig.c:254-257)
 //   k_scan        read lengths -> output offsets
-//   k_signal      one wavefront per worker chain: ranks, in-order stream hand-out, samples
-//                                                                      (src/gensig.c:226-356)
+//   k_events      per worker chain: ranks, in-order hand-out of the k-mer streams
+//   k_samples     per 64-event tile: the samples                       (src/gensig.c:226-356)
 //   k_fixup       FP64 recomputation of the samples the certified fp32 path could not decide
 //   k_certify     exhaustive error sweep of the fp32 normal-deviate path over all 2^31-2 states
 //   k_store_probe int16 streaming-store ceiling
@@ -112,6 +112,8 @@ struct ReadDesc {
     int ne0, ne1;         // events per segment
     int worker;           // context-local worker index
     uint32_t time_c0;     // worker's time-stream state at the start of this read
+    int tile_off;         // first 64-event tile of this read in the batch's tile arrays
+    int pad;
 };
 
 struct FixEntry {         // one sample handed to the FP64 path
@@ -140,6 +142,11 @@ struct SigParams {
     FixEntry* fix;               // certified mode: undecided samples
     unsigned int* fix_count;
     unsigned int fix_cap;
+    uint2* evrec;                // per event {stream state at its first draw, k-mer rank}
+    uint32_t* tile_so;           // per 64-event tile: its first sample within the read
+    const int* tile_read;        // per tile: read index
+    int* slow_tiles;             // tiles the lean sample kernel left to the generic one
+    unsigned int* slow_count;
     double dig, range, kd;       // kd = dig/range
     float delta_x;               // swept bound on |x_fast - x_exact| (incl. margin)
     int k, num_kmer;
@@ -163,6 +170,9 @@ __global__ void k_init_rows(uint32_t* rows, int num_kmer, long long seed, int wo
 
 // ---- k_dwell: one thread per event of the batch --------------------------------------------
 // sps = round(nrng(rand_time)); sps = sps<1 ? -sps+1 : sps           (src/gensig.c:255-256)
+// Event e of a read uses draws 2e+1, 2e+2 after the worker's time-stream state at the start of
+// the read: position addressed by the jump a^(2e) (two LDS table levels, a third in memory).
+#define DW_RD 8            // read descriptors cached per 256-event block (reads are >= ~190 events)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_dwell(const ReadDesc* __restrict__ reads, int n_reads,
                                                const int* __restrict__ blk_read, long long n_events,
@@ -171,15 +181,38 @@ __global__ __launch_bounds__(256) void k_dwell(const ReadDesc* __restrict__ read
                                                uint16_t* __restrict__ dwell,
                                                unsigned long long* __restrict__ seglen,
                                                unsigned int* __restrict__ err) {
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint32_t j0[POW_N], j1[POW_N];          // a^(2j), a^(2*1024*j)
+    __shared__ long long r_ev[DW_RD + 1];
+    __shared__ uint32_t r_c0[DW_RD];
+    __shared__ int r_ne0[DW_RD];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < POW_N; i += 256) { j0[i] = pw[2 * POW_N + i]; j1[i] = pw[3 * POW_N + i]; }
+    const int rb = blk_read[blockIdx.x];
+    if (tid <= DW_RD) {
+        const int q = rb + tid;
+        r_ev[tid] = q < n_reads ? reads[q].ev_off : 0x7fffffffffffffffLL;
+        if (tid < DW_RD && q < n_reads) { r_c0[tid] = reads[q].time_c0; r_ne0[tid] = reads[q].ne0; }
+    }
+    __syncthreads();
+    const long long gid = (long long)blockIdx.x * 256 + tid;
     const bool valid = gid < n_events;
-    int r = blk_read[blockIdx.x];
+    int r = rb;
     int sps = 0, seg = 0;
     if (valid) {
-        while (r + 1 < n_reads && gid >= reads[r + 1].ev_off) r++;
-        const uint32_t e = (uint32_t)(gid - reads[r].ev_off);
-        const uint32_t c = lcg_mul(reads[r].time_c0, lcg_jump2(pw, e));
-        const uint32_t c1 = lcg_mul(c, LCG_A);
+        int q = 0;
+        while (q + 1 < DW_RD && gid >= r_ev[q + 1]) q++;
+        uint32_t e, c0; int ne0;
+        if (gid < r_ev[q + 1]) { e = (uint32_t)(gid - r_ev[q]); c0 = r_c0[q]; ne0 = r_ne0[q]; r = rb + q; }
+        else {                                         // more than DW_RD reads in one block: walk the table
+            r = rb + q;
+            while (r + 1 < n_reads && gid >= reads[r + 1].ev_off) r++;
+            e = (uint32_t)(gid - reads[r].ev_off); c0 = reads[r].time_c0; ne0 = reads[r].ne0;
+        }
+        uint32_t jp = j0[e & (POW_N - 1)];
+        const uint32_t hi = (e >> 10) & (POW_N - 1), hi2 = e >> 20;
+        if (hi) jp = lcg_mul(jp, j1[hi]);
+        if (hi2) jp = lcg_mul(jp, pw[4 * POW_N + hi2]);
+        const uint32_t c1 = lcg_mul(lcg_mul(c0, jp), LCG_A);
         bool decided = false;
         if (MODE == 1) {
             // v' = x'*s + m in fp32; round(v) = floor(v+1/2) unless v is within eps of a half-integer
@@ -204,15 +237,15 @@ __global__ __launch_bounds__(256) void k_dwell(const ReadDesc* __restrict__ read
         sps = sps < 1 ? -sps + 1 : sps;                          // src/gensig.c:256
         if (sps > 65535) { atomicOr(err, 1u); sps = 65535; }
         dwell[gid] = (uint16_t)sps;
-        seg = e >= (uint32_t)reads[r].ne0;
+        seg = e >= (uint32_t)ne0;
     }
     // per-read totals: one atomic per wavefront when the wave is inside one (read, segment)
     const int key = valid ? (r * 2 + seg) : -1;
     const int key0 = __shfl(key, 0);
     if (__all(key == key0)) {
-        int s = sps;
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-        if ((threadIdx.x & 63) == 0 && key0 >= 0) atomicAdd(&seglen[key0], (unsigned long long)s);
+        int sum = sps;
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+        if ((tid & 63) == 0 && key0 >= 0) atomicAdd(&seglen[key0], (unsigned long long)sum);
     } else if (valid) {
         atomicAdd(&seglen[key], (unsigned long long)sps);
     }
@@ -248,328 +281,356 @@ __global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restr
     if (tid == 0) sig_off[n_reads] = carry;
 }
 
-// ---- k_signal ------------------------------------------------------------------------------
-// One workgroup of NT threads per worker chain (a worker's reads of this batch, in batch order).
-// A read is walked in segments of NT consecutive events, one event per thread:
-//   event phase  (whole workgroup): k-mer rank, dwell, block scan -> first sample of each event;
-//                hand-out of the per-(worker,k-mer) Lehmer streams IN EVENT ORDER: events are
-//                binned by k-mer in an LDS hash table, bin members listed via a block scan, and
-//                each event sums the dwell of the same-k-mer events before it (bins hold 1-3
-//                events).  Stream states live in HBM/L2 (rows[worker][rank]); one load and, for
-//                the last event of a bin, one store per event, by an O(1) jump a^(2*samples).
-//   sample phase (per wavefront, no block barriers): wave w emits the samples of events
-//                [64w, 64w+64) of the segment, 64 consecutive samples per step (contiguous int16
-//                stores).  sample -> event through start-marker bytes in LDS + ballot/mbcnt; the
-//                two draws of a sample are two modular multiplications of the event's state with
-//                per-slot constants a^(2j+1), a^(2j+2) held in LDS.
-#ifndef SQG_SIGNAL_WAVES_PER_SIMD
-#define SQG_SIGNAL_WAVES_PER_SIMD 4
+// ---- k_events + k_samples ------------------------------------------------------------------
+// The per-read loop nest of src/gensig.c:249-282 is split at its only sequential dependency:
+//
+// k_events   one workgroup of NT threads per worker chain (a worker's reads of this batch, in
+//            batch order); a read is walked in segments of NT consecutive events, one event per
+//            thread: k-mer rank, dwell, block scan -> first sample of each 64-event tile, and the
+//            hand-out of the per-(worker,k-mer) Lehmer streams IN EVENT ORDER: events are binned
+//            by k-mer in an LDS hash table, bin members listed through a block scan, and each
+//            event sums the dwell of the same-k-mer events before it (bins hold 1-3 events).
+//            Stream states live in HBM/L2 (rows[worker][rank]): one load per event and one store
+//            per bin, advanced by an O(1) jump a^(2*samples).  Output: 8 B per event
+//            {state at the event's first draw, rank}.
+// k_samples  one wavefront per 64-event tile, no inter-wave dependency and no block barrier:
+//            64 consecutive samples per step (contiguous int16 stores).  sample -> event through
+//            start-marker bytes in LDS + ballot/mbcnt; the two draws of a sample are two modular
+//            multiplications of the event's state with per-slot constants a^(2j+1), a^(2j+2).
+#ifndef SQG_EVENT_THREADS
+#define SQG_EVENT_THREADS 512
 #endif
 #define MK_W 1024          // marker window (samples) per wavefront
 #define MULT_N 256         // LDS jump constants cover events of up to 256 samples
 #define BIN_EMPTY 0xffffffffu
-
-template <int NT>
-struct SigLds {
-    uint4 rec_a[NT];            // {c_ev, first sample in segment, F | level_mean, sdk | sd}
-    uint2 rec_b[NT];            // {I | constant sample, thr | rank}
-    uint32_t keys[2 * NT];      // hash bins: k-mer rank
-    uint32_t bins[2 * NT];      // events per bin; after the scan (first member slot << 16) | count
-    uint32_t mem[NT];           // bin members: (event index in segment << 16) | dwell
-    uint2 mult[MULT_N];         // {a^(2j+1), a^(2j+2)}
-    uint32_t jump[MULT_N];      // a^(2j)
-    uint8_t mk[NT / 64][MK_W];  // event-start markers, one window per wavefront
-    uint8_t lut[256];           // base -> 2-bit code
-    int wsum[NT / 64];
-    int wsum2[NT / 64];
-};
 
 __device__ static inline int wave_incl_scan(int v, int lane) {
     for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(v, o); if (lane >= o) v += y; }
     return v;
 }
 
+#define EV_NIL 0xffffu
+#define EV_HALO 20          // 2*(k_max-1)+2 extra base codes per segment (segment-0/1 boundary)
+
 template <int NT>
-__device__ static inline uint32_t jump2_lds(const SigLds<NT>& L, const uint32_t* __restrict__ pw, uint32_t n) {
-    return n < MULT_N ? L.jump[n] : lcg_jump2(pw, n);
+struct EvLds {
+    uint32_t keys[2 * NT];      // hash bins: k-mer rank
+    uint32_t head[2 * NT];      // bin -> most recently inserted event of the segment (EV_NIL: none)
+    uint32_t nxt[NT];           // per event: (dwell << 16) | next event in the same bin
+    uint32_t jump[MULT_N];      // a^(2j)
+    uint8_t codes[NT + EV_HALO + 4];   // 2-bit base codes of the segment
+    uint8_t lut[256];           // base -> 2-bit code (src/seq.h:14-27)
+    int wsum[NT / 64];
+};
+
+// LDS-only workgroup barrier: does not wait for outstanding global loads/stores
+__device__ static inline void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// generic per-sample emitter: every option, both modes (used for tiles the fast loop excludes)
-template <int MODE, int NT>
-__device__ static void emit_generic(const SigParams& P, SigLds<NT>& L, int lane, int ev0, uint8_t* mk, bool valid,
-                                    int so_w, int wave_total, uint32_t base_pos, uint32_t read_len, int16_t* out,
-                                    long long sig_base, int r, long long ev_first, double offset,
-                                    long long shift_lo, long long n1, bool shift_tile) {
-    const unsigned long long lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);
-    for (int w0 = 0; w0 < wave_total; w0 += MK_W) {
-        ((uint4*)mk)[lane] = make_uint4(0, 0, 0, 0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (valid && so_w >= w0 && so_w < w0 + MK_W) mk[so_w - w0] = 1;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        int base_ev = __popcll(__ballot(valid && so_w < w0));
-        const int w_end = min(w0 + MK_W, wave_total);
-        for (int c0 = w0; c0 < w_end; c0 += 64) {
-            const int idx = c0 + lane;
-            const unsigned long long sm = __ballot(mk[idx - w0] != 0);
-            const int ev = ev0 + base_ev + __popcll(sm & lane_le) - 1;
-            base_ev += __popcll(sm);
-            if (idx < w_end) {
-                const uint4 ra = L.rec_a[ev];
-                const uint2 rb = L.rec_b[ev];
-                const uint32_t j = (uint32_t)idx - (ra.y - (uint32_t)(L.rec_a[ev0].y));   // sample within event
-                const uint32_t pos = base_pos + (uint32_t)idx;
-                const uint32_t at = P.rna ? (read_len - 1 - pos) : pos;
-                const bool in_shift = shift_tile && (long long)pos >= shift_lo && (long long)pos < n1;
-                int16_t q;
-                bool ok = true;
-                uint32_t c1 = 1;
-                if (!P.use_streams) {
-                    q = (int16_t)(uint16_t)rb.x;
-                } else {
-                    if (j < MULT_N) c1 = lcg_mul(ra.x, L.mult[j].x);
-                    else c1 = lcg_mul(lcg_mul(ra.x, lcg_jump2(P.pw, j)), LCG_A);
-                    if (MODE == 1) {
-                        const float x = box_muller_fast(c1, lcg_mul_lazy(c1, LCG_A));
-                        const float v = __builtin_fmaf(x, __uint_as_float(ra.w), __uint_as_float(ra.z));
-                        const float fl = floorf(v);
-                        const float fr = v - fl;
-                        ok = fabsf(fr - 0.5f) < __uint_as_float(rb.y) && c1 <= LCG_M - (1u << NEAR_ONE_BITS);
-                        int n = (int)rb.x + (int)fl;
-                        n -= n >> 31;                                      // truncation toward zero (value is not an integer)
-                        q = (int16_t)(uint16_t)((uint32_t)n & 0xffffu);
-                    } else {
-                        const double z = box_muller_exact(c1, lcg_mul(c1, LCG_A));
-                        const float sv = (float)((z * (double)__uint_as_float(ra.w)) + (double)__uint_as_float(ra.z));   // src/gensig.c:268
-                        q = to_i16((double)sv * P.dig / P.range - offset);                                             // src/gensig.c:270
-                    }
-                }
-                if (in_shift) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);
-                if (ok) out[at] = q;
-                if (MODE == 1) {
-                    const unsigned long long am = __ballot(!ok);
-                    if (am) {                                              // hand the undecided samples to k_fixup
-                        unsigned int slot0 = 0;
-                        const int leader = __ffsll((long long)am) - 1;
-                        if (lane == leader) slot0 = atomicAdd(P.fix_count, (unsigned int)__popcll(am));
-                        slot0 = __shfl(slot0, leader);
-                        if (!ok) {
-                            const unsigned int slot = slot0 + (unsigned int)__popcll(am & lane_le) - 1u;
-                            if (slot < P.fix_cap) {
-                                FixEntry fe; fe.at = sig_base + at; fe.c1 = c1; fe.ev = ev_first + ev; fe.read = r; fe.shifted = in_shift;
-                                P.fix[slot] = fe;
-                            } else atomicOr(P.err, 8u);
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-// the hot loop: certified mode, events of <= MULT_N samples, no level-shift window, positive ADC values
 template <int NT>
-__device__ static inline void emit_fast(const SigParams& P, SigLds<NT>& L, int lane, int ev0, uint8_t* mk, bool valid,
-                                        int so_w, int wave_total, uint32_t base_pos, uint32_t read_len, int16_t* out,
-                                        long long sig_base, int r, long long ev_first, float thr, uint32_t so_first) {
-    const unsigned long long lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);
-    const bool rna = P.rna != 0;
-    const uint32_t a_top = read_len - 1 - base_pos;
-    for (int w0 = 0; w0 < wave_total; w0 += MK_W) {
-        ((uint4*)mk)[lane] = make_uint4(0, 0, 0, 0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        if (valid && so_w >= w0 && so_w < w0 + MK_W) mk[so_w - w0] = 1;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        int base_ev = ev0 - 1 + __popcll(__ballot(valid && so_w < w0));
-        const int w_end = min(w0 + MK_W, wave_total);
-        for (int c0 = w0; c0 < w_end; c0 += 64) {
-            const int idx = c0 + lane;
-            const unsigned long long sm = __ballot(mk[idx - w0] != 0);
-            const int ev = base_ev + __popcll(sm & lane_le);
-            base_ev += __popcll(sm);
-            const uint4 ra = L.rec_a[ev];
-            const int I = (int)L.rec_b[ev].x;
-            const uint32_t j = ((uint32_t)idx + so_first - ra.y) & (MULT_N - 1);
-            const uint2 mu = L.mult[j];
-            const uint32_t c1 = lcg_mul(ra.x, mu.x);
-            const uint32_t r2 = lcg_mul_lazy(ra.x, mu.y);
-            const float x = box_muller_fast(c1, r2);
-            const float v = __builtin_fmaf(x, __uint_as_float(ra.w), __uint_as_float(ra.z));
-            const float fl = floorf(v);
-            const float fr = v - fl;
-            const bool act = idx < w_end;
-            const bool ok = fabsf(fr - 0.5f) < thr && c1 <= LCG_M - (1u << NEAR_ONE_BITS);
-            const int n = I + (int)fl;
-            const uint32_t at = rna ? (a_top - (uint32_t)idx) : (base_pos + (uint32_t)idx);
-            if (act && ok) out[at] = (int16_t)(uint16_t)((uint32_t)n & 0xffffu);
-            const unsigned long long am = __ballot(act && !ok);
-            if (am) {
-                unsigned int slot0 = 0;
-                const int leader = __ffsll((long long)am) - 1;
-                if (lane == leader) slot0 = atomicAdd(P.fix_count, (unsigned int)__popcll(am));
-                slot0 = __shfl(slot0, leader);
-                if (act && !ok) {
-                    const unsigned int slot = slot0 + (unsigned int)__popcll(am & lane_le) - 1u;
-                    if (slot < P.fix_cap) {
-                        FixEntry fe; fe.at = sig_base + at; fe.c1 = c1; fe.ev = ev_first + ev; fe.read = r; fe.shifted = 0;
-                        P.fix[slot] = fe;
-                    } else atomicOr(P.err, 8u);
-                }
-            }
-        }
-    }
-}
-
-template <int MODE, int NT>
-__global__ __launch_bounds__(NT, SQG_SIGNAL_WAVES_PER_SIMD) void k_signal(const SigParams P) {
-    __shared__ SigLds<NT> L;
+__global__ __launch_bounds__(NT) void k_events(const SigParams P) {
+    __shared__ EvLds<NT> L;
     constexpr int NW = NT / 64, HT = 2 * NT;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int i = tid; i < MULT_N; i += NT) { L.mult[i] = make_uint2(P.pw[i], P.pw[POW_N + i]); L.jump[i] = P.pw[2 * POW_N + i]; }
+    for (int i = tid; i < MULT_N; i += NT) L.jump[i] = P.pw[2 * POW_N + i];
     for (int i = tid; i < 256; i += NT) L.lut[i] = (uint8_t)base_code((uint8_t)i);
 
     const int chain = P.chain_order[blockIdx.x];
     const int c_lo = P.chain_off[chain], c_hi = P.chain_off[chain + 1];
     uint32_t* row = P.rows ? P.rows + (size_t)P.reads[P.chain_reads[c_lo]].worker * P.num_kmer : nullptr;
     const int k = P.k;
-    const double kd = P.kd;
-    uint8_t* mk = L.mk[wid];
     __syncthreads();
 
     for (int ci = c_lo; ci < c_hi; ci++) {
         const int r = P.chain_reads[ci];
         const ReadDesc rd = P.reads[r];
-        const long long sig_base = P.sig_off[r];
-        const uint32_t read_len = (uint32_t)(P.sig_off[r + 1] - sig_base);
-        const long long n1 = (long long)P.seglen[2 * r];             // samples of segment 0
-        const long long shift_lo = n1 - P.shift_len;                  // src/genread.c:79
         const int ne = rd.ne0 + rd.ne1;
-        const double offset = rd.offset;
-        int16_t* out = P.sig + sig_base;
-        uint32_t done = 0;                                            // samples emitted so far in this read
-
+        const uint8_t* rbases = P.bases + rd.base_off;
+        const long long nbytes = (long long)rd.len0 + rd.len1;
+        // base index of event e: e in segment 0, e + (k-1) in segment 1 (the stall's k-mers do not
+        // straddle the boundary, src/genread.c:87-88)
+        #define EV_BASE(e_) ((long long)(e_) + ((e_) >= rd.ne0 ? (long long)rd.len0 - rd.ne0 : 0LL))
+        uint32_t done = 0;                                            // samples before this segment
+        // prefetch of segment 0: one base byte per thread (+ halo), one dwell per thread
+        uint8_t b_cur = 'A', b_halo = 'A';
+        uint16_t d_cur = 0;
+        {
+            const long long b0 = EV_BASE(0);
+            if (b0 + tid < nbytes) b_cur = rbases[b0 + tid];
+            if (tid < EV_HALO && b0 + NT + tid < nbytes) b_halo = rbases[b0 + NT + tid];
+            if (tid < ne && P.dwell) d_cur = P.dwell[rd.ev_off + tid];
+        }
         for (int s0 = 0; s0 < ne; s0 += NT) {
-            // ================= event phase =================
             const int e = s0 + tid;
             const bool valid = e < ne;
-            uint32_t rank = 0;
-            int sps = 0;
-            if (valid) {
-                const uint8_t* bp = P.bases + rd.base_off + (e < rd.ne0 ? (long long)e : (long long)rd.len0 + (e - rd.ne0));
-                for (int i = 0; i < k; i++) rank = (rank << 2) | L.lut[bp[i]];                 // src/seq.h:31-42
-                sps = P.dwell ? (int)P.dwell[rd.ev_off + e] : P.const_sps;
-            }
-            const float2 md = valid ? P.model[rank] : make_float2(0.f, 0.f);
+            const long long bseg = EV_BASE(s0);
+            L.codes[tid] = L.lut[b_cur];
+            if (tid < EV_HALO) L.codes[NT + tid] = L.lut[b_halo];
+            const int sps = valid ? (P.dwell ? (int)d_cur : P.const_sps) : 0;
             const int incl = wave_incl_scan(sps, lane);
             if (lane == 63) L.wsum[wid] = incl;
-            if (P.use_streams) for (int i = tid; i < HT; i += NT) { L.keys[i] = BIN_EMPTY; L.bins[i] = 0; }
-            __syncthreads();                                                                  // (1)
+            if (P.use_streams) for (int i = tid; i < HT; i += NT) { L.keys[i] = BIN_EMPTY; L.head[i] = EV_NIL; }
+            lds_barrier();                                                                    // (1)
             int woff = 0, seg_total = 0;
             for (int w = 0; w < NW; w++) { const int x = L.wsum[w]; if (w < wid) woff += x; seg_total += x; }
-            const int so = woff + incl - sps;                 // first sample of my event within the segment
-            const int wave_total = __shfl(incl, 63);
-
+            uint32_t rank = 0;
+            if (valid) {
+                const int cb = (int)(EV_BASE(e) - bseg);
+                for (int i = 0; i < k; i++) rank = (rank << 2) | L.codes[cb + i];               // src/seq.h:31-42
+            }
+            uint32_t h = (rank * 2654435761u) >> (32 - (31 - __builtin_clz(HT)));
+            if (P.use_streams && valid) {
+                for (;;) {
+                    const uint32_t old = atomicCAS(&L.keys[h], BIN_EMPTY, rank);
+                    if (old == BIN_EMPTY || old == rank) break;
+                    h = (h + 1) & (HT - 1);
+                }
+                const uint32_t prev = atomicExch(&L.head[h], (uint32_t)tid);
+                L.nxt[tid] = ((uint32_t)sps << 16) | prev;
+            }
+            __syncthreads();                                                                  // (2) + earlier row stores have landed
+            // prefetch the next segment's inputs; they land while this segment waits for its states
+            {
+                const int s1 = s0 + NT;
+                if (s1 < ne) {
+                    const long long b1 = EV_BASE(s1);
+                    b_cur = (b1 + tid < nbytes) ? rbases[b1 + tid] : (uint8_t)'A';
+                    if (tid < EV_HALO) b_halo = (b1 + NT + tid < nbytes) ? rbases[b1 + NT + tid] : (uint8_t)'A';
+                    if (s1 + tid < ne && P.dwell) d_cur = P.dwell[rd.ev_off + s1 + tid];
+                }
+            }
+            if (lane == 0 && s0 + wid * 64 < ne) P.tile_so[rd.tile_off + (s0 >> 6) + wid] = done + (uint32_t)woff;
             uint32_t c_ev = 0;
             if (P.use_streams) {
-                uint32_t h = (rank * 2654435761u) >> (32 - (31 - __builtin_clz(HT)));
-                uint32_t ord = 0;
-                if (valid) {
-                    for (;;) {
-                        const uint32_t old = atomicCAS(&L.keys[h], BIN_EMPTY, rank);
-                        if (old == BIN_EMPTY || old == rank) break;
-                        h = (h + 1) & (HT - 1);
-                    }
-                    ord = atomicAdd(&L.bins[h], 1u);
-                }
-                __syncthreads();                                                              // (2)
-                const uint32_t b0 = L.bins[2 * tid], b1 = L.bins[2 * tid + 1];
-                const int local = (int)(b0 + b1);
-                const int incl2 = wave_incl_scan(local, lane);
-                if (lane == 63) L.wsum2[wid] = incl2;
-                __syncthreads();                                                              // (3)
-                int woff2 = 0;
-                for (int w = 0; w < wid; w++) woff2 += L.wsum2[w];
-                const uint32_t ex = (uint32_t)(woff2 + incl2 - local);
-                L.bins[2 * tid] = (ex << 16) | b0;
-                L.bins[2 * tid + 1] = ((ex + b0) << 16) | b1;
-                __syncthreads();                                                              // (4)
-                uint32_t bv = 0;
-                if (valid) { bv = L.bins[h]; L.mem[(bv >> 16) + ord] = ((uint32_t)tid << 16) | (uint32_t)sps; }
-                __syncthreads();                                                              // (5)
-                uint32_t prior = 0, total = (uint32_t)sps;
+                // dwell drawn from my k-mer's stream by earlier events of this segment, by all of them,
+                // and whether I am the last one (who stores the advanced state)
+                uint32_t prior = 0, total = 0;
                 bool last = true;
-                if (valid && (bv & 0xffffu) > 1u) {
-                    total = 0;
-                    const uint32_t m0 = bv >> 16, mc = bv & 0xffffu;
-                    for (uint32_t m = 0; m < mc; m++) {
-                        const uint32_t v = L.mem[m0 + m];
-                        const uint32_t t2 = v >> 16, s2 = v & 0xffffu;
-                        total += s2;
-                        if (t2 < (uint32_t)tid) prior += s2;
-                        if (t2 > (uint32_t)tid) last = false;
-                    }
-                }
                 uint32_t c_row = 0;
-                if (valid) c_row = __hip_atomic_load(&row[rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();                                                              // (6) all states read before any is advanced
                 if (valid) {
-                    c_ev = prior ? lcg_mul(c_row, jump2_lds(L, P.pw, prior)) : c_row;
-                    if (last) __hip_atomic_store(&row[rank], lcg_mul(c_row, jump2_lds(L, P.pw, total)),
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-            float thr = 1.0f;
-            bool fast_ok = true;
-            if (!P.use_streams) {
-                // no amplitude noise (--ideal / --ideal-amp): s = level_mean, one digitisation per event (src/gensig.c:266,270)
-                const int16_t qc = to_i16((double)md.x * P.dig / P.range - offset);
-                L.rec_a[tid] = make_uint4(0u, (uint32_t)so, 0u, 0u);
-                L.rec_b[tid] = make_uint2((uint32_t)(uint16_t)qc, 0u);
-            } else if (MODE == 1) {
-                // v = s_f*dig/range - offset  ~  x*(sd*kd) + (m*kd - offset) = x*sdk + (I + F)
-                const double mkd = (double)md.x * kd;
-                const double mk = mkd - offset;
-                const double fl = floor(mk);
-                const float F = (float)(mk - fl);
-                const float sdk = (float)((double)md.y * kd);
-                const float asdk = fabsf(sdk);
-                // error budget (DESIGN.md "Certified fast path"): swept |x'-x| * sdk; float narrowing of s
-                // (2^-24 (|m| kd + 6.56 sdk)); roundings of sdk (x6.56), of F (2^-25) and of the fma
-                // (2^-24 (6.56 sdk + 1)); FP64 roundings and the fp32 evaluation of eps itself in the slack
-                const float eps = P.delta_x * asdk + 5.9604645e-8f * ((float)fabs(mkd) + 21.0f * asdk + 3.0f) + 2.0e-7f;
-                thr = 0.5f - eps;
-                if (!(fabs(fl) < 1.0e9)) thr = -1.0f;                     // absurd profile: everything goes to FP64
-                fast_ok = !valid || (sps <= MULT_N && fl - 7.0 * (double)asdk > 2.0 && fl < 1.0e9);
-                L.rec_a[tid] = make_uint4(c_ev, (uint32_t)so, __float_as_uint(F), __float_as_uint(sdk));
-                L.rec_b[tid] = make_uint2((uint32_t)(int)fl, __float_as_uint(thr));
-            } else {
-                L.rec_a[tid] = make_uint4(c_ev, (uint32_t)so, __float_as_uint(md.x), __float_as_uint(md.y));
-                L.rec_b[tid] = make_uint2(0u, 0u);
-            }
-            __syncthreads();                                                                  // (7)
-
-            // ================= sample phase (wave-local) =================
-            if (wave_total > 0) {
-                const uint32_t base_pos = done + (uint32_t)woff;
-                const bool shift_tile = P.shift_len > 0 && (long long)base_pos + wave_total > shift_lo && (long long)base_pos < n1;
-                const int so_w = so - woff;
-                bool use_fast = false;
-                if (MODE == 1 && P.use_streams && !shift_tile) {
-                    use_fast = __all(fast_ok);
-                    if (use_fast) {
-                        float t = valid ? thr : 1.0f;
-                        for (int o = 32; o > 0; o >>= 1) t = fminf(t, __shfl_xor(t, o));
-                        thr = t;
+                    c_row = __builtin_nontemporal_load(&row[rank]);   // L2-served (bypasses the CU's L1): sees this workgroup's earlier stores
+                    uint32_t t = L.head[h];
+                    while (t != EV_NIL) {
+                        const uint32_t v = L.nxt[t];
+                        const uint32_t s2 = v >> 16;
+                        total += s2;
+                        if (t < (uint32_t)tid) prior += s2;
+                        if (t > (uint32_t)tid) last = false;
+                        t = v & 0xffffu;
                     }
                 }
-                if (use_fast) emit_fast<NT>(P, L, lane, wid * 64, mk, valid, so_w, wave_total, base_pos, read_len, out,
-                                            sig_base, r, rd.ev_off + s0, thr, (uint32_t)woff);
-                else emit_generic<MODE, NT>(P, L, lane, wid * 64, mk, valid, so_w, wave_total, base_pos, read_len, out,
-                                            sig_base, r, rd.ev_off + s0, offset, shift_lo, n1, shift_tile);
+                __syncthreads();                                                              // (3) every state read before any is advanced
+                if (valid) {
+                    c_ev = prior ? lcg_mul(c_row, prior < MULT_N ? L.jump[prior] : lcg_jump2(P.pw, prior)) : c_row;
+                    if (last) row[rank] = lcg_mul(c_row, total < MULT_N ? L.jump[total] : lcg_jump2(P.pw, total));   // plain store: merged in L2
+                }
             }
+            if (valid) P.evrec[rd.ev_off + e] = make_uint2(c_ev, rank);
             done += (uint32_t)seg_total;
-            __syncthreads();                                                                  // (8)
+            lds_barrier();                                                                    // (4) LDS reusable; stores stay in flight
         }
-        if (done != read_len && tid == 0) atomicOr(P.err, 4u);
+        #undef EV_BASE
+        if ((long long)done != P.sig_off[r + 1] - P.sig_off[r] && tid == 0) atomicOr(P.err, 4u);
+        __syncthreads();                                // the chain's next read starts with this read's stores landed
+    }
+}
+
+struct SmpWaveLds {
+    uint4 rec_a[64];            // {c_ev, first sample in tile, F | level_mean, sdk | sd}
+    uint2 rec_b[64];            // {I | constant sample, thr}
+    uint8_t mk[MK_W];           // event-start markers of the current sample window
+};
+struct SmpLds {
+    uint2 mult[MULT_N];         // {a^(2j+1), a^(2j+2)}
+    SmpWaveLds w[4];
+};
+
+__device__ static inline void push_fix(const SigParams& P, bool bad, int lane, unsigned long long lane_le,
+                                       long long at, uint32_t c1, long long ev, int r, int shifted) {
+    const unsigned long long am = __ballot(bad);
+    if (am) {                                                  // hand the undecided samples to k_fixup
+        unsigned int slot0 = 0;
+        const int leader = __ffsll((long long)am) - 1;
+        if (lane == leader) slot0 = atomicAdd(P.fix_count, (unsigned int)__popcll(am));
+        slot0 = __shfl(slot0, leader);
+        if (bad) {
+            const unsigned int slot = slot0 + (unsigned int)__popcll(am & lane_le) - 1u;
+            if (slot < P.fix_cap) {
+                FixEntry fe; fe.at = at; fe.c1 = c1; fe.ev = ev; fe.read = r; fe.shifted = shifted; fe.pad = 0;
+                P.fix[slot] = fe;
+            } else atomicOr(P.err, 8u);
+        }
+    }
+}
+
+// MODE 0: FP64 everywhere.  MODE 1: certified fp32 path.
+// GENERIC false: the lean kernel; tiles it cannot take (long events, level-shift window, possibly
+//                negative ADC values, no-noise modes) are queued for the GENERIC instantiation.
+template <int MODE, bool GENERIC>
+__global__ __launch_bounds__(256) void k_samples(const SigParams P, const int n_tiles) {
+    __shared__ SmpLds L;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < MULT_N; i += 256) L.mult[i] = make_uint2(P.pw[i], P.pw[POW_N + i]);
+    __syncthreads();
+    SmpWaveLds& W = L.w[wid];
+    const unsigned long long lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);   // lanes <= me
+    const int n_work = GENERIC && P.slow_tiles ? (int)min(*P.slow_count, (unsigned int)n_tiles) : n_tiles;
+
+    for (int wi = blockIdx.x * 4 + wid; wi < n_work; wi += gridDim.x * 4) {
+        const int g = GENERIC && P.slow_tiles ? P.slow_tiles[wi] : wi;
+        const int r = P.tile_read[g];
+        const ReadDesc rd = P.reads[r];
+        const int ne = rd.ne0 + rd.ne1;
+        const int e = (g - rd.tile_off) * 64 + lane;
+        const bool valid = e < ne;
+        const long long ev_first = rd.ev_off + (long long)(g - rd.tile_off) * 64;
+        uint2 er = make_uint2(0u, 0u);
+        int sps = 0;
+        if (valid) {
+            er = P.evrec[rd.ev_off + e];
+            sps = P.dwell ? (int)P.dwell[rd.ev_off + e] : P.const_sps;
+        }
+        const float2 md = valid ? P.model[er.y] : make_float2(0.f, 0.f);
+        const int incl = wave_incl_scan(sps, lane);
+        const int wave_total = __shfl(incl, 63);
+        const int so = incl - sps;                                     // first sample of my event within the tile
+        const long long sig_base = P.sig_off[r];
+        const uint32_t read_len = (uint32_t)(P.sig_off[r + 1] - sig_base);
+        const long long n1 = (long long)P.seglen[2 * r];               // samples of segment 0
+        const long long shift_lo = n1 - P.shift_len;                    // src/genread.c:79
+        const uint32_t base_pos = P.tile_so[g];
+        const bool shift_tile = P.shift_len > 0 && (long long)base_pos + wave_total > shift_lo && (long long)base_pos < n1;
+        const double offset = rd.offset;
+        int16_t* out = P.sig + sig_base;
+
+        float thr = 1.0f;
+        bool fast_ok = false;
+        uint4 ra; uint2 rb;
+        if (!P.use_streams) {
+            // no amplitude noise (--ideal / --ideal-amp): s = level_mean, one digitisation per event (src/gensig.c:266,270)
+            const int16_t qc = to_i16((double)md.x * P.dig / P.range - offset);
+            ra = make_uint4(0u, (uint32_t)so, 0u, 0u);
+            rb = make_uint2((uint32_t)(uint16_t)qc, 0u);
+        } else if (MODE == 1) {
+            // v = s_f*dig/range - offset  ~  x*(sd*kd) + (m*kd - offset) = x*sdk + (I + F)
+            const double mkd = (double)md.x * P.kd;
+            const double mk = mkd - offset;
+            const double fl = floor(mk);
+            const float F = (float)(mk - fl);
+            const float sdk = (float)((double)md.y * P.kd);
+            const float asdk = fabsf(sdk);
+            // error budget (DESIGN.md "Certified fast path"): swept |x'-x| * sdk; float narrowing of s
+            // (2^-24 (|m| kd + 6.56 sdk)); roundings of sdk (x6.56), of F (2^-25) and of the fma
+            // (2^-24 (6.56 sdk + 1)); FP64 roundings and the fp32 evaluation of eps itself in the slack
+            const float eps = P.delta_x * asdk + 5.9604645e-8f * ((float)fabs(mkd) + 21.0f * asdk + 3.0f) + 2.0e-7f;
+            thr = 0.5f - eps;
+            if (!(fabs(fl) < 1.0e9)) thr = -1.0f;                     // absurd profile: everything goes to FP64
+            fast_ok = !valid || (sps <= MULT_N && fl - 7.0 * (double)asdk > 2.0 && fl < 1.0e9);
+            ra = make_uint4(er.x, (uint32_t)so, __float_as_uint(F), __float_as_uint(sdk));
+            rb = make_uint2((uint32_t)(int)fl, __float_as_uint(thr));
+        } else {
+            ra = make_uint4(er.x, (uint32_t)so, __float_as_uint(md.x), __float_as_uint(md.y));
+            rb = make_uint2(0u, 0u);
+        }
+        const bool take_fast = MODE == 1 && P.use_streams && !shift_tile && __all(fast_ok);
+        if (!GENERIC) {
+            if (!take_fast) {                                          // leave this tile to the generic kernel
+                if (lane == 0) { const unsigned int q = atomicAdd(P.slow_count, 1u); P.slow_tiles[q] = g; }
+                continue;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // previous tile's LDS reads are done
+        W.rec_a[lane] = ra;
+        W.rec_b[lane] = rb;
+        if (wave_total <= 0) continue;
+
+        if (!GENERIC) {
+            // ---------------- the hot loop ----------------
+            float t = valid ? thr : 1.0f;
+            for (int o = 32; o > 0; o >>= 1) t = fminf(t, __shfl_xor(t, o));
+            const bool rna = P.rna != 0;
+            const uint32_t a_top = read_len - 1 - base_pos;
+            for (int w0 = 0; w0 < wave_total; w0 += MK_W) {
+                ((uint4*)W.mk)[lane] = make_uint4(0, 0, 0, 0);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (valid && so >= w0 && so < w0 + MK_W) W.mk[so - w0] = 1;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                int base_ev = __popcll(__ballot(valid && so < w0)) - 1;
+                const int w_end = min(w0 + MK_W, wave_total);
+                for (int c0 = w0; c0 < w_end; c0 += 64) {
+                    const int idx = c0 + lane;
+                    const unsigned long long sm = __ballot(W.mk[idx - w0] != 0);
+                    const int ev = base_ev + __popcll(sm & lane_le);
+                    base_ev += __popcll(sm);
+                    const uint4 qa = W.rec_a[ev];
+                    const int I = (int)W.rec_b[ev].x;
+                    const uint32_t j = ((uint32_t)idx - qa.y) & (MULT_N - 1);
+                    const uint2 mu = L.mult[j];
+                    const uint32_t c1 = lcg_mul(qa.x, mu.x);
+                    const uint32_t r2 = lcg_mul_lazy(qa.x, mu.y);
+                    const float x = box_muller_fast(c1, r2);
+                    const float v = __builtin_fmaf(x, __uint_as_float(qa.w), __uint_as_float(qa.z));
+                    const float fl = floorf(v);
+                    const float fr = v - fl;
+                    const bool act = idx < w_end;
+                    const bool ok = fabsf(fr - 0.5f) < t && c1 <= LCG_M - (1u << NEAR_ONE_BITS);
+                    const int n = I + (int)fl;
+                    const uint32_t at = rna ? (a_top - (uint32_t)idx) : (base_pos + (uint32_t)idx);
+                    if (act && ok) out[at] = (int16_t)(uint16_t)((uint32_t)n & 0xffffu);
+                    push_fix(P, act && !ok, lane, lane_le, sig_base + at, c1, ev_first + ev, r, 0);
+                }
+            }
+        } else {
+            // ---------------- every option, both modes ----------------
+            for (int w0 = 0; w0 < wave_total; w0 += MK_W) {
+                ((uint4*)W.mk)[lane] = make_uint4(0, 0, 0, 0);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (valid && so >= w0 && so < w0 + MK_W) W.mk[so - w0] = 1;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                int base_ev = __popcll(__ballot(valid && so < w0)) - 1;
+                const int w_end = min(w0 + MK_W, wave_total);
+                for (int c0 = w0; c0 < w_end; c0 += 64) {
+                    const int idx = c0 + lane;
+                    const unsigned long long sm = __ballot(W.mk[idx - w0] != 0);
+                    const int ev = base_ev + __popcll(sm & lane_le);
+                    base_ev += __popcll(sm);
+                    const bool act = idx < w_end;
+                    const uint4 qa = W.rec_a[act ? ev : 0];
+                    const uint2 qb = W.rec_b[act ? ev : 0];
+                    const uint32_t j = (uint32_t)idx - qa.y;
+                    const uint32_t pos = base_pos + (uint32_t)idx;
+                    const uint32_t at = P.rna ? (read_len - 1 - pos) : pos;
+                    const bool in_shift = shift_tile && (long long)pos >= shift_lo && (long long)pos < n1;
+                    int16_t q = 0;
+                    bool ok = true;
+                    uint32_t c1 = 1;
+                    if (!P.use_streams) {
+                        q = (int16_t)(uint16_t)qb.x;
+                    } else if (act) {
+                        if (j < MULT_N) c1 = lcg_mul(qa.x, L.mult[j].x);
+                        else c1 = lcg_mul(lcg_mul(qa.x, lcg_jump2(P.pw, j)), LCG_A);
+                        if (MODE == 1) {
+                            const float x = box_muller_fast(c1, lcg_mul_lazy(c1, LCG_A));
+                            const float v = __builtin_fmaf(x, __uint_as_float(qa.w), __uint_as_float(qa.z));
+                            const float fl = floorf(v);
+                            const float fr = v - fl;
+                            ok = fabsf(fr - 0.5f) < __uint_as_float(qb.y) && c1 <= LCG_M - (1u << NEAR_ONE_BITS);
+                            int n = (int)qb.x + (int)fl;
+                            n -= n >> 31;                                  // truncation toward zero (value is not an integer)
+                            q = (int16_t)(uint16_t)((uint32_t)n & 0xffffu);
+                        } else {
+                            const double z = box_muller_exact(c1, lcg_mul(c1, LCG_A));
+                            const float sv = (float)((z * (double)__uint_as_float(qa.w)) + (double)__uint_as_float(qa.z));   // src/gensig.c:268
+                            q = to_i16((double)sv * P.dig / P.range - offset);                                             // src/gensig.c:270
+                        }
+                    }
+                    if (in_shift) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);
+                    if (act && ok) out[at] = q;
+                    if (MODE == 1) push_fix(P, act && !ok, lane, lane_le, sig_base + at, c1, ev_first + ev, r, in_shift ? 1 : 0);
+                }
+            }
+        }
     }
 }
 
