@@ -30,7 +30,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from squigulator_amd import api, model, profiles  # noqa: E402
+from squigulator_amd import api, model, profiles, shard  # noqa: E402
 
 HBM_PEAK_BYTES_PER_S = 8.0e12   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 GENOME = os.path.join(ROOT, "tests", "golden", "inputs", "nCoV-2019.reference.fasta")
@@ -132,23 +132,22 @@ def main():
     k = profiles.default_kmer_size(flags)
     n_k = 1 << (2 * k)
     # pore model: rank 0 owns it; RCCL broadcast to the other GPUs (the only collective on this path)
-    tbl = torch.empty((n_k, 2), dtype=torch.float32, device="cuda")
     if rank == 0:
         mean, stdv = model.synthetic_model(k)
-        tbl.copy_(torch.from_numpy(np.stack([mean, stdv], 1)))
+    else:
+        mean, stdv = np.zeros(n_k, np.float32), np.zeros(n_k, np.float32)
     if world > 1:
-        dist.broadcast(tbl, src=0)
-    tbl_h = tbl.cpu().numpy()
-    mean, stdv = np.ascontiguousarray(tbl_h[:, 0]), np.ascontiguousarray(tbl_h[:, 1])
+        mean, stdv = shard.broadcast_model(mean, stdv, src=0)
 
     K = args.batch_reads
     T = K * world
+    w_lo, w_hi = shard.worker_range(rank, world, T)              # contiguous block of K virtual workers
     gen = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=T, device=local_rank,
                               mode=api.MODE_EXACT if args.mode == "exact" else api.MODE_CERTIFIED,
-                              worker_lo=rank * K, worker_hi=(rank + 1) * K)
+                              worker_lo=w_lo, worker_hi=w_hi)
     genome = load_genome(GENOME)
     rng = np.random.default_rng(42 + rank)
-    workers = np.arange(rank * K, (rank + 1) * K, dtype=np.int32)
+    workers = np.arange(w_lo, w_hi, dtype=np.int32)
 
     nsteps = args.warmup + args.steps
     batches = []

@@ -628,6 +628,21 @@ orc_batch_t *orc_batch_run_seqs(orc_core_t *c, int32_t n_rec, const char *const 
     return run_batch(c, NULL, n_rec, seqs, lens, want_ss, nthreads);
 }
 
+orc_batch_t *orc_batch_run_assigned(orc_core_t *c, int32_t n_rec, const char *const *seqs,
+                                    const int32_t *lens, const int32_t *workers, int want_ss) {
+    orc_batch_t *b = (orc_batch_t *)calloc(1, sizeof *b);
+    b->n = n_rec;
+    b->reads = (orc_read_t *)calloc((size_t)(n_rec > 0 ? n_rec : 1), sizeof(orc_read_t));
+    job_t j = {c, NULL, b, seqs, lens, want_ss, n_rec, 0, PTHREAD_MUTEX_INITIALIZER};
+    for (int32_t i = 0; i < n_rec; i++) one_read(&j, i, workers[i]);   /* index order == per-worker order */
+    for (int32_t i = 0; i < n_rec; i++) {
+        b->reads[i].start_time = c->n_samples;
+        c->n_samples += b->reads[i].len_raw_signal;
+    }
+    c->total_reads += n_rec;
+    return b;
+}
+
 void orc_batch_free(orc_batch_t *b) {
     if (!b) return;
     for (int32_t i = 0; i < b->n; i++) { free(b->reads[i].seq); free(b->reads[i].raw_signal); free(b->reads[i].ss); }

@@ -167,6 +167,10 @@ orc_batch_t *orc_batch_run(orc_core_t *c, const orc_ref_t *ref, int32_t n_rec,
  * used to drive the GPU path and the oracle from the same sequences */
 orc_batch_t *orc_batch_run_seqs(orc_core_t *c, int32_t n_rec, const char *const *seqs,
                                 const int32_t *lens, int want_ss, int nthreads);
+/* as orc_batch_run_seqs but with an explicit worker id per read (reads of one worker are
+ * processed in index order); used by the multi-GPU sharding tests */
+orc_batch_t *orc_batch_run_assigned(orc_core_t *c, int32_t n_rec, const char *const *seqs,
+                                    const int32_t *lens, const int32_t *workers, int want_ss);
 void     orc_batch_free(orc_batch_t *b);
 
 /* worker id of read i in a batch of n_rec under -t T (src/thread.c:80-99,122-125) */

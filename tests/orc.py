@@ -96,6 +96,9 @@ def lib():
         L.orc_batch_run_seqs.restype = C.POINTER(Batch)
         L.orc_batch_run_seqs.argtypes = [C.POINTER(Core), C.c_int32, C.POINTER(C.c_char_p),
                                          C.POINTER(C.c_int32), C.c_int, C.c_int]
+        L.orc_batch_run_assigned.restype = C.POINTER(Batch)
+        L.orc_batch_run_assigned.argtypes = [C.POINTER(Core), C.c_int32, C.POINTER(C.c_char_p),
+                                             C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]
         L.orc_batch_free.argtypes = [C.POINTER(Batch)]
         L.orc_worker_of.restype = C.c_int32
         L.orc_worker_of.argtypes = [C.c_int32, C.c_int32, C.c_int32]
@@ -173,6 +176,14 @@ class Oracle:
         arr = (C.c_char_p * n)(*seqs)
         lens = (C.c_int32 * n)(*[len(s) for s in seqs])
         b = self.L.orc_batch_run_seqs(self.core, n, arr, lens, int(want_ss), nthreads)
+        return self._collect(b, want_ss)
+
+    def run_batch_assigned(self, seqs, workers, want_ss=True):
+        n = len(seqs)
+        arr = (C.c_char_p * n)(*seqs)
+        lens = (C.c_int32 * n)(*[len(s) for s in seqs])
+        wk = (C.c_int32 * n)(*[int(w) for w in workers])
+        b = self.L.orc_batch_run_assigned(self.core, n, arr, lens, wk, int(want_ss))
         return self._collect(b, want_ss)
 
     def simulate(self, n, batch=1000, want_ss=True, nthreads=1):

@@ -1,0 +1,88 @@
+"""N>1 path on CPU: two processes over gloo.  Rank 0 owns the pore model and broadcasts it; every
+rank processes only the reads of the workers it owns (squigulator_amd.shard); gathering the shards
+must reproduce the single-process run bit for bit -- i.e. sharding workers over GPUs changes nothing.
+The per-rank compute stands in for the GPU kernel by calling the oracle (this is a test)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _reads(n, seed):
+    rng = np.random.default_rng(seed)
+    return [bytes(rng.choice(list(b"ACGT"), size=int(L)).astype(np.uint8)) for L in rng.integers(250, 900, size=n)]
+
+
+def _worker(rank, world, port, T, n_batches, K, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import orc
+    from squigulator_amd import model, profiles, shard
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    if rank == 0:
+        mean, stdv = model.synthetic_model(6)
+    else:
+        mean, stdv = np.zeros(4096, np.float32), np.zeros(4096, np.float32)
+    mean, stdv = shard.broadcast_model(mean, stdv, src=0)
+    o = orc.Oracle(prof, fl, 6, mean, stdv, 42, num_workers=T)
+    digest = []
+    for b in range(n_batches):
+        reads = _reads(K, 100 + b)
+        idx, wk = shard.shard_batch(K, T, rank, world)
+        res = o.run_batch_assigned([reads[i] for i in idx], wk, want_ss=False)
+        for i, r in zip(idx, res):
+            digest.append((b, int(i), len(r.sig), int(np.int64(r.sig.astype(np.int64) @ np.arange(1, len(r.sig) + 1) % 1000003)), r.offset))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, digest)
+    if rank == 0:
+        out.put(sorted(sum(gathered, [])))
+    dist.barrier()
+    dist.destroy_process_group()
+    o.close()
+
+
+@pytest.mark.parametrize("T,K", [(8, 8), (6, 13)])
+def test_two_rank_sharding_equals_single_process(T, K):
+    sys.path.insert(0, HERE)
+    import orc
+    from squigulator_amd import model, profiles, shard
+    n_batches = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, T, n_batches, K, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    mean, stdv = model.synthetic_model(6)
+    o = orc.Oracle(prof, fl, 6, mean, stdv, 42, num_workers=T)
+    want = []
+    for b in range(n_batches):
+        reads = _reads(K, 100 + b)
+        res = o.run_batch_assigned(reads, shard.batch_workers(K, T), want_ss=False)
+        for i, r in enumerate(res):
+            want.append((b, i, len(r.sig), int(np.int64(r.sig.astype(np.int64) @ np.arange(1, len(r.sig) + 1) % 1000003)), r.offset))
+    o.close()
+    assert got == sorted(want)

@@ -115,3 +115,37 @@ def test_short_and_odd_reads():
     assert e.n_samples == 0 and e.n_reads == 0
     e.free()
     gen.close(); orac.close()
+
+
+def test_worker_shards_equal_one_context():
+    """Multi-GPU sharding at the C ABI: two contexts owning workers [0,5) and [5,12) (as two GPUs would)
+    reproduce, read for read, what one context owning all 12 workers produces -- over two batches."""
+    import orc
+    from squigulator_amd import model, profiles, shard
+    prof, fl = profiles.get_profile("dna-r10-prom")
+    k = 9
+    mean, stdv = model.synthetic_model(k)
+    rng = np.random.default_rng(5)
+    T = 12
+    batches = [[bytes(rng.choice(list(b"ACGT"), size=int(n)).astype(np.uint8)) for n in rng.integers(300, 1500, size=T)]
+               for _ in range(2)]
+    whole = api.SignalGenerator(prof, fl, k, mean, stdv, seed=9, num_workers=T, mode=api.MODE_CERTIFIED)
+    parts = [api.SignalGenerator(prof, fl, k, mean, stdv, seed=9, num_workers=T, mode=api.MODE_CERTIFIED,
+                                 worker_lo=lo, worker_hi=hi) for lo, hi in ((0, 5), (5, 12))]
+    for reads in batches:
+        bw = whole.submit(reads)
+        sw = bw.signal()
+        for g, (lo, hi) in zip(parts, ((0, 5), (5, 12))):
+            idx = [i for i in range(T) if lo <= i < hi]
+            bp = g.submit([reads[i] for i in idx], workers=idx)
+            sp = bp.signal()
+            for j, i in enumerate(idx):
+                np.testing.assert_array_equal(sp[bp.sig_off[j]:bp.sig_off[j + 1]], sw[bw.sig_off[i]:bw.sig_off[i + 1]])
+                assert bp.offset[j] == bw.offset[i] and bp.median_before[j] == bw.median_before[i]
+            bp.free()
+        bw.free()
+    with pytest.raises(api.SqgError):
+        parts[0].submit([batches[0][0]], workers=[7])          # a worker this context does not own
+    whole.close()
+    for g in parts:
+        g.close()
