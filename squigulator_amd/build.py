@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsqg_hip.so")
 SOURCES = [os.path.join(CSRC, "sqg_hip.hip")]
-HEADERS = [os.path.join(os.path.dirname(HERE), "include", "sqg.h")]
+HEADERS = [os.path.join(os.path.dirname(HERE), "include", "sqg.h"), os.path.join(CSRC, "sqg_kernels.h")]
 ARCH = "gfx950"
 
 

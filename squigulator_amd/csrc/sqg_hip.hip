@@ -49,12 +49,18 @@ struct sqg_ctx {
     bool use_dwell_stream = true, use_kmer_streams = true;
     float delta_x = 0.f;                   // certified mode: swept |x_fast - x_exact| bound incl. margin
     float delta_x_measured = 0.f;
+    double amp_floor = 0, amp_ceil = 0;    // min/max over k-mers of m*kd -/+ 7|sd*kd| (ADC value range before the offset)
+    float thr_all = -1.f;                  // lean-kernel acceptance threshold (0.5 - largest eps over the table)
+    double dwell_hi = 1;                   // hard upper bound of a dwell draw
     bool force_fix = false;
     FixEntry* d_fix = nullptr; size_t fix_cap = 0;
     unsigned int* d_fix_count = nullptr;       // [0] fix-up entries, [1] slow tiles
     uint2* d_evrec = nullptr; size_t evrec_cap = 0;
     uint32_t* d_tile_so = nullptr; size_t tile_cap = 0;
     int* d_slow = nullptr; size_t slow_cap = 0;
+    uint4* d_tfix = nullptr; size_t tfix_cap = 0;
+    unsigned char* d_tfix_n = nullptr; size_t tfixn_cap = 0;
+    long long tile_fix = 0;                // undecided samples parked per tile in the last batch (timing info)
     std::string err;
 };
 
@@ -73,7 +79,8 @@ struct sqg_batch {
     int* d_chain_reads = nullptr;
     int* d_chain_order = nullptr;
     int* d_tile_read = nullptr;
-    long long n_tiles = 0;
+    int* d_stile_read = nullptr;
+    long long n_tiles = 0, n_stiles = 0;
     long long* h_sigoff = nullptr;   // pinned
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel-phase boundaries on the stream
     bool ran = false, waited = false;
@@ -146,6 +153,7 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     (void)hipFree(ctx->d_sig); (void)hipFree(ctx->d_dwell); (void)hipFree(ctx->d_seglen); (void)hipFree(ctx->d_sigoff);
     (void)hipFree(ctx->d_fix); (void)hipFree(ctx->d_fix_count);
     (void)hipFree(ctx->d_evrec); (void)hipFree(ctx->d_tile_so); (void)hipFree(ctx->d_slow);
+    (void)hipFree(ctx->d_tfix); (void)hipFree(ctx->d_tfix_n);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -214,8 +222,8 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     CHK(hipMemcpy(c->d_pow, pw.data(), pw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     CHK(hipMalloc(&c->d_err, sizeof(unsigned int)));
     CHK(hipMemset(c->d_err, 0, sizeof(unsigned int)));
-    CHK(hipMalloc(&c->d_fix_count, 2 * sizeof(unsigned int)));
-    CHK(hipMemset(c->d_fix_count, 0, 2 * sizeof(unsigned int)));
+    CHK(hipMalloc(&c->d_fix_count, 4 * sizeof(unsigned int)));
+    CHK(hipMemset(c->d_fix_count, 0, 4 * sizeof(unsigned int)));
     if (cfg->mode == SQG_MODE_CERTIFIED) {
         // exhaustive sweep of the fp32 deviate against the FP64 one on THIS device (~25 ms):
         // the bound the acceptance test uses is measured, not assumed
@@ -234,6 +242,25 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
         c->delta_x = m * 1.25f + 1.0e-7f;
         // testing knob: inflate the bound so that (almost) every sample takes the FP64 fix-up path
         if (const char* ov = getenv("SQG_TEST_DELTA_X")) { c->delta_x = (float)atof(ov); c->force_fix = true; }
+        // table-wide quantities of the lean kernel (same eps formula as k_samples<1, GENERIC>, per k-mer)
+        const double kd = cfg->profile.digitisation / cfg->profile.range;
+        double lo = 1e300, hi = -1e300, eps_max = 0;
+        for (long long j = 0; j < nk; j++) {
+            const double mkd = (double)hm[(size_t)j].x * kd;
+            const float sdk = (float)((double)hm[(size_t)j].y * kd);
+            const float asdk = std::fabs(sdk);
+            lo = std::min(lo, mkd - 7.0 * asdk); hi = std::max(hi, mkd + 7.0 * asdk);
+            const float eps = c->delta_x * asdk + 5.9604645e-8f * ((float)std::fabs(mkd) + 21.0f * asdk + 3.0f) + 2.0e-7f;
+            eps_max = std::max(eps_max, (double)eps);
+        }
+        c->amp_floor = lo; c->amp_ceil = hi;
+        c->thr_all = std::nextafterf((float)(0.5 - eps_max * 1.000001), 0.0f);
+    }
+    {
+        const sqg_profile_t& q = cfg->profile;
+        const double a = std::floor(q.dwell_mean + 6.5546 * std::fabs(q.dwell_std) + 0.5);
+        const double z = std::floor(std::fabs(q.dwell_mean - 6.5546 * std::fabs(q.dwell_std)) + 0.5) + 1.0;
+        c->dwell_hi = c->use_dwell_stream ? std::max(std::max(a, z), 1.0) + 1.0 : (double)(int)q.dwell_mean;
     }
 
     // per-(worker,k-mer) stream states
@@ -278,7 +305,7 @@ extern "C" void sqg_batch_free(sqg_ctx_t* ctx, sqg_batch_t* b) {
     if (!b) return;
     if (ctx) { (void)hipSetDevice(ctx->cfg.device); if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); }
     (void)hipFree(b->d_bases); (void)hipFree(b->d_reads); (void)hipFree(b->d_blk_read);
-    (void)hipFree(b->d_chain_off); (void)hipFree(b->d_chain_reads); (void)hipFree(b->d_chain_order); (void)hipFree(b->d_tile_read);
+    (void)hipFree(b->d_chain_off); (void)hipFree(b->d_chain_reads); (void)hipFree(b->d_chain_order); (void)hipFree(b->d_tile_read); (void)hipFree(b->d_stile_read);
     if (b->h_sigoff) (void)hipHostFree(b->h_sigoff);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
@@ -324,9 +351,17 @@ extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const 
     b->ev_off[(size_t)n] = nev; b->n_events = nev; b->n_bases = nb;
     // 64-event tiles (the work unit of k_samples); a tile never spans two reads
     long long ntile = 0;
-    for (int i = 0; i < n; i++) { rd[(size_t)i].tile_off = (int)ntile; rd[(size_t)i].pad = 0; ntile += (rd[(size_t)i].ne0 + rd[(size_t)i].ne1 + 63) / 64; }
+    for (int i = 0; i < n; i++) { rd[(size_t)i].tile_off = (int)ntile; rd[(size_t)i].fast = 0; rd[(size_t)i].stile_off = 0; rd[(size_t)i].pad = 0; ntile += (rd[(size_t)i].ne0 + rd[(size_t)i].ne1 + 63) / 64; }
     if (ntile > 2000000000LL) { delete b; c->err = "batch too large"; return SQG_EINVAL; }
     b->n_tiles = ntile;
+    long long nst = 0;                                        // 256-event super tiles (work items of k_samples_lean)
+    for (int i = 0; i < n; i++) { rd[(size_t)i].stile_off = (int)nst; rd[(size_t)i].pad = 0; nst += (rd[(size_t)i].ne0 + rd[(size_t)i].ne1 + LEAN_EV - 1) / LEAN_EV; }
+    b->n_stiles = nst;
+    std::vector<int> stile_read((size_t)std::max<long long>(nst, 1));
+    for (int i = 0; i < n; i++) {
+        const int t1 = (i + 1 < n) ? rd[(size_t)i + 1].stile_off : (int)nst;
+        for (int t = rd[(size_t)i].stile_off; t < t1; t++) stile_read[(size_t)t] = i;
+    }
     std::vector<int> tile_read((size_t)std::max<long long>(ntile, 1));
     for (int i = 0; i < n; i++) {
         const int t1 = (i + 1 < n) ? rd[(size_t)i + 1].tile_off : (int)ntile;
@@ -387,6 +422,8 @@ extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const 
             b->median[(size_t)i] = host_nrng(p.median_before_mean, p.median_before_std, &c->med_x[w]);
         }
         b->offset[(size_t)i] = d.offset;
+        d.fast = (c->cfg.mode == SQG_MODE_CERTIFIED && c->use_kmer_streams && c->dwell_hi <= (double)MULT_N && !getenv("SQG_TEST_NO_LEAN") &&
+                  c->amp_floor - d.offset > 4.0 && c->amp_ceil - d.offset < 65000.0) ? 1 : 0;
         d.time_c0 = c->time_c[w];
         if (c->use_dwell_stream)                          // two draws per event (src/gensig.c:255)
             c->time_c[w] = lcg_mul(c->time_c[w], lcg_pow(a2, (unsigned long long)(d.ne0 + d.ne1)));
@@ -397,13 +434,13 @@ extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const 
         for (int i = 0; i < n; i++) { b->seglen_host[(size_t)2 * i] = sps * rd[(size_t)i].ne0; b->seglen_host[(size_t)2 * i + 1] = sps * rd[(size_t)i].ne1; }
     }
 
-    // dwell kernel launch geometry: first read of every 256-event block
-    const long long nblk = (nev + 255) / 256;
+    // dwell kernel launch geometry: first read of every DW_EPB-event block
+    const long long nblk = (nev + DW_EPB - 1) / DW_EPB;
     std::vector<int> blk_read((size_t)std::max<long long>(nblk, 1), 0);
     {
         int r = 0;
         for (long long bi = 0; bi < nblk; bi++) {
-            const long long g = bi * 256;
+            const long long g = bi * DW_EPB;
             while (r + 1 < n && g >= rd[(size_t)r + 1].ev_off) r++;
             blk_read[(size_t)bi] = r;
         }
@@ -421,6 +458,8 @@ extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const 
     CHKB(hipMemcpyAsync(b->d_chain_off, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     CHKB(hipMalloc(&b->d_chain_reads, std::max<size_t>(1, chain_reads.size()) * sizeof(int)));
     if (n) CHKB(hipMemcpyAsync(b->d_chain_reads, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    CHKB(hipMalloc(&b->d_stile_read, stile_read.size() * sizeof(int)));
+    CHKB(hipMemcpyAsync(b->d_stile_read, stile_read.data(), stile_read.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     CHKB(hipMalloc(&b->d_tile_read, tile_read.size() * sizeof(int)));
     CHKB(hipMemcpyAsync(b->d_tile_read, tile_read.data(), tile_read.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     CHKB(hipMalloc(&b->d_chain_order, std::max<size_t>(1, chain_order.size()) * sizeof(int)));
@@ -431,6 +470,17 @@ extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const 
 #undef CHKB
     c->next_stage++;
     *out = b;
+    return SQG_OK;
+}
+
+// debugging aid: SQG_DEBUG_SYNC=1 synchronises after every launch and names the kernel that faulted
+static int dbg_sync(sqg_ctx* c, const char* what) {
+    static const bool on = getenv("SQG_DEBUG_SYNC") != nullptr;
+    if (!on) return SQG_OK;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { c->err = std::string(what) + ": " + hipGetErrorString(e); fprintf(stderr, "[sqg] %s\n", c->err.c_str()); return SQG_EDEVICE; }
+    fprintf(stderr, "[sqg] %s ok\n", what);
     return SQG_OK;
 }
 
@@ -454,12 +504,17 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     if ((rc = ensure(c, (void**)&c->d_evrec, &c->evrec_cap, (size_t)b->n_events + 64, sizeof(uint2)))) return rc;
     if ((rc = ensure(c, (void**)&c->d_tile_so, &c->tile_cap, (size_t)b->n_tiles + 64, sizeof(uint32_t)))) return rc;
     if ((rc = ensure(c, (void**)&c->d_slow, &c->slow_cap, (size_t)b->n_tiles + 64, sizeof(int)))) return rc;
+    if (certified && c->use_kmer_streams) {
+        if ((rc = ensure(c, (void**)&c->d_tfix, &c->tfix_cap, (size_t)b->n_stiles * FIX_SLOTS + 64, sizeof(uint4)))) return rc;
+        if ((rc = ensure(c, (void**)&c->d_tfix_n, &c->tfixn_cap, (size_t)b->n_stiles + 64, 1))) return rc;
+        HIPCHK(c, hipMemsetAsync(c->d_tfix_n, 0, (size_t)b->n_stiles + 1, c->stream));
+    }
 
     HIPCHK(c, hipEventRecord(b->ev[0], c->stream));
     if (n > 0) {
         if (c->use_dwell_stream) {
             HIPCHK(c, hipMemsetAsync(c->d_seglen, 0, (size_t)2 * n * sizeof(unsigned long long), c->stream));
-            const long long nblk = (b->n_events + 255) / 256;
+            const long long nblk = (b->n_events + DW_EPB - 1) / DW_EPB;
             if (nblk > 0)
             {
                 if (certified)
@@ -472,8 +527,10 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
         } else {
             HIPCHK(c, hipMemcpyAsync(c->d_seglen, b->seglen_host.data(), (size_t)2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
         }
+        if ((rc = dbg_sync(c, "k_dwell"))) return rc;
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_seglen, n, c->d_sigoff, c->d_err);
         HIPCHK(c, hipGetLastError());
+        if ((rc = dbg_sync(c, "k_scan"))) return rc;
     }
     HIPCHK(c, hipEventRecord(b->ev[1], c->stream));
     // Output size is data-dependent.  A hard bound exists (|z| <= sqrt(2 ln(2^31-1)) = 6.5546 for any
@@ -483,12 +540,7 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     else b->h_sigoff[0] = 0;
     size_t need_samples;
     {
-        double hi = 1.0;
-        if (c->use_dwell_stream) {
-            const double a = std::floor(p.dwell_mean + 6.5546 * std::fabs(p.dwell_std) + 0.5);
-            const double z = std::floor(std::fabs(p.dwell_mean - 6.5546 * std::fabs(p.dwell_std)) + 0.5) + 1.0;
-            hi = std::max(std::max(a, z), 1.0) + 1.0;
-        } else hi = (double)(int)p.dwell_mean;
+        const double hi = c->dwell_hi;
         const double bound = hi * (double)b->n_events;
         if (bound <= 4.0e10) need_samples = (size_t)bound;
         else {
@@ -500,7 +552,7 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     if (certified && c->use_kmer_streams) {
         if ((rc = ensure(c, (void**)&c->d_fix, &c->fix_cap, (c->force_fix ? need_samples : need_samples / 256) + 65536, sizeof(FixEntry)))) return rc;
     }
-    HIPCHK(c, hipMemsetAsync(c->d_fix_count, 0, 2 * sizeof(unsigned int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_fix_count, 0, 4 * sizeof(unsigned int), c->stream));
 
     HIPCHK(c, hipEventRecord(b->ev[2], c->stream));
     if (n > 0 && b->n_chains > 0) {
@@ -510,7 +562,7 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
         P.seglen = c->d_seglen; P.sig_off = c->d_sigoff; P.model = c->d_model; P.pw = c->d_pow; P.rows = c->d_rows;
         P.sig = c->d_sig; P.err = c->d_err; P.dig = p.digitisation; P.range = p.range; P.kd = p.digitisation / p.range;
         P.chain_order = b->d_chain_order; P.fix = c->d_fix; P.fix_count = c->d_fix_count;
-        P.fix_cap = (unsigned int)std::min<size_t>(c->fix_cap, 0xffffffffu); P.delta_x = c->delta_x;
+        P.fix_cap = (unsigned int)std::min<size_t>(c->fix_cap, 0xffffffffu); P.delta_x = c->delta_x; P.thr_all = c->thr_all;
         P.k = c->k; P.num_kmer = c->num_kmer; P.const_sps = (int)p.dwell_mean;
         P.use_streams = c->use_kmer_streams ? 1 : 0;
         P.rna = (c->cfg.flags & SQG_RNA) ? 1 : 0;
@@ -521,18 +573,26 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
             int32_t t = (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000u;
             P.shift = (int)(int16_t)(uint16_t)((uint32_t)t & 0xffffu);
         }
-        P.evrec = c->d_evrec; P.tile_so = c->d_tile_so; P.tile_read = b->d_tile_read;
-        P.slow_tiles = nullptr; P.slow_count = c->d_fix_count + 1;
+        P.evrec = c->d_evrec; P.tile_so = c->d_tile_so; P.tile_read = b->d_tile_read; P.stile_read = b->d_stile_read;
+        P.slow_tiles = nullptr; P.slow_count = c->d_fix_count + 1; P.tfix = c->d_tfix; P.tfix_n = c->d_tfix_n;
         constexpr int NT = SQG_EVENT_THREADS;
         const int n_tiles = (int)b->n_tiles;
         const unsigned sgrid = (unsigned)((n_tiles + 3) / 4);
         hipLaunchKernelGGL((k_events<NT>), dim3((unsigned)b->n_chains), dim3(NT), 0, c->stream, P);
         HIPCHK(c, hipEventRecord(b->ev[3], c->stream));
+        if ((rc = dbg_sync(c, "k_events"))) return rc;
         if (certified && c->use_kmer_streams) {
             P.slow_tiles = c->d_slow;
-            hipLaunchKernelGGL((k_samples<1, false>), dim3(sgrid), dim3(256), 0, c->stream, P, n_tiles);
+            const int n_stiles = (int)b->n_stiles;
+            const unsigned lgrid = (unsigned)((n_stiles + 3) / 4);
+            if (P.rna) hipLaunchKernelGGL((k_samples_lean<true>), dim3(lgrid), dim3(256), 0, c->stream, P, n_stiles);
+            else hipLaunchKernelGGL((k_samples_lean<false>), dim3(lgrid), dim3(256), 0, c->stream, P, n_stiles);
+            if ((rc = dbg_sync(c, "k_samples_lean"))) return rc;
             hipLaunchKernelGGL((k_samples<1, true>), dim3(std::min(sgrid, 4096u)), dim3(256), 0, c->stream, P, n_tiles);
+            if ((rc = dbg_sync(c, "k_samples<generic>"))) return rc;
             hipLaunchKernelGGL(k_fixup, dim3(512), dim3(256), 0, c->stream, P);
+            hipLaunchKernelGGL(k_fixup_tiles, dim3((unsigned)((n_stiles + 255) / 256)), dim3(256), 0, c->stream, P, n_stiles);
+            if ((rc = dbg_sync(c, "k_fixup"))) return rc;
         } else if (certified) {
             hipLaunchKernelGGL((k_samples<1, true>), dim3(sgrid), dim3(256), 0, c->stream, P, n_tiles);
         } else {
@@ -568,7 +628,16 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
         HIPCHK(c, hipEventElapsedTime(&t, b->ev[0], b->ev[4]));
         c->timing.events_ms = ee;
         unsigned int nfix = 0;
-        if (c->cfg.mode == SQG_MODE_CERTIFIED) HIPCHK(c, hipMemcpy(&nfix, c->d_fix_count, sizeof nfix, hipMemcpyDeviceToHost));
+        if (c->cfg.mode == SQG_MODE_CERTIFIED) {
+            unsigned int cnt[4] = {0, 0, 0, 0};
+            HIPCHK(c, hipMemcpy(cnt, c->d_fix_count, sizeof cnt, hipMemcpyDeviceToHost));
+            nfix = cnt[0];                                  // global list ...
+            if (c->use_kmer_streams && b->n_stiles > 0) {   // ... plus the per-tile slots of the lean kernel
+                std::vector<unsigned char> tn((size_t)b->n_stiles);
+                HIPCHK(c, hipMemcpy(tn.data(), c->d_tfix_n, tn.size(), hipMemcpyDeviceToHost));
+                for (unsigned char v : tn) nfix += v;
+            }
+        }
         c->timing.dwell_ms = d; c->timing.samples_ms = s; c->timing.total_ms = t; c->timing.fallback_samples = nfix;
         b->waited = true;
     }

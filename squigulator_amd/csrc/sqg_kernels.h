@@ -113,6 +113,8 @@ struct ReadDesc {
     int worker;           // context-local worker index
     uint32_t time_c0;     // worker's time-stream state at the start of this read
     int tile_off;         // first 64-event tile of this read in the batch's tile arrays
+    int fast;             // certified mode: every ADC value of this read is provably in (2, 65000) -> lean kernel
+    int stile_off;        // first 256-event super tile of this read
     int pad;
 };
 
@@ -145,10 +147,14 @@ struct SigParams {
     uint2* evrec;                // per event {stream state at its first draw, k-mer rank}
     uint32_t* tile_so;           // per 64-event tile: its first sample within the read
     const int* tile_read;        // per tile: read index
+    const int* stile_read;       // per 256-event super tile (lean kernel work item): read index
     int* slow_tiles;             // tiles the lean sample kernel left to the generic one
     unsigned int* slow_count;
+    uint4* tfix;                 // lean kernel: FIX_SLOTS undecided samples per tile {index in read, c1, event in read, 0}
+    unsigned char* tfix_n;       // lean kernel: entries used per tile
     double dig, range, kd;       // kd = dig/range
     float delta_x;               // swept bound on |x_fast - x_exact| (incl. margin)
+    float thr_all;               // 1/2 - (largest eps over all k-mers): acceptance threshold of the lean kernel
     int k, num_kmer;
     int const_sps;               // (int)dwell_mean, used when dwell == null
     int use_streams;             // 0 in --ideal / --ideal-amp (src/gensig.c:265-269)
@@ -172,7 +178,9 @@ __global__ void k_init_rows(uint32_t* rows, int num_kmer, long long seed, int wo
 // sps = round(nrng(rand_time)); sps = sps<1 ? -sps+1 : sps           (src/gensig.c:255-256)
 // Event e of a read uses draws 2e+1, 2e+2 after the worker's time-stream state at the start of
 // the read: position addressed by the jump a^(2e) (two LDS table levels, a third in memory).
-#define DW_RD 8            // read descriptors cached per 256-event block (reads are >= ~190 events)
+#define DW_RD 16           // read descriptors cached per block (reads are >= ~190 events)
+#define DW_IT 8            // events per thread: the block's fixed latencies (tables, descriptors) are paid once per 2048 events
+#define DW_EPB (256 * DW_IT)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_dwell(const ReadDesc* __restrict__ reads, int n_reads,
                                                const int* __restrict__ blk_read, long long n_events,
@@ -194,60 +202,61 @@ __global__ __launch_bounds__(256) void k_dwell(const ReadDesc* __restrict__ read
         if (tid < DW_RD && q < n_reads) { r_c0[tid] = reads[q].time_c0; r_ne0[tid] = reads[q].ne0; }
     }
     __syncthreads();
-    const long long gid = (long long)blockIdx.x * 256 + tid;
-    const bool valid = gid < n_events;
-    int r = rb;
-    int sps = 0, seg = 0;
-    if (valid) {
-        int q = 0;
-        while (q + 1 < DW_RD && gid >= r_ev[q + 1]) q++;
-        uint32_t e, c0; int ne0;
-        if (gid < r_ev[q + 1]) { e = (uint32_t)(gid - r_ev[q]); c0 = r_c0[q]; ne0 = r_ne0[q]; r = rb + q; }
-        else {                                         // more than DW_RD reads in one block: walk the table
-            r = rb + q;
-            while (r + 1 < n_reads && gid >= reads[r + 1].ev_off) r++;
-            e = (uint32_t)(gid - reads[r].ev_off); c0 = reads[r].time_c0; ne0 = reads[r].ne0;
-        }
-        uint32_t jp = j0[e & (POW_N - 1)];
-        const uint32_t hi = (e >> 10) & (POW_N - 1), hi2 = e >> 20;
-        if (hi) jp = lcg_mul(jp, j1[hi]);
-        if (hi2) jp = lcg_mul(jp, pw[4 * POW_N + hi2]);
-        const uint32_t c1 = lcg_mul(lcg_mul(c0, jp), LCG_A);
-        bool decided = false;
-        if (MODE == 1) {
-            // v' = x'*s + m in fp32; round(v) = floor(v+1/2) unless v is within eps of a half-integer
-            const float sf = (float)dstd, mf = (float)dmean;
-            const float x = box_muller_fast(c1, lcg_mul_lazy(c1, LCG_A));
-            const float g = __builtin_fmaf(x, sf, mf) + 0.5f;
-            const float fl = floorf(g);
-            const float fr = g - fl;
-            const float mag = fabsf(mf) + 7.0f * fabsf(sf) + 1.0f;
-            // delta_x*s (swept) + float roundings of s, m, the fma and the +1/2 (each <= 2^-24 * mag) + slack
-            const float eps = delta_x * fabsf(sf) + 4.0f * 5.9604645e-8f * mag + 1e-6f;
-            if (fabsf(fr - 0.5f) < 0.5f - eps && c1 <= LCG_M - (1u << NEAR_ONE_BITS) && fabsf(g) < 1.0e6f) {
-                sps = (int)fl;
-                decided = true;
+    const float sf = (float)dstd, mf = (float)dmean;
+    const float mag = fabsf(mf) + 7.0f * fabsf(sf) + 1.0f;
+    // delta_x*s (swept) + float roundings of s, m, the fma and the +1/2 (each <= 2^-24 * mag) + slack
+    const float eps = delta_x * fabsf(sf) + 4.0f * 5.9604645e-8f * mag + 1e-6f;
+    int q = 0;                                          // cached descriptor index (monotone over the iterations)
+    for (int it = 0; it < DW_IT; it++) {
+        const long long gid = (long long)blockIdx.x * DW_EPB + it * 256 + tid;
+        const bool valid = gid < n_events;
+        int r = rb, sps = 0, seg = 0;
+        if (valid) {
+            while (q + 1 < DW_RD && gid >= r_ev[q + 1]) q++;
+            uint32_t e, c0; int ne0;
+            if (gid < r_ev[q + 1]) { e = (uint32_t)(gid - r_ev[q]); c0 = r_c0[q]; ne0 = r_ne0[q]; r = rb + q; }
+            else {                                     // more than DW_RD reads in one block: walk the table
+                r = rb + q;
+                while (r + 1 < n_reads && gid >= reads[r + 1].ev_off) r++;
+                e = (uint32_t)(gid - reads[r].ev_off); c0 = reads[r].time_c0; ne0 = reads[r].ne0;
             }
+            uint32_t jp = j0[e & (POW_N - 1)];
+            const uint32_t hi = (e >> 10) & (POW_N - 1), hi2 = e >> 20;
+            if (hi) jp = lcg_mul(jp, j1[hi]);
+            if (hi2) jp = lcg_mul(jp, pw[4 * POW_N + hi2]);
+            const uint32_t c1 = lcg_mul(lcg_mul(c0, jp), LCG_A);
+            bool decided = false;
+            if (MODE == 1) {
+                // v' = x'*s + m in fp32; round(v) = floor(v+1/2) unless v is within eps of a half-integer
+                const float x = box_muller_fast(c1, lcg_mul_lazy(c1, LCG_A));
+                const float g = __builtin_fmaf(x, sf, mf) + 0.5f;
+                const float fl = floorf(g);
+                const float fr = g - fl;
+                if (fabsf(fr - 0.5f) < 0.5f - eps && c1 <= LCG_M - (1u << NEAR_ONE_BITS) && fabsf(g) < 1.0e6f) {
+                    sps = (int)fl;
+                    decided = true;
+                }
+            }
+            if (!decided) {
+                const double z = box_muller_exact(c1, lcg_mul(c1, LCG_A));
+                const double v = (z * dstd) + dmean;                 // nrng: (x * s) + m
+                sps = (int)round(v);                                 // src/gensig.c:255
+            }
+            sps = sps < 1 ? -sps + 1 : sps;                          // src/gensig.c:256
+            if (sps > 65535) { atomicOr(err, 1u); sps = 65535; }
+            dwell[gid] = (uint16_t)sps;
+            seg = e >= (uint32_t)ne0;
         }
-        if (!decided) {
-            const double z = box_muller_exact(c1, lcg_mul(c1, LCG_A));
-            const double v = (z * dstd) + dmean;                 // nrng: (x * s) + m
-            sps = (int)round(v);                                 // src/gensig.c:255
+        // per-read totals: one atomic per wavefront when the wave is inside one (read, segment)
+        const int key = valid ? (r * 2 + seg) : -1;
+        const int key0 = __shfl(key, 0);
+        if (__all(key == key0)) {
+            int sum = sps;
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+            if ((tid & 63) == 0 && key0 >= 0) atomicAdd(&seglen[key0], (unsigned long long)sum);
+        } else if (valid) {
+            atomicAdd(&seglen[key], (unsigned long long)sps);
         }
-        sps = sps < 1 ? -sps + 1 : sps;                          // src/gensig.c:256
-        if (sps > 65535) { atomicOr(err, 1u); sps = 65535; }
-        dwell[gid] = (uint16_t)sps;
-        seg = e >= (uint32_t)ne0;
-    }
-    // per-read totals: one atomic per wavefront when the wave is inside one (read, segment)
-    const int key = valid ? (r * 2 + seg) : -1;
-    const int key0 = __shfl(key, 0);
-    if (__all(key == key0)) {
-        int sum = sps;
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
-        if ((tid & 63) == 0 && key0 >= 0) atomicAdd(&seglen[key0], (unsigned long long)sum);
-    } else if (valid) {
-        atomicAdd(&seglen[key], (unsigned long long)sps);
     }
 }
 
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restr
 #define SQG_EVENT_THREADS 512
 #endif
 #define MK_W 1024          // marker window (samples) per wavefront
-#define MULT_N 256         // LDS jump constants cover events of up to 256 samples
+#define MULT_N 512         // LDS jump constants cover events of up to 512 samples
 #define BIN_EMPTY 0xffffffffu
 
 __device__ static inline int wave_incl_scan(int v, int lane) {
@@ -461,6 +470,181 @@ __device__ static inline void push_fix(const SigParams& P, bool bad, int lane, u
                 P.fix[slot] = fe;
             } else atomicOr(P.err, 8u);
         }
+    }
+}
+
+// inclusive wave scan with DPP row shifts/broadcasts (6 VALU, no LDS)
+__device__ static inline int wave_incl_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
+#define LEAN_EPL 4                         // events per lane
+#define LEAN_EV (64 * LEAN_EPL)            // events per wavefront work item ("super tile" = 4 consecutive 64-event tiles of one read)
+#define FIX_SLOTS 8                        // parked undecided samples per super tile (expected ~0.5); overflow -> global list
+
+struct LeanWaveLds {
+    uint4 rec[LEAN_EV];         // {c_ev, (I << 16) | first sample in super tile, F, sdk}
+    uint8_t mk[MK_W + 64];      // marker at (first sample - 1) of events 1.. (+64: the pipelined loop reads one step ahead)
+};
+struct LeanLds {
+    uint2 mult[MULT_N];         // {a^(2j+1), a^(2j+2)}
+    LeanWaveLds w[4];
+};
+
+// k_samples_lean: the hot kernel.  Certified fp32 path only, for reads whose ADC values are provably in
+// (2, 65000) (ReadDesc.fast), events of <= MULT_N samples, outside the RNA level-shift window; everything
+// else is queued (as 64-event tiles) for k_samples<MODE, GENERIC>.
+// One wavefront per 256 consecutive events of a read (4 per lane: the three dependent global round trips
+// of the set-up are paid once per ~2300 samples).  Per step 64 consecutive samples:
+//   marker byte -> ballot/mbcnt -> event -> {state, I|first, F, sdk} (one ds_read_b128) ->
+//   jump constants (ds_read_b64) -> 2 modular multiplications -> v_log/v_sqrt/v_cos -> fma ->
+//   floor / acceptance test -> int16 store.  The loads of step i+1 are issued before the arithmetic of
+//   step i (software pipelining).
+template <bool RNA>
+__global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const int n_stiles) {
+    __shared__ LeanLds L;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < MULT_N; i += 256) L.mult[i] = make_uint2(P.pw[i], P.pw[POW_N + i]);
+    __syncthreads();
+    LeanWaveLds& W = L.w[wid];
+    const unsigned long long lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);
+    const float thr = P.thr_all;
+
+    for (int g = blockIdx.x * 4 + wid; g < n_stiles; g += gridDim.x * 4) {
+        const int r = P.stile_read[g];
+        const ReadDesc rd = P.reads[r];
+        const int lt = g - rd.stile_off;                               // super tile within the read
+        const int ne = rd.ne0 + rd.ne1;
+        const int e0 = lt * LEAN_EV + lane * LEAN_EPL;                 // my first event (within the read)
+        const long long gev = rd.ev_off + e0;
+        // ---- set-up: 4 consecutive events per lane ----
+        uint2 er[LEAN_EPL];
+        int sps[LEAN_EPL];
+        if (e0 + LEAN_EPL <= ne) {
+            const uint4 a = *reinterpret_cast<const uint4*>(P.evrec + gev);          // gev is a multiple of 4 only within a read;
+            const uint4 b = *reinterpret_cast<const uint4*>(P.evrec + gev + 2);      // 8-B elements: 16-B aligned iff gev even
+            er[0] = make_uint2(a.x, a.y); er[1] = make_uint2(a.z, a.w); er[2] = make_uint2(b.x, b.y); er[3] = make_uint2(b.z, b.w);
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) sps[q] = P.dwell ? (int)P.dwell[gev + q] : P.const_sps;
+        } else {
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) {
+                const bool v = e0 + q < ne;
+                er[q] = v ? P.evrec[gev + q] : make_uint2(0u, 0u);
+                sps[q] = v ? (P.dwell ? (int)P.dwell[gev + q] : P.const_sps) : 0;
+            }
+        }
+        float2 md[LEAN_EPL];
+#pragma unroll
+        for (int q = 0; q < LEAN_EPL; q++) md[q] = (e0 + q < ne) ? P.model[er[q].y] : make_float2(0.f, 0.f);
+        const int lane_total = sps[0] + sps[1] + sps[2] + sps[3];
+        const int incl = wave_incl_scan_dpp(lane_total);
+        const int wave_total = __builtin_amdgcn_readlane(incl, 63);
+        const uint32_t base_pos = P.tile_so[rd.tile_off + lt * LEAN_EPL];
+        const long long sig_base = P.sig_off[r];
+        bool take = rd.fast != 0;
+        if (P.shift_len > 0) {                                         // RNA adaptor level-shift window (src/genread.c:79-86)
+            const long long n1 = (long long)P.seglen[2 * r];
+            if ((long long)base_pos + wave_total > n1 - P.shift_len && (long long)base_pos < n1) take = false;
+        }
+        if (!take) {                                                   // leave these (up to 4) 64-event tiles to the generic kernel
+            const int nt = min(LEAN_EPL, (ne - lt * LEAN_EV + 63) >> 6);
+            if (lane < nt) { const unsigned int q = atomicAdd(P.slow_count, 1u); P.slow_tiles[q] = rd.tile_off + lt * LEAN_EPL + lane; }
+            continue;
+        }
+        if (wave_total <= 0) continue;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // previous item's LDS reads are done
+        int so[LEAN_EPL];
+        {
+            int run = incl - lane_total;
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) {
+                so[q] = run; run += sps[q];
+                // v = s_f*dig/range - offset  ~  x*(sd*kd) + (m*kd - offset) = x*sdk + (I + F), I = floor(.) in (2, 65000)
+                const double mk = (double)md[q].x * P.kd - rd.offset;
+                const double fl0 = floor(mk);
+                const float F = (float)(mk - fl0);
+                const float sdk = (float)((double)md[q].y * P.kd);
+                W.rec[lane * LEAN_EPL + q] = make_uint4(er[q].x, ((uint32_t)(int)fl0 << 16) | (uint32_t)so[q], __float_as_uint(F), __float_as_uint(sdk));
+            }
+        }
+        int16_t* out = P.sig + sig_base;
+        const uint32_t read_len = (uint32_t)(P.sig_off[r + 1] - sig_base);
+        const uint32_t a_top = read_len - 1 - base_pos;                // RNA: generation index i is stored at a_top - i
+        const int ev_read0 = lt * LEAN_EV;                             // event index (within the read) of rec[0]
+
+        int nfix = 0;                                                  // undecided samples of this item so far (wave-uniform)
+        for (int w0 = 0; w0 < wave_total; w0 += MK_W) {
+            ((uint4*)W.mk)[lane] = make_uint4(0, 0, 0, 0);
+            if (lane < 4) ((uint4*)W.mk)[64 + lane] = make_uint4(0, 0, 0, 0);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            int before = 0;                                            // my events (other than event 0) begun before this window
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) {
+                const int mpos = so[q] - 1 - w0;                       // marker of an event sits one sample early
+                const bool real = (e0 + q < ne) && (lane | q) != 0;
+                if (real && mpos >= 0 && mpos < MK_W) W.mk[mpos] = 1;
+                before += (real && mpos < 0) ? 1 : 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            int base_ev = before;
+            for (int o = 32; o > 0; o >>= 1) base_ev += __shfl_xor(base_ev, o);
+            const int w_len = min(MK_W, wave_total - w0);
+            const int nchunk = (w_len + 63) >> 6;
+            // prologue: loads of chunk 0
+            unsigned long long sm = __ballot(W.mk[lane] != 0);
+            int ev = base_ev + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
+            base_ev += __popcll(sm);
+            uint4 ra = W.rec[ev];
+            uint2 mu = L.mult[((uint32_t)(w0 + lane) - (ra.y & 0xffffu)) & (MULT_N - 1)];
+            for (int c = 0; c < nchunk; c++) {
+                const int idx = w0 + c * 64 + lane;                    // sample index within the item
+                // ---- loads of chunk c+1, unconditional (the marker pad makes the last one harmless) ----
+                sm = __ballot(W.mk[(c + 1) * 64 + lane] != 0);
+                const int ev_n = min(base_ev + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u)), LEAN_EV - 1);
+                base_ev += __popcll(sm);
+                const uint4 ra_n = W.rec[ev_n];
+                // ---- arithmetic of chunk c ----
+#if defined(SQG_EXP_NOMAD)      /* ablation builds (bench only; results are wrong) */
+                const uint32_t c1 = (ra.x ^ mu.x) & 0x7fffffffu, r2 = ra.x + mu.y;
+#else
+                const uint32_t c1 = lcg_mul(ra.x, mu.x);
+                const uint32_t r2 = lcg_mul_lazy(ra.x, mu.y);
+#endif
+#if defined(SQG_EXP_NOTRANS)
+                const float x = (float)c1 * 1e-9f + (float)r2 * 1e-10f;
+#else
+                const float x = box_muller_fast(c1, r2);
+#endif
+                const float v = __builtin_fmaf(x, __uint_as_float(ra.w), __uint_as_float(ra.z));
+                const float fl = floorf(v);
+                const float fr = v - fl;
+                const bool act = idx < w0 + w_len;
+                const bool ok = fabsf(fr - 0.5f) < thr && c1 <= LCG_M - (1u << NEAR_ONE_BITS);
+                const int n = (int)(ra.y >> 16) + (int)fl;
+                const uint32_t at = RNA ? (a_top - (uint32_t)idx) : (base_pos + (uint32_t)idx);
+                if (act && ok) out[at] = (int16_t)(uint16_t)((uint32_t)n & 0xffffu);
+                const unsigned long long am = __ballot(act && !ok);
+                if (am) {                                              // ~1 % of steps: park the undecided samples (no round trip)
+                    const int slot = nfix + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+                    nfix += __popcll(am);
+                    if (act && !ok) {
+                        if (slot < FIX_SLOTS) P.tfix[(size_t)g * FIX_SLOTS + slot] = make_uint4(at, c1, (uint32_t)(ev_read0 + ev), 0u);
+                    }
+                    if (nfix > FIX_SLOTS)                              // overflow (never in practice): global list
+                        push_fix(P, act && !ok && slot >= FIX_SLOTS, lane, lane_le, sig_base + at, c1, rd.ev_off + ev_read0 + ev, r, 0);
+                }
+                const uint2 mu_n = L.mult[((uint32_t)(idx + 64) - (ra_n.y & 0xffffu)) & (MULT_N - 1)];
+                ra = ra_n; mu = mu_n; ev = ev_n;
+            }
+        }
+        if (nfix && lane == 0) P.tfix_n[g] = (unsigned char)min(nfix, FIX_SLOTS);
     }
 }
 
@@ -635,6 +819,27 @@ __global__ __launch_bounds__(256) void k_samples(const SigParams P, const int n_
 }
 
 // ---- k_fixup: FP64 path for the samples k_signal<CERTIFIED> left undecided -------------------
+// per-tile slots of the lean kernel: one thread per super tile walks its (0-8, typically 0-1) parked samples.
+// No atomics: a returning atomic per wavefront on one counter costs ~10 ns each and serialises.
+__global__ __launch_bounds__(256) void k_fixup_tiles(const SigParams P, const int n_stiles) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_stiles) return;
+    const int n = (int)P.tfix_n[g];
+    if (n == 0) return;
+    const int r = P.stile_read[g];
+    const ReadDesc rd = P.reads[r];
+    const long long sig_base = P.sig_off[r];
+    for (int slot = 0; slot < n; slot++) {
+        const uint4 fe = P.tfix[(size_t)g * FIX_SLOTS + slot];
+        const int e = (int)fe.z;
+        const uint8_t* bp = P.bases + rd.base_off + (e < rd.ne0 ? (long long)e : (long long)rd.len0 + (e - rd.ne0));
+        uint32_t rank = 0;
+        for (int q = 0; q < P.k; q++) rank = (rank << 2) | base_code(bp[q]);
+        const float2 md = P.model[rank];
+        P.sig[sig_base + fe.x] = sample_exact(fe.y, md.x, md.y, P.dig, P.range, rd.offset);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fixup(const SigParams P) {
     const unsigned int n = min(*P.fix_count, P.fix_cap);
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
