@@ -578,7 +578,8 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
         constexpr int NT = SQG_EVENT_THREADS;
         const int n_tiles = (int)b->n_tiles;
         const unsigned sgrid = (unsigned)((n_tiles + 3) / 4);
-        hipLaunchKernelGGL((k_events<NT>), dim3((unsigned)b->n_chains), dim3(NT), 0, c->stream, P);
+        if (c->k <= 6) hipLaunchKernelGGL((k_events<NT, true>), dim3((unsigned)b->n_chains), dim3(NT), 0, c->stream, P);
+        else hipLaunchKernelGGL((k_events<NT, false>), dim3((unsigned)b->n_chains), dim3(NT), 0, c->stream, P);
         HIPCHK(c, hipEventRecord(b->ev[3], c->stream));
         if ((rc = dbg_sync(c, "k_events"))) return rc;
         if (certified && c->use_kmer_streams) {

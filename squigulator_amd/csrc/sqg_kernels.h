@@ -321,10 +321,11 @@ __device__ static inline int wave_incl_scan(int v, int lane) {
 #define EV_NIL 0xffffu
 #define EV_HALO 20          // 2*(k_max-1)+2 extra base codes per segment (segment-0/1 boundary)
 
-template <int NT>
+// DIRECT (k <= 6): one bin per k-mer rank, no keys, no probing; otherwise an open-addressing hash of 2*NT bins
+template <int NT, bool DIRECT>
 struct EvLds {
-    uint32_t keys[2 * NT];      // hash bins: k-mer rank
-    uint32_t head[2 * NT];      // bin -> most recently inserted event of the segment (EV_NIL: none)
+    uint32_t keys[DIRECT ? 1 : 2 * NT];      // hash bins: k-mer rank
+    uint32_t head[DIRECT ? 4096 : 2 * NT];   // bin -> most recently inserted event of the segment (EV_NIL: none)
     uint32_t nxt[NT];           // per event: (dwell << 16) | next event in the same bin
     uint32_t jump[MULT_N];      // a^(2j)
     uint8_t codes[NT + EV_HALO + 4];   // 2-bit base codes of the segment
@@ -337,13 +338,14 @@ __device__ static inline void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int NT>
+template <int NT, bool DIRECT>
 __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
-    __shared__ EvLds<NT> L;
+    __shared__ EvLds<NT, DIRECT> L;
     constexpr int NW = NT / 64, HT = 2 * NT;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < MULT_N; i += NT) L.jump[i] = P.pw[2 * POW_N + i];
     for (int i = tid; i < 256; i += NT) L.lut[i] = (uint8_t)base_code((uint8_t)i);
+    if (DIRECT) for (int i = tid; i < 4096; i += NT) L.head[i] = EV_NIL;      // kept clean by the events themselves
 
     const int chain = P.chain_order[blockIdx.x];
     const int c_lo = P.chain_off[chain], c_hi = P.chain_off[chain + 1];
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
             const int sps = valid ? (P.dwell ? (int)d_cur : P.const_sps) : 0;
             const int incl = wave_incl_scan(sps, lane);
             if (lane == 63) L.wsum[wid] = incl;
-            if (P.use_streams) for (int i = tid; i < HT; i += NT) { L.keys[i] = BIN_EMPTY; L.head[i] = EV_NIL; }
+            if (!DIRECT && P.use_streams) for (int i = tid; i < HT; i += NT) { L.keys[i] = BIN_EMPTY; L.head[i] = EV_NIL; }
             lds_barrier();                                                                    // (1)
             int woff = 0, seg_total = 0;
             for (int w = 0; w < NW; w++) { const int x = L.wsum[w]; if (w < wid) woff += x; seg_total += x; }
@@ -388,12 +390,14 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
                 const int cb = (int)(EV_BASE(e) - bseg);
                 for (int i = 0; i < k; i++) rank = (rank << 2) | L.codes[cb + i];               // src/seq.h:31-42
             }
-            uint32_t h = (rank * 2654435761u) >> (32 - (31 - __builtin_clz(HT)));
+            uint32_t h = DIRECT ? rank : (rank * 2654435761u) >> (32 - (31 - __builtin_clz(HT)));
             if (P.use_streams && valid) {
-                for (;;) {
-                    const uint32_t old = atomicCAS(&L.keys[h], BIN_EMPTY, rank);
-                    if (old == BIN_EMPTY || old == rank) break;
-                    h = (h + 1) & (HT - 1);
+                if (!DIRECT) {
+                    for (;;) {
+                        const uint32_t old = atomicCAS(&L.keys[h], BIN_EMPTY, rank);
+                        if (old == BIN_EMPTY || old == rank) break;
+                        h = (h + 1) & (HT - 1);
+                    }
                 }
                 const uint32_t prev = atomicExch(&L.head[h], (uint32_t)tid);
                 L.nxt[tid] = ((uint32_t)sps << 16) | prev;
@@ -430,6 +434,7 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
                     }
                 }
                 __syncthreads();                                                              // (3) every state read before any is advanced
+                if (DIRECT && valid) L.head[h] = EV_NIL;                                       // leave the table clean for the next segment
                 if (valid) {
                     c_ev = prior ? lcg_mul(c_row, prior < MULT_N ? L.jump[prior] : lcg_jump2(P.pw, prior)) : c_row;
                     if (last) row[rank] = lcg_mul(c_row, total < MULT_N ? L.jump[total] : lcg_jump2(P.pw, total));   // plain store: merged in L2
