@@ -510,13 +510,37 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
         HIPCHK(c, hipMemsetAsync(c->d_tfix_n, 0, (size_t)b->n_stiles + 1, c->stream));
     }
 
+    // Dwell draws are made inside k_events (SQG_SEPARATE_DWELL=1 keeps the stand-alone k_dwell for A/B runs).
+    static const bool separate_dwell = getenv("SQG_SEPARATE_DWELL") != nullptr;
+    const bool inline_dwell = c->use_dwell_stream && !separate_dwell;
+    SigParams P;
+    memset(&P, 0, sizeof P);
+    P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
+    P.dwell = c->use_dwell_stream ? c->d_dwell : nullptr; P.dwell_out = c->d_dwell; P.seglen_out = c->d_seglen;
+    P.dmean = p.dwell_mean; P.dstd = p.dwell_std;
+    P.seglen = c->d_seglen; P.sig_off = c->d_sigoff; P.model = c->d_model; P.pw = c->d_pow; P.rows = c->d_rows;
+    P.err = c->d_err; P.dig = p.digitisation; P.range = p.range; P.kd = p.digitisation / p.range;
+    P.chain_order = b->d_chain_order; P.delta_x = c->delta_x; P.thr_all = c->thr_all;
+    P.k = c->k; P.num_kmer = c->num_kmer; P.const_sps = (int)p.dwell_mean;
+    P.use_streams = c->use_kmer_streams ? 1 : 0;
+    P.rna = (c->cfg.flags & SQG_RNA) ? 1 : 0;
+    P.evrec = c->d_evrec; P.tile_so = c->d_tile_so; P.tile_read = b->d_tile_read; P.stile_read = b->d_stile_read;
+    constexpr int NT = SQG_EVENT_THREADS;
+    auto launch_events = [&](int dw) {
+        const dim3 g((unsigned)b->n_chains), t(NT);
+        const bool direct = c->k <= 6;
+#define EVL(D, W) hipLaunchKernelGGL((k_events<NT, D, W>), g, t, 0, c->stream, P)
+        if (direct) { if (dw == 0) EVL(true, 0); else if (dw == 1) EVL(true, 1); else EVL(true, 2); }
+        else { if (dw == 0) EVL(false, 0); else if (dw == 1) EVL(false, 1); else EVL(false, 2); }
+#undef EVL
+    };
+
     HIPCHK(c, hipEventRecord(b->ev[0], c->stream));
     if (n > 0) {
-        if (c->use_dwell_stream) {
+        if (c->use_dwell_stream && !inline_dwell) {
             HIPCHK(c, hipMemsetAsync(c->d_seglen, 0, (size_t)2 * n * sizeof(unsigned long long), c->stream));
             const long long nblk = (b->n_events + DW_EPB - 1) / DW_EPB;
-            if (nblk > 0)
-            {
+            if (nblk > 0) {
                 if (certified)
                     hipLaunchKernelGGL(k_dwell<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, b->d_reads, n, b->d_blk_read,
                                        b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, c->delta_x, c->d_dwell, c->d_seglen, c->d_err);
@@ -524,15 +548,24 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
                     hipLaunchKernelGGL(k_dwell<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, b->d_reads, n, b->d_blk_read,
                                        b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, 0.f, c->d_dwell, c->d_seglen, c->d_err);
             }
-        } else {
+            if ((rc = dbg_sync(c, "k_dwell"))) return rc;
+        } else if (!c->use_dwell_stream) {
             HIPCHK(c, hipMemcpyAsync(c->d_seglen, b->seglen_host.data(), (size_t)2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
         }
-        if ((rc = dbg_sync(c, "k_dwell"))) return rc;
+    }
+    HIPCHK(c, hipEventRecord(b->ev[1], c->stream));
+    HIPCHK(c, hipEventRecord(b->ev[2], c->stream));
+    if (n > 0 && b->n_chains > 0) {
+        launch_events(inline_dwell ? (certified ? 1 : 2) : 0);
+        HIPCHK(c, hipGetLastError());
+        if ((rc = dbg_sync(c, "k_events"))) return rc;
+    }
+    HIPCHK(c, hipEventRecord(b->ev[3], c->stream));
+    if (n > 0) {
         hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_seglen, n, c->d_sigoff, c->d_err);
         HIPCHK(c, hipGetLastError());
         if ((rc = dbg_sync(c, "k_scan"))) return rc;
     }
-    HIPCHK(c, hipEventRecord(b->ev[1], c->stream));
     // Output size is data-dependent.  A hard bound exists (|z| <= sqrt(2 ln(2^31-1)) = 6.5546 for any
     // draw), so the slab is sized by it and the launches continue without a host round trip; only
     // if that bound is unreasonable (huge dwell spread) is the scan read back first.
@@ -554,18 +587,9 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     }
     HIPCHK(c, hipMemsetAsync(c->d_fix_count, 0, 4 * sizeof(unsigned int), c->stream));
 
-    HIPCHK(c, hipEventRecord(b->ev[2], c->stream));
     if (n > 0 && b->n_chains > 0) {
-        SigParams P;
-        P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
-        P.dwell = c->use_dwell_stream ? c->d_dwell : nullptr;
-        P.seglen = c->d_seglen; P.sig_off = c->d_sigoff; P.model = c->d_model; P.pw = c->d_pow; P.rows = c->d_rows;
-        P.sig = c->d_sig; P.err = c->d_err; P.dig = p.digitisation; P.range = p.range; P.kd = p.digitisation / p.range;
-        P.chain_order = b->d_chain_order; P.fix = c->d_fix; P.fix_count = c->d_fix_count;
-        P.fix_cap = (unsigned int)std::min<size_t>(c->fix_cap, 0xffffffffu); P.delta_x = c->delta_x; P.thr_all = c->thr_all;
-        P.k = c->k; P.num_kmer = c->num_kmer; P.const_sps = (int)p.dwell_mean;
-        P.use_streams = c->use_kmer_streams ? 1 : 0;
-        P.rna = (c->cfg.flags & SQG_RNA) ? 1 : 0;
+        P.sig = c->d_sig; P.fix = c->d_fix; P.fix_count = c->d_fix_count;
+        P.fix_cap = (unsigned int)std::min<size_t>(c->fix_cap, 0xffffffffu);
         const bool rna_prefix = (c->cfg.flags & SQG_RNA) && (c->cfg.flags & SQG_PREFIX);
         P.shift_len = rna_prefix ? (int)strlen(kAdaptorRna) * (int)p.dwell_mean : 0;
         {   // int16_t off = 30*dig/range (src/genread.c:82): double -> int16 as the CPU does it
@@ -573,15 +597,9 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
             int32_t t = (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000u;
             P.shift = (int)(int16_t)(uint16_t)((uint32_t)t & 0xffffu);
         }
-        P.evrec = c->d_evrec; P.tile_so = c->d_tile_so; P.tile_read = b->d_tile_read; P.stile_read = b->d_stile_read;
         P.slow_tiles = nullptr; P.slow_count = c->d_fix_count + 1; P.tfix = c->d_tfix; P.tfix_n = c->d_tfix_n;
-        constexpr int NT = SQG_EVENT_THREADS;
         const int n_tiles = (int)b->n_tiles;
         const unsigned sgrid = (unsigned)((n_tiles + 3) / 4);
-        if (c->k <= 6) hipLaunchKernelGGL((k_events<NT, true>), dim3((unsigned)b->n_chains), dim3(NT), 0, c->stream, P);
-        else hipLaunchKernelGGL((k_events<NT, false>), dim3((unsigned)b->n_chains), dim3(NT), 0, c->stream, P);
-        HIPCHK(c, hipEventRecord(b->ev[3], c->stream));
-        if ((rc = dbg_sync(c, "k_events"))) return rc;
         if (certified && c->use_kmer_streams) {
             P.slow_tiles = c->d_slow;
             const int n_stiles = (int)b->n_stiles;

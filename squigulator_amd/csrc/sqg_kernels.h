@@ -134,6 +134,9 @@ struct SigParams {
     const int* chain_order;      // launch order (longest chain first)
     const uint8_t* bases;
     const uint16_t* dwell;       // per event (null when dwell is constant)
+    uint16_t* dwell_out;         // k_events with inline dwell draws: the same array, written
+    unsigned long long* seglen_out;    // ... and the per-read segment totals
+    double dmean, dstd;          // dwell_mean, dwell_std
     const unsigned long long* seglen;  // [2*n_reads] samples in segment 0 / 1
     const long long* sig_off;    // [n_reads+1]
     const float2* model;         // {level_mean, (float)(level_stdv*amp_noise)}
@@ -326,6 +329,7 @@ template <int NT, bool DIRECT>
 struct EvLds {
     uint32_t keys[DIRECT ? 1 : 2 * NT];      // hash bins: k-mer rank
     uint32_t head[DIRECT ? 4096 : 2 * NT];   // bin -> most recently inserted event of the segment (EV_NIL: none)
+    uint32_t row[DIRECT ? 4096 : 1];         // DIRECT: the worker's stream states, resident for the whole chain
     uint32_t nxt[NT];           // per event: (dwell << 16) | next event in the same bin
     uint32_t jump[MULT_N];      // a^(2j)
     uint8_t codes[NT + EV_HALO + 4];   // 2-bit base codes of the segment
@@ -338,9 +342,12 @@ __device__ static inline void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int NT, bool DIRECT>
+// DW: 0 = dwell comes from memory (k_dwell ran) or is constant; 1 = drawn here, certified fp32 path with
+// inline FP64 fallback; 2 = drawn here in FP64 (src/gensig.c:254-257)
+template <int NT, bool DIRECT, int DW>
 __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
     __shared__ EvLds<NT, DIRECT> L;
+    __shared__ long long n1_sh;
     constexpr int NW = NT / 64, HT = 2 * NT;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < MULT_N; i += NT) L.jump[i] = P.pw[2 * POW_N + i];
@@ -351,6 +358,11 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
     const int c_lo = P.chain_off[chain], c_hi = P.chain_off[chain + 1];
     uint32_t* row = P.rows ? P.rows + (size_t)P.reads[P.chain_reads[c_lo]].worker * P.num_kmer : nullptr;
     const int k = P.k;
+    if (DIRECT && P.use_streams) for (int i = tid; i < P.num_kmer; i += NT) L.row[i] = row[i];
+    const uint32_t a2nt = DW ? lcg_jump2(P.pw, (uint32_t)NT) : 0u;       // time-stream jump over one segment
+    const float dw_sf = (float)P.dstd, dw_mf = (float)P.dmean;
+    // delta_x*s (swept) + float roundings of s, m, the fma and the +1/2 (each <= 2^-24 * mag) + slack
+    const float dw_eps = P.delta_x * fabsf(dw_sf) + 4.0f * 5.9604645e-8f * (fabsf(dw_mf) + 7.0f * fabsf(dw_sf) + 1.0f) + 1e-6f;
     __syncthreads();
 
     for (int ci = c_lo; ci < c_hi; ci++) {
@@ -363,6 +375,8 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
         // straddle the boundary, src/genread.c:87-88)
         #define EV_BASE(e_) ((long long)(e_) + ((e_) >= rd.ne0 ? (long long)rd.len0 - rd.ne0 : 0LL))
         uint32_t done = 0;                                            // samples before this segment
+        uint32_t c_seg = rd.time_c0;                                  // time-stream state at the segment's first event
+        if (DW && tid == 0) n1_sh = -1;
         // prefetch of segment 0: one base byte per thread (+ halo), one dwell per thread
         uint8_t b_cur = 'A', b_halo = 'A';
         uint16_t d_cur = 0;
@@ -370,7 +384,7 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
             const long long b0 = EV_BASE(0);
             if (b0 + tid < nbytes) b_cur = rbases[b0 + tid];
             if (tid < EV_HALO && b0 + NT + tid < nbytes) b_halo = rbases[b0 + NT + tid];
-            if (tid < ne && P.dwell) d_cur = P.dwell[rd.ev_off + tid];
+            if (!DW && tid < ne && P.dwell) d_cur = P.dwell[rd.ev_off + tid];
         }
         for (int s0 = 0; s0 < ne; s0 += NT) {
             const int e = s0 + tid;
@@ -378,7 +392,29 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
             const long long bseg = EV_BASE(s0);
             L.codes[tid] = L.lut[b_cur];
             if (tid < EV_HALO) L.codes[NT + tid] = L.lut[b_halo];
-            const int sps = valid ? (P.dwell ? (int)d_cur : P.const_sps) : 0;
+            int sps = 0;
+            if (DW == 0) {
+                sps = valid ? (P.dwell ? (int)d_cur : P.const_sps) : 0;
+            } else if (valid) {
+                // event e uses draws 2e+1, 2e+2 of the worker's time stream after the read's first state
+                const uint32_t c1 = lcg_mul(lcg_mul(c_seg, L.jump[tid]), LCG_A);
+                bool decided = false;
+                if (DW == 1) {
+                    // v' = x'*s + m in fp32; round(v) = floor(v+1/2) unless v is within eps of a half-integer
+                    const float x = box_muller_fast(c1, lcg_mul_lazy(c1, LCG_A));
+                    const float g = __builtin_fmaf(x, dw_sf, dw_mf) + 0.5f;
+                    const float fl = floorf(g);
+                    if (fabsf(g - fl - 0.5f) < 0.5f - dw_eps && c1 <= LCG_M - (1u << NEAR_ONE_BITS) && fabsf(g) < 1.0e6f) { sps = (int)fl; decided = true; }
+                }
+                if (!decided) {
+                    const double z = box_muller_exact(c1, lcg_mul(c1, LCG_A));
+                    sps = (int)round((z * P.dstd) + P.dmean);             // src/gensig.c:255
+                }
+                sps = sps < 1 ? -sps + 1 : sps;                          // src/gensig.c:256
+                if (sps > 65535) { atomicOr(P.err, 1u); sps = 65535; }
+                P.dwell_out[rd.ev_off + e] = (uint16_t)sps;
+            }
+            if (DW) c_seg = lcg_mul(c_seg, a2nt);
             const int incl = wave_incl_scan(sps, lane);
             if (lane == 63) L.wsum[wid] = incl;
             if (!DIRECT && P.use_streams) for (int i = tid; i < HT; i += NT) { L.keys[i] = BIN_EMPTY; L.head[i] = EV_NIL; }
@@ -402,7 +438,7 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
                 const uint32_t prev = atomicExch(&L.head[h], (uint32_t)tid);
                 L.nxt[tid] = ((uint32_t)sps << 16) | prev;
             }
-            __syncthreads();                                                                  // (2) + earlier row stores have landed
+            if (DIRECT) lds_barrier(); else __syncthreads();                                  // (2) global rows: + earlier row stores have landed
             // prefetch the next segment's inputs; they land while this segment waits for its states
             {
                 const int s1 = s0 + NT;
@@ -410,10 +446,11 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
                     const long long b1 = EV_BASE(s1);
                     b_cur = (b1 + tid < nbytes) ? rbases[b1 + tid] : (uint8_t)'A';
                     if (tid < EV_HALO) b_halo = (b1 + NT + tid < nbytes) ? rbases[b1 + NT + tid] : (uint8_t)'A';
-                    if (s1 + tid < ne && P.dwell) d_cur = P.dwell[rd.ev_off + s1 + tid];
+                    if (!DW && s1 + tid < ne && P.dwell) d_cur = P.dwell[rd.ev_off + s1 + tid];
                 }
             }
             if (lane == 0 && s0 + wid * 64 < ne) P.tile_so[rd.tile_off + (s0 >> 6) + wid] = done + (uint32_t)woff;
+            if (DW && valid && e == rd.ne0) n1_sh = (long long)done + woff + incl - sps;      // samples of segment 0
             uint32_t c_ev = 0;
             if (P.use_streams) {
                 // dwell drawn from my k-mer's stream by earlier events of this segment, by all of them,
@@ -422,7 +459,7 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
                 bool last = true;
                 uint32_t c_row = 0;
                 if (valid) {
-                    c_row = __builtin_nontemporal_load(&row[rank]);   // L2-served (bypasses the CU's L1): sees this workgroup's earlier stores
+                    c_row = DIRECT ? L.row[rank] : __builtin_nontemporal_load(&row[rank]);   // global: L2-served (bypasses the CU's L1)
                     uint32_t t = L.head[h];
                     while (t != EV_NIL) {
                         const uint32_t v = L.nxt[t];
@@ -433,11 +470,14 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
                         t = v & 0xffffu;
                     }
                 }
-                __syncthreads();                                                              // (3) every state read before any is advanced
+                if (DIRECT) lds_barrier(); else __syncthreads();                                // (3) every state read before any is advanced
                 if (DIRECT && valid) L.head[h] = EV_NIL;                                       // leave the table clean for the next segment
                 if (valid) {
                     c_ev = prior ? lcg_mul(c_row, prior < MULT_N ? L.jump[prior] : lcg_jump2(P.pw, prior)) : c_row;
-                    if (last) row[rank] = lcg_mul(c_row, total < MULT_N ? L.jump[total] : lcg_jump2(P.pw, total));   // plain store: merged in L2
+                    if (last) {
+                        const uint32_t nv = lcg_mul(c_row, total < MULT_N ? L.jump[total] : lcg_jump2(P.pw, total));
+                        if (DIRECT) L.row[rank] = nv; else row[rank] = nv;                     // global: plain store, merged in L2
+                    }
                 }
             }
             if (valid) P.evrec[rd.ev_off + e] = make_uint2(c_ev, rank);
@@ -445,9 +485,17 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
             lds_barrier();                                                                    // (4) LDS reusable; stores stay in flight
         }
         #undef EV_BASE
-        if ((long long)done != P.sig_off[r + 1] - P.sig_off[r] && tid == 0) atomicOr(P.err, 4u);
         __syncthreads();                                // the chain's next read starts with this read's stores landed
+        if (tid == 0) {
+            if (DW) {
+                const long long n1 = n1_sh >= 0 ? n1_sh : (long long)done;
+                P.seglen_out[2 * r] = (unsigned long long)n1;
+                P.seglen_out[2 * r + 1] = (unsigned long long)((long long)done - n1);
+            } else if ((long long)done != (long long)(P.seglen[2 * r] + P.seglen[2 * r + 1])) atomicOr(P.err, 4u);
+        }
+        __syncthreads();
     }
+    if (DIRECT && P.use_streams) for (int i = tid; i < P.num_kmer; i += NT) row[i] = L.row[i];
 }
 
 struct SmpWaveLds {
