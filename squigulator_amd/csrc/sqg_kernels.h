@@ -79,6 +79,13 @@ __device__ static inline float box_muller_fast(uint32_t c1, uint32_t r2) {
     return r * cs;
 }
 
+// dwell draw in FP64 (src/gensig.c:255), kept out of line: it is taken for ~4e-5 of the events and must not
+// set the register budget of the kernels that call it
+__device__ __attribute__((noinline)) static int dwell_exact(uint32_t c1, double dstd, double dmean) {
+    const double z = box_muller_exact(c1, lcg_mul(c1, LCG_A));
+    return (int)round((z * dstd) + dmean);
+}
+
 // (int16_t)double as gcc/x86-64 lowers it (cvttsd2si r32, low half): src/gensig.c:270
 __device__ static inline int16_t to_i16(double v) {
     int32_t t;
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restr
 //            start-marker bytes in LDS + ballot/mbcnt; the two draws of a sample are two modular
 //            multiplications of the event's state with per-slot constants a^(2j+1), a^(2j+2).
 #ifndef SQG_EVENT_THREADS
-#define SQG_EVENT_THREADS 512
+#define SQG_EVENT_THREADS 256
 #endif
 #define MK_W 1024          // marker window (samples) per wavefront
 #define MULT_N 512         // LDS jump constants cover events of up to 512 samples
@@ -331,7 +338,7 @@ struct EvLds {
     uint32_t head[DIRECT ? 4096 : 2 * NT];   // bin -> most recently inserted event of the segment (EV_NIL: none)
     uint32_t row[DIRECT ? 4096 : 1];         // DIRECT: the worker's stream states, resident for the whole chain
     uint32_t nxt[NT];           // per event: (dwell << 16) | next event in the same bin
-    uint32_t jump[MULT_N];      // a^(2j)
+    uint32_t jump[(MULT_N > NT ? MULT_N : NT)];      // a^(2j)
     uint8_t codes[NT + EV_HALO + 4];   // 2-bit base codes of the segment
     uint8_t lut[256];           // base -> 2-bit code (src/seq.h:14-27)
     int wsum[NT / 64];
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
     __shared__ long long n1_sh;
     constexpr int NW = NT / 64, HT = 2 * NT;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int i = tid; i < MULT_N; i += NT) L.jump[i] = P.pw[2 * POW_N + i];
+    for (int i = tid; i < (MULT_N > NT ? MULT_N : NT); i += NT) L.jump[i] = P.pw[2 * POW_N + i];
     for (int i = tid; i < 256; i += NT) L.lut[i] = (uint8_t)base_code((uint8_t)i);
     if (DIRECT) for (int i = tid; i < 4096; i += NT) L.head[i] = EV_NIL;      // kept clean by the events themselves
 
@@ -406,10 +413,7 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
                     const float fl = floorf(g);
                     if (fabsf(g - fl - 0.5f) < 0.5f - dw_eps && c1 <= LCG_M - (1u << NEAR_ONE_BITS) && fabsf(g) < 1.0e6f) { sps = (int)fl; decided = true; }
                 }
-                if (!decided) {
-                    const double z = box_muller_exact(c1, lcg_mul(c1, LCG_A));
-                    sps = (int)round((z * P.dstd) + P.dmean);             // src/gensig.c:255
-                }
+                if (!decided) sps = dwell_exact(c1, P.dstd, P.dmean);    // src/gensig.c:255
                 sps = sps < 1 ? -sps + 1 : sps;                          // src/gensig.c:256
                 if (sps > 65535) { atomicOr(P.err, 1u); sps = 65535; }
                 P.dwell_out[rd.ev_off + e] = (uint16_t)sps;
