@@ -129,6 +129,9 @@ def main():
     ap.add_argument("--mode", default="certified", choices=["exact", "certified"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-store-probe", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL) for one rank per GPU; gloo only to exercise the N>1 control flow on a "
+                         "box with fewer GPUs than ranks (ranks then share GPUs)")
     args = ap.parse_args()
 
     import torch
@@ -141,9 +144,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the signal path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks but {ndev} GPUs (use --backend gloo to share GPUs in a dry run)")
+    local_rank %= ndev
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     prof, flags = profiles.get_profile(args.profile)
     k = profiles.default_kmer_size(flags)
@@ -194,7 +204,8 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
 
-    tot = torch.tensor([float(samples), float(reads), dt], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([float(samples), float(reads), dt], dtype=torch.float64,
+                       device="cuda" if (world == 1 or args.backend == "nccl") else "cpu")
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
