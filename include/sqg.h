@@ -113,9 +113,10 @@ typedef struct {
 
 /* kernel timings of the last sqg_batch_run, from hipEvents on the context's stream */
 typedef struct {
-    float dwell_ms;             /* k_dwell + k_scan                                          */
-    float events_ms;            /* k_events (k-mer ranks, stream hand-out)                   */
-    float samples_ms;           /* k_samples (+ k_fixup): the dominant, roofline-priced part */
+    float dwell_ms;             /* stand-alone k_dwell (0 when the draws are made inside k_events) */
+    float events_ms;            /* k_events (dwell draws, k-mer ranks, stream hand-out)      */
+    float samples_ms;           /* k_scan + k_samples_lean + k_samples<generic> + k_fixup*   */
+    float lean_ms;              /* k_samples_lean alone: the dominant, roofline-priced kernel (0 if not launched) */
     float total_ms;             /* first launch to last completion                           */
     int64_t fallback_samples;   /* CERTIFIED mode: samples recomputed on the FP64 path       */
 } sqg_timing_t;

@@ -53,7 +53,7 @@ class CResult(C.Structure):
 
 class CTiming(C.Structure):
     _fields_ = [("dwell_ms", C.c_float), ("events_ms", C.c_float), ("samples_ms", C.c_float),
-                ("total_ms", C.c_float), ("fallback_samples", C.c_int64)]
+                ("lean_ms", C.c_float), ("total_ms", C.c_float), ("fallback_samples", C.c_int64)]
 
 
 EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_device_count",
@@ -218,7 +218,7 @@ class SignalGenerator:
         t = CTiming()
         self._chk(self.L.sqg_get_timing(self.ctx, C.byref(t)), "sqg_get_timing")
         return {"dwell_ms": t.dwell_ms, "events_ms": t.events_ms, "samples_ms": t.samples_ms,
-                "total_ms": t.total_ms, "fallback_samples": t.fallback_samples}
+                "lean_ms": t.lean_ms, "total_ms": t.total_ms, "fallback_samples": t.fallback_samples}
 
     def probe_store_bandwidth(self, nbytes=1 << 30, iters=10) -> float:
         ms = C.c_float()

@@ -45,7 +45,7 @@ struct sqg_ctx {
     std::vector<uint32_t> time_c;          // canonical time-stream state per local worker
     std::vector<long long> off_x, med_x;   // raw Schrage states (as the reference keeps them)
     unsigned long long next_stage = 0, next_run = 0;
-    sqg_timing_t timing = {0, 0, 0, 0, 0};
+    sqg_timing_t timing = {0, 0, 0, 0, 0, 0};
     bool use_dwell_stream = true, use_kmer_streams = true;
     float delta_x = 0.f;                   // certified mode: swept |x_fast - x_exact| bound incl. margin
     float delta_x_measured = 0.f;
@@ -82,8 +82,8 @@ struct sqg_batch {
     int* d_stile_read = nullptr;
     long long n_tiles = 0, n_stiles = 0;
     long long* h_sigoff = nullptr;   // pinned
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel-phase boundaries on the stream
-    bool ran = false, waited = false;
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel-phase boundaries on the stream
+    bool ran = false, waited = false, lean_timed = false;
 };
 
 #define HIPCHK(ctx, call)                                                                      \
@@ -604,8 +604,11 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
             P.slow_tiles = c->d_slow;
             const int n_stiles = (int)b->n_stiles;
             const unsigned lgrid = (unsigned)((n_stiles + 3) / 4);
+            HIPCHK(c, hipEventRecord(b->ev[5], c->stream));
             if (P.rna) hipLaunchKernelGGL((k_samples_lean<true>), dim3(lgrid), dim3(256), 0, c->stream, P, n_stiles);
             else hipLaunchKernelGGL((k_samples_lean<false>), dim3(lgrid), dim3(256), 0, c->stream, P, n_stiles);
+            HIPCHK(c, hipEventRecord(b->ev[6], c->stream));
+            b->lean_timed = true;
             if ((rc = dbg_sync(c, "k_samples_lean"))) return rc;
             hipLaunchKernelGGL((k_samples<1, true>), dim3(std::min(sgrid, 4096u)), dim3(256), 0, c->stream, P, n_tiles);
             if ((rc = dbg_sync(c, "k_samples<generic>"))) return rc;
@@ -646,6 +649,8 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
         HIPCHK(c, hipEventElapsedTime(&s, b->ev[3], b->ev[4]));
         HIPCHK(c, hipEventElapsedTime(&t, b->ev[0], b->ev[4]));
         c->timing.events_ms = ee;
+        c->timing.lean_ms = 0.f;
+        if (b->lean_timed) HIPCHK(c, hipEventElapsedTime(&c->timing.lean_ms, b->ev[5], b->ev[6]));
         unsigned int nfix = 0;
         if (c->cfg.mode == SQG_MODE_CERTIFIED) {
             unsigned int cnt[4] = {0, 0, 0, 0};

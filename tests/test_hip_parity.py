@@ -149,3 +149,30 @@ def test_worker_shards_equal_one_context():
     whole.close()
     for g in parts:
         g.close()
+
+
+def test_paf_sam_goldens_from_device_dwell():
+    """the per-event dwell array of the HIP path feeds PAF/SAM `ss:Z:` emission; with the
+    reads of the reference's own golden runs (scripts/test.sh:81-99) the product's writers reproduce
+    test/dna_r10_paf.paf.exp and test/rna_paf.{paf,sam}.exp byte for byte (these files do not depend on the
+    absent pore-model tables)."""
+    import gzip
+    from refcases import CASES
+    from squigulator_amd import aln_text, slow5_text
+    exp_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_exp")
+    for cid in ("r10_paf", "rna_paf_sam", "r10_paf_ref"):
+        _, cmd, exp = next(c for c in CASES if c[0] == cid)
+        o, k, names, lengths, reads, orac = simrun.run_oracle(cmd)      # the oracle only SAMPLES the reads here
+        orac.close()
+        got = hiprun.run_hip_on_reads(cmd, [r.seq for r in reads], mode=api.MODE_CERTIFIED)
+        paf, sam = [], [aln_text.sam_header(names, lengths)]
+        for r, g in zip(reads, got):
+            rid = slow5_text.read_id(o.flags, r.read_number + 1, names[r.ref_idx], r.ref_pos_st, r.ref_pos_end, r.strand)
+            a = aln_text.Aln(o.flags, k, rid, names[r.ref_idx], r.ref_len, r.ref_pos_st, r.ref_pos_end, r.strand,
+                             r.rlen, len(g["sig"]), g["ss"])
+            paf.append(aln_text.paf_str(a))
+            sam.append(aln_text.sam_str(a, r.seq.decode(), names[r.ref_idx], r.ref_pos_st))
+        for kind, text in (("paf", "".join(paf)), ("sam", "".join(sam))):
+            if kind in exp:
+                with gzip.open(os.path.join(exp_dir, exp[kind] + ".gz"), "rt") as f:
+                    assert text == f.read(), f"{cid}: {kind}"
