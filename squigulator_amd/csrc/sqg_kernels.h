@@ -486,7 +486,8 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
             }
             if (valid) P.evrec[rd.ev_off + e] = make_uint2(c_ev, rank);
             done += (uint32_t)seg_total;
-            lds_barrier();                                                                    // (4) LDS reusable; stores stay in flight
+            // no barrier here: every LDS structure rewritten at the top of the next segment (codes, wsum, bins) was last
+            // read before barrier (2)/(3) of this one, which every thread has passed
         }
         #undef EV_BASE
         __syncthreads();                                // the chain's next read starts with this read's stores landed
