@@ -128,6 +128,54 @@ def cpu_baseline(prof, flags, k, mean, stdv, genome, rlen, target_cpu_seconds=20
                       f"-t {n} -K {n} on {cores} host threads, {dt:.2f} s wall"}
 
 
+def cpu_reference(prof, flags, k, mean, stdv, nproc, reads_per_proc=24, rlen=10000):
+    """The REFERENCE's own gensig.c/genread.c (oracle/_ref/ref_harness, compiled in the build container from the
+    upstream sources where they lie) timed on the host cores: `nproc` independent single-threaded processes
+    (-t1, different seeds), aggregate samples/s.  Includes the reference's read sampling and the harness's
+    binary dump; returns None when the binary did not travel."""
+    import subprocess
+    import tempfile
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if not os.path.exists(harness):
+        return None
+    with tempfile.TemporaryDirectory() as tmp:
+        mpath = os.path.join(tmp, "m.model")
+        model.write_f5c_model(mpath, k, mean, stdv)
+        cfgs = []
+        for i in range(nproc):
+            cfg = {"fasta": GENOME, "model": mpath, "out": os.path.join(tmp, f"o{i}.bin"), "flags": flags, "amp_noise": 1.0,
+                   "seed": 1000 + 7919 * i, "threads": 1, "batch": 1000, "nreads": reads_per_proc, "rlen": rlen}
+            for name, v in zip(("digitisation", "sample_rate", "bps", "range", "offset_mean", "offset_std",
+                                "median_before_mean", "median_before_std", "dwell_mean", "dwell_std"), prof.as_tuple()):
+                cfg[name] = repr(float(v))
+            cp = os.path.join(tmp, f"c{i}.txt")
+            with open(cp, "w") as f:
+                f.write("".join(f"{a}={b}\n" for a, b in cfg.items()))
+            cfgs.append(cp)
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([harness, c], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for c in cfgs]
+        rcs = [p.wait() for p in procs]
+        dt = time.perf_counter() - t0
+        if any(rcs):
+            return None
+        import struct
+        ns = 0
+        for i in range(nproc):
+            # dump layout (oracle/ref_harness.c): "SQGREF1\0", int32 n; per read int32[6] (…, rlen at [4], …),
+            # f64 offset, f64 median, i64 len_raw_signal, i64 start_time, i64 ss_n, seq, int16 signal, int32 ss
+            with open(os.path.join(tmp, f"o{i}.bin"), "rb") as f:
+                f.seek(8)
+                (n,) = struct.unpack("<i", f.read(4))
+                for _ in range(n):
+                    hdr = struct.unpack("<6i", f.read(24))
+                    _, _, ln, _, ssn = struct.unpack("<ddqqq", f.read(40))
+                    ns += ln
+                    f.seek(hdr[4] + 2 * ln + 4 * ssn, 1)
+    return {"value": ns / dt, "unit": "samples/s", "cores": nproc, "kind": "reference",
+            "sample": f"{nproc} x ref_harness -t1 -n {reads_per_proc} (reference gensig.c/genread.c, synthetic table), "
+                      f"{dt:.2f} s wall incl. process start, model/FASTA load and the dump"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,7 +303,7 @@ def main():
             "samples_per_step_per_gpu": samples / steps,
             "kernel_ms": {"k_samples_lean": k_ms, "k_scan+k_samples*+k_fixup*": float(np.mean(sig_ms)) if sig_ms else None,
                           "k_events(+dwell)": float(np.mean(ev_ms)) if ev_ms else None,
-                          "k_dwell(separate)": float(np.mean(dwell_ms)) if dwell_ms else None},
+                          "k_dwell(separate)": float(np.mean(dwell_ms)) if dwell_ms and np.mean(dwell_ms) > 0.01 else None},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S,
                          "traffic": pmc_traffic(args.profile, K, args.rlen, args.mode),
@@ -265,6 +313,9 @@ def main():
             out["roofline"]["measured_store_peak_GBps"] = gen.probe_store_bandwidth(1 << 30, 10) / 1e9
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prof, flags, k, mean, stdv, genome, args.rlen)
+            ref = cpu_reference(prof, flags, k, mean, stdv, nproc=min(os.cpu_count() or 1, 128), reads_per_proc=150)
+            if ref:
+                out["cpu_reference"] = ref
         print(json.dumps(out))
     for b in batches:
         b.free()
