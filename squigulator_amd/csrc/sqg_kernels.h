@@ -531,6 +531,15 @@ __device__ static inline void push_fix(const SigParams& P, bool bad, int lane, u
     }
 }
 
+// one undecided sample from a divergent region (rare overflow path of the lean kernel)
+__device__ static inline void push_fix_one(const SigParams& P, long long at, uint32_t c1, long long ev, int r, int shifted) {
+    const unsigned int slot = atomicAdd(P.fix_count, 1u);
+    if (slot < P.fix_cap) {
+        FixEntry fe; fe.at = at; fe.c1 = c1; fe.ev = ev; fe.read = r; fe.shifted = shifted; fe.pad = 0;
+        P.fix[slot] = fe;
+    } else atomicOr(P.err, 8u);
+}
+
 // inclusive wave scan with DPP row shifts/broadcasts (6 VALU, no LDS)
 __device__ static inline int wave_incl_scan_dpp(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
@@ -547,32 +556,40 @@ __device__ static inline int wave_incl_scan_dpp(int v) {
 #define FIX_SLOTS 8                        // parked undecided samples per super tile (expected ~0.5); overflow -> global list
 
 struct LeanWaveLds {
-    uint4 rec[LEAN_EV];         // {c_ev, (I << 16) | first sample in super tile, F, sdk}
-    uint8_t mk[MK_W + 64];      // marker at (first sample - 1) of events 1.. (+64: the pipelined loop reads one step ahead)
+    uint4 rec[LEAN_EV];                 // {c_ev, ((8*first sample) & 0xfff) << 16 | I (16 bits), F - 1/2, sdk}
+    unsigned long long bm[64];          // bit s-1 set: an event (other than the item's first) starts at sample s
+    int nfix;                           // undecided samples of the item so far
+    int pad[3];
 };
 struct LeanLds {
-    uint2 mult[MULT_N];         // {a^(2j+1), a^(2j+2)}
+    uint2 mult[MULT_N];                 // {a^(2j+1), a^(2j+2)}
     LeanWaveLds w[4];
 };
+#define LEAN_MAX_SAMPLES 4096           // samples per work item the 64x64-bit start map covers
+#define LEAN_MAGIC 12582912.0f          // 1.5 * 2^23: t = v + MAGIC rounds v to the nearest integer, in the low bits of t
 
 // k_samples_lean: the hot kernel.  Certified fp32 path only, for reads whose ADC values are provably in
 // (2, 65000) (ReadDesc.fast), events of <= MULT_N samples, outside the RNA level-shift window; everything
 // else is queued (as 64-event tiles) for k_samples<MODE, GENERIC>.
-// One wavefront per 256 consecutive events of a read (4 per lane: the three dependent global round trips
-// of the set-up are paid once per ~2300 samples).  Per step 64 consecutive samples:
-//   marker byte -> ballot/mbcnt -> event -> {state, I|first, F, sdk} (one ds_read_b128) ->
-//   jump constants (ds_read_b64) -> 2 modular multiplications -> v_log/v_sqrt/v_cos -> fma ->
-//   floor / acceptance test -> int16 store.  The loads of step i+1 are issued before the arithmetic of
-//   step i (software pipelining).
+// One wavefront per 256 consecutive events of a read (4 per lane: the dependent global round trips of the
+// set-up are paid once per ~2300 samples; the item's descriptors are wave-uniform and live in SGPRs).
+// Per step 64 consecutive samples:
+//   64-bit slice of the event-start map (v_readlane) -> mbcnt -> event -> {state, first|I, F-1/2, sdk}
+//   (one ds_read_b128) -> jump constants (ds_read_b64) -> 2 modular multiplications -> v_log/v_sqrt/v_cos ->
+//   v' = fma(x, sdk, F-1/2) -> t = v' + 1.5*2^23 (round to nearest: floor of the ADC value unless it is within
+//   eps of an integer) -> acceptance test on v' - (t - 1.5*2^23) -> int16 store of the low half of bits(t) + I.
+// The loads of step i+1 are issued before the arithmetic of step i (software pipelining, two steps unrolled
+// so that the pipeline registers do not have to be copied).
 template <bool RNA>
 __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const int n_stiles) {
     __shared__ LeanLds L;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < MULT_N; i += 256) L.mult[i] = make_uint2(P.pw[i], P.pw[POW_N + i]);
     __syncthreads();
     LeanWaveLds& W = L.w[wid];
-    const unsigned long long lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);
     const float thr = P.thr_all;
+    const char* mult_b = reinterpret_cast<const char*>(L.mult);
 
     for (int g = blockIdx.x * 4 + wid; g < n_stiles; g += gridDim.x * 4) {
         const int r = P.stile_read[g];
@@ -585,8 +602,8 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         uint2 er[LEAN_EPL];
         int sps[LEAN_EPL];
         if (e0 + LEAN_EPL <= ne) {
-            const uint4 a = *reinterpret_cast<const uint4*>(P.evrec + gev);          // gev is a multiple of 4 only within a read;
-            const uint4 b = *reinterpret_cast<const uint4*>(P.evrec + gev + 2);      // 8-B elements: 16-B aligned iff gev even
+            const uint4 a = *reinterpret_cast<const uint4*>(P.evrec + gev);          // ev_off is even: 16-B aligned
+            const uint4 b = *reinterpret_cast<const uint4*>(P.evrec + gev + 2);
             er[0] = make_uint2(a.x, a.y); er[1] = make_uint2(a.z, a.w); er[2] = make_uint2(b.x, b.y); er[3] = make_uint2(b.z, b.w);
 #pragma unroll
             for (int q = 0; q < LEAN_EPL; q++) sps[q] = P.dwell ? (int)P.dwell[gev + q] : P.const_sps;
@@ -606,7 +623,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         const int wave_total = __builtin_amdgcn_readlane(incl, 63);
         const uint32_t base_pos = P.tile_so[rd.tile_off + lt * LEAN_EPL];
         const long long sig_base = P.sig_off[r];
-        bool take = rd.fast != 0;
+        bool take = rd.fast != 0 && wave_total <= LEAN_MAX_SAMPLES;
         if (P.shift_len > 0) {                                         // RNA adaptor level-shift window (src/genread.c:79-86)
             const long long n1 = (long long)P.seglen[2 * r];
             if ((long long)base_pos + wave_total > n1 - P.shift_len && (long long)base_pos < n1) take = false;
@@ -618,90 +635,90 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         }
         if (wave_total <= 0) continue;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // previous item's LDS reads are done
-        int so[LEAN_EPL];
+        W.bm[lane] = 0ull;
+        if (lane == 0) W.nfix = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         {
             int run = incl - lane_total;
 #pragma unroll
             for (int q = 0; q < LEAN_EPL; q++) {
-                so[q] = run; run += sps[q];
+                const int so = run; run += sps[q];
                 // v = s_f*dig/range - offset  ~  x*(sd*kd) + (m*kd - offset) = x*sdk + (I + F), I = floor(.) in (2, 65000)
                 const double mk = (double)md[q].x * P.kd - rd.offset;
                 const double fl0 = floor(mk);
-                const float F = (float)(mk - fl0);
+                const float Fh = (float)(mk - fl0 - 0.5);
                 const float sdk = (float)((double)md[q].y * P.kd);
-                W.rec[lane * LEAN_EPL + q] = make_uint4(er[q].x, ((uint32_t)(int)fl0 << 16) | (uint32_t)so[q], __float_as_uint(F), __float_as_uint(sdk));
+                W.rec[lane * LEAN_EPL + q] = make_uint4(er[q].x, ((((uint32_t)so << 3) & 0xfffu) << 16) | ((uint32_t)(int)fl0 & 0xffffu),
+                                                        __float_as_uint(Fh), __float_as_uint(sdk));
+                if ((e0 + q < ne) && (lane | q) != 0)                  // so >= 1: every earlier event has >= 1 sample
+                    atomicOr(reinterpret_cast<unsigned int*>(W.bm) + ((so - 1) >> 5), 1u << ((so - 1) & 31));
             }
         }
-        int16_t* out = P.sig + sig_base;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const unsigned long long my_bm = W.bm[lane];
+        const uint32_t bm_lo = (uint32_t)my_bm, bm_hi = (uint32_t)(my_bm >> 32);
         const uint32_t read_len = (uint32_t)(P.sig_off[r + 1] - sig_base);
-        const uint32_t a_top = read_len - 1 - base_pos;                // RNA: generation index i is stored at a_top - i
+        // wave-uniform output base: keep it in SGPRs (global_store saddr + 32-bit lane offset)
+        const long long sig_base_u = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)sig_base >> 32)) << 32) |
+                                                 (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)sig_base));
+        char* const out_b = reinterpret_cast<char*>(P.sig + sig_base_u);
+        // byte offset of my sample of step 0 within the read: generation index i is stored at base_pos + i (RNA: read_len-1-base_pos-i)
+        uint32_t voff = RNA ? 2u * (read_len - 1u - base_pos - (uint32_t)lane) : 2u * (base_pos + (uint32_t)lane);
+        uint32_t idx8 = (uint32_t)lane << 3;                           // 8 * (my sample index within the item)
         const int ev_read0 = lt * LEAN_EV;                             // event index (within the read) of rec[0]
+        const int nfull = wave_total >> 6, rem = wave_total & 63;
+        int base_ev;
 
-        int nfix = 0;                                                  // undecided samples of this item so far (wave-uniform)
-        for (int w0 = 0; w0 < wave_total; w0 += MK_W) {
-            ((uint4*)W.mk)[lane] = make_uint4(0, 0, 0, 0);
-            if (lane < 4) ((uint4*)W.mk)[64 + lane] = make_uint4(0, 0, 0, 0);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            int before = 0;                                            // my events (other than event 0) begun before this window
-#pragma unroll
-            for (int q = 0; q < LEAN_EPL; q++) {
-                const int mpos = so[q] - 1 - w0;                       // marker of an event sits one sample early
-                const bool real = (e0 + q < ne) && (lane | q) != 0;
-                if (real && mpos >= 0 && mpos < MK_W) W.mk[mpos] = 1;
-                before += (real && mpos < 0) ? 1 : 0;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            int base_ev = before;
-            for (int o = 32; o > 0; o >>= 1) base_ev += __shfl_xor(base_ev, o);
-            const int w_len = min(MK_W, wave_total - w0);
-            const int nchunk = (w_len + 63) >> 6;
-            // prologue: loads of chunk 0
-            unsigned long long sm = __ballot(W.mk[lane] != 0);
-            int ev = base_ev + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u));
-            base_ev += __popcll(sm);
-            uint4 ra = W.rec[ev];
-            uint2 mu = L.mult[((uint32_t)(w0 + lane) - (ra.y & 0xffffu)) & (MULT_N - 1)];
-            for (int c = 0; c < nchunk; c++) {
-                const int idx = w0 + c * 64 + lane;                    // sample index within the item
-                // ---- loads of chunk c+1, unconditional (the marker pad makes the last one harmless) ----
-                sm = __ballot(W.mk[(c + 1) * 64 + lane] != 0);
-                const int ev_n = min(base_ev + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(sm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sm, 0u)), LEAN_EV - 1);
-                base_ev += __popcll(sm);
-                const uint4 ra_n = W.rec[ev_n];
-                // ---- arithmetic of chunk c ----
-#if defined(SQG_EXP_NOMAD)      /* ablation builds (bench only; results are wrong) */
-                const uint32_t c1 = (ra.x ^ mu.x) & 0x7fffffffu, r2 = ra.x + mu.y;
-#else
-                const uint32_t c1 = lcg_mul(ra.x, mu.x);
-                const uint32_t r2 = lcg_mul_lazy(ra.x, mu.y);
-#endif
-#if defined(SQG_EXP_NOTRANS)
-                const float x = (float)c1 * 1e-9f + (float)r2 * 1e-10f;
-#else
-                const float x = box_muller_fast(c1, r2);
-#endif
-                const float v = __builtin_fmaf(x, __uint_as_float(ra.w), __uint_as_float(ra.z));
-                const float fl = floorf(v);
-                const float fr = v - fl;
-                const bool act = idx < w0 + w_len;
-                const bool ok = fabsf(fr - 0.5f) < thr && c1 <= LCG_M - (1u << NEAR_ONE_BITS);
-                const int n = (int)(ra.y >> 16) + (int)fl;
-                const uint32_t at = RNA ? (a_top - (uint32_t)idx) : (base_pos + (uint32_t)idx);
-                if (act && ok) out[at] = (int16_t)(uint16_t)((uint32_t)n & 0xffffu);
-                const unsigned long long am = __ballot(act && !ok);
-                if (am) {                                              // ~1 % of steps: park the undecided samples (no round trip)
-                    const int slot = nfix + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-                    nfix += __popcll(am);
-                    if (act && !ok) {
-                        if (slot < FIX_SLOTS) P.tfix[(size_t)g * FIX_SLOTS + slot] = make_uint4(at, c1, (uint32_t)(ev_read0 + ev), 0u);
-                    }
-                    if (nfix > FIX_SLOTS)                              // overflow (never in practice): global list
-                        push_fix(P, act && !ok && slot >= FIX_SLOTS, lane, lane_le, sig_base + at, c1, rd.ev_off + ev_read0 + ev, r, 0);
-                }
-                const uint2 mu_n = L.mult[((uint32_t)(idx + 64) - (ra_n.y & 0xffffu)) & (MULT_N - 1)];
-                ra = ra_n; mu = mu_n; ev = ev_n;
-            }
+        // event of my sample in step c: events begun in earlier steps + start bits below my lane
+        #define LEAN_MAP(c_, ev_) {                                                                              \
+            const uint32_t lo_ = __builtin_amdgcn_readlane(bm_lo, (c_)), hi_ = __builtin_amdgcn_readlane(bm_hi, (c_)); \
+            ev_ = (int)__builtin_amdgcn_mbcnt_hi(hi_, __builtin_amdgcn_mbcnt_lo(lo_, (uint32_t)base_ev));          \
+            base_ev += __builtin_popcount(lo_) + __builtin_popcount(hi_); }
+        // one step: issue the loads of step c_+1 into (RN, MN, EN), then the arithmetic of step c_ from (RA, MU, EV)
+        #define LEAN_STEP(TAIL, c_, RA, MU, EV, RN, MN, EN) {                                                    \
+            LEAN_MAP(min((c_) + 1, 63), EN)                                                                       \
+            RN = W.rec[EN];                                                                                       \
+            const uint32_t c1 = lcg_mul(RA.x, MU.x);                                                              \
+            const uint32_t r2 = lcg_mul_lazy(RA.x, MU.y);                                                         \
+            const float x = box_muller_fast(c1, r2);                                                              \
+            const float vh = __builtin_fmaf(x, __uint_as_float(RA.w), __uint_as_float(RA.z));                     \
+            const float t = vh + LEAN_MAGIC;                                                                      \
+            const float d = vh - (t - LEAN_MAGIC);                                                                \
+            const bool act = !(TAIL) || (int)(idx8 >> 3) < wave_total;                                            \
+            const bool ok = fabsf(d) < thr && c1 <= LCG_M - (1u << NEAR_ONE_BITS);                                \
+            if (act && ok) *reinterpret_cast<uint16_t*>(out_b + voff) = (uint16_t)((__float_as_uint(t) + RA.y) & 0xffffu); \
+            else if (act) {                                        /* ~1 % of steps: park the undecided samples (no round trip) */ \
+                const unsigned long long am = __builtin_amdgcn_ballot_w64(true);                                  \
+                const int n0 = W.nfix;                                                                            \
+                const int slot = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)); \
+                if (slot < FIX_SLOTS) P.tfix[(size_t)g * FIX_SLOTS + slot] = make_uint4(voff >> 1, c1, (uint32_t)(ev_read0 + EV), 0u); \
+                else push_fix_one(P, sig_base + (voff >> 1), c1, rd.ev_off + ev_read0 + EV, r, 0);   /* overflow (never in practice): global list */ \
+                if (slot + 1 == n0 + __popcll(am)) W.nfix = slot + 1;          /* the last of them publishes the new count */ \
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                            \
+            }                                                                                                     \
+            idx8 += 512u;                                                                                         \
+            voff = RNA ? voff - 128u : voff + 128u;                                                               \
+            MN = *reinterpret_cast<const uint2*>(mult_b + ((idx8 - (RN.y >> 16)) & 0xff8u)); }
+
+        uint4 ra, rb; uint2 ma, mb; int eva, evb;
+        base_ev = 0;
+        LEAN_MAP(0, eva)
+        ra = W.rec[eva];
+        ma = *reinterpret_cast<const uint2*>(mult_b + ((idx8 - (ra.y >> 16)) & 0xff8u));
+        int c = 0;
+        for (; c + 2 <= nfull; c += 2) {
+            LEAN_STEP(false, c, ra, ma, eva, rb, mb, evb)
+            LEAN_STEP(false, c + 1, rb, mb, evb, ra, ma, eva)
         }
+        if (c < nfull) {
+            LEAN_STEP(false, c, ra, ma, eva, rb, mb, evb)
+            ra = rb; ma = mb; eva = evb; c++;
+        }
+        if (rem) LEAN_STEP(true, c, ra, ma, eva, rb, mb, evb)
+        #undef LEAN_STEP
+        #undef LEAN_MAP
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int nfix = W.nfix;
         if (nfix && lane == 0) P.tfix_n[g] = (unsigned char)min(nfix, FIX_SLOTS);
     }
 }
