@@ -60,6 +60,7 @@ struct sqg_ctx {
     int* d_slow = nullptr; size_t slow_cap = 0;
     uint4* d_tfix = nullptr; size_t tfix_cap = 0;
     unsigned char* d_tfix_n = nullptr; size_t tfixn_cap = 0;
+    ItemDesc* d_items = nullptr; size_t items_cap = 0;          // [n_stiles] work items of the lean kernel (k_items)
     long long tile_fix = 0;                // undecided samples parked per tile in the last batch (timing info)
     std::string err;
 };
@@ -153,7 +154,7 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     (void)hipFree(ctx->d_sig); (void)hipFree(ctx->d_dwell); (void)hipFree(ctx->d_seglen); (void)hipFree(ctx->d_sigoff);
     (void)hipFree(ctx->d_fix); (void)hipFree(ctx->d_fix_count);
     (void)hipFree(ctx->d_evrec); (void)hipFree(ctx->d_tile_so); (void)hipFree(ctx->d_slow);
-    (void)hipFree(ctx->d_tfix); (void)hipFree(ctx->d_tfix_n);
+    (void)hipFree(ctx->d_tfix); (void)hipFree(ctx->d_tfix_n); (void)hipFree(ctx->d_items);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -507,6 +508,7 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     if (certified && c->use_kmer_streams) {
         if ((rc = ensure(c, (void**)&c->d_tfix, &c->tfix_cap, (size_t)b->n_stiles * FIX_SLOTS + 64, sizeof(uint4)))) return rc;
         if ((rc = ensure(c, (void**)&c->d_tfix_n, &c->tfixn_cap, (size_t)b->n_stiles + 64, 1))) return rc;
+        if ((rc = ensure(c, (void**)&c->d_items, &c->items_cap, (size_t)b->n_stiles + 64, sizeof(ItemDesc)))) return rc;
         HIPCHK(c, hipMemsetAsync(c->d_tfix_n, 0, (size_t)b->n_stiles + 1, c->stream));
     }
 
@@ -597,13 +599,16 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
             int32_t t = (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000u;
             P.shift = (int)(int16_t)(uint16_t)((uint32_t)t & 0xffffu);
         }
-        P.slow_tiles = nullptr; P.slow_count = c->d_fix_count + 1; P.tfix = c->d_tfix; P.tfix_n = c->d_tfix_n;
+        P.slow_tiles = nullptr; P.slow_count = c->d_fix_count + 1; P.tfix = c->d_tfix; P.tfix_n = c->d_tfix_n; P.items = c->d_items;
         const int n_tiles = (int)b->n_tiles;
         const unsigned sgrid = (unsigned)((n_tiles + 3) / 4);
         if (certified && c->use_kmer_streams) {
             P.slow_tiles = c->d_slow;
             const int n_stiles = (int)b->n_stiles;
-            const unsigned lgrid = (unsigned)((n_stiles + 3) / 4);
+            unsigned lgrid = (unsigned)((n_stiles + 3) / 4);
+            static const int lean_grid_cap = getenv("SQG_LEAN_GRID") ? atoi(getenv("SQG_LEAN_GRID")) : 0;   // A/B knob
+            if (lean_grid_cap > 0) lgrid = std::min(lgrid, (unsigned)lean_grid_cap);
+            hipLaunchKernelGGL(k_items, dim3((unsigned)((n_stiles + 255) / 256)), dim3(256), 0, c->stream, P, n_stiles);
             HIPCHK(c, hipEventRecord(b->ev[5], c->stream));
             if (P.rna) hipLaunchKernelGGL((k_samples_lean<true>), dim3(lgrid), dim3(256), 0, c->stream, P, n_stiles);
             else hipLaunchKernelGGL((k_samples_lean<false>), dim3(lgrid), dim3(256), 0, c->stream, P, n_stiles);
@@ -638,6 +643,9 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
         for (int i = 0; i <= b->n; i++) b->sig_off[(size_t)i] = b->h_sigoff[i];
         unsigned int e = 0;
         HIPCHK(c, hipMemcpy(&e, c->d_err, sizeof e, hipMemcpyDeviceToHost));
+#if defined(SQG_ABL_EV_NOSTORE) || defined(SQG_ABL_NOSTORE)       /* timing-only ablation builds: results are garbage by design */
+        if (e) { HIPCHK(c, hipMemset(c->d_err, 0, sizeof e)); e = 0; }
+#endif
         if (e) {
             HIPCHK(c, hipMemset(c->d_err, 0, sizeof e));
             c->err = "device reported: " + std::string((e & 1) ? "dwell>65535 " : "") + ((e & 2) ? "read>=UINT32_MAX samples " : "") + ((e & 4) ? "internal length mismatch " : "") + ((e & 8) ? "FP64 fix-up list overflow" : "");

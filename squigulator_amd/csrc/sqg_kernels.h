@@ -134,6 +134,19 @@ struct FixEntry {         // one sample handed to the FP64 path
     int pad;
 };
 
+// work item of k_samples_lean (256 consecutive events of one read), filled by k_items
+struct ItemDesc {
+    long long ev_first;          // index (in evrec / dwell) of the item's first event
+    long long sig_base;          // index (in sig) of the read's first sample
+    double offset;               // the read's slow5 offset
+    int n_ev;                    // events in the item (1..256); 0: not taken (queued for the generic kernel, or empty)
+    int n_samples;               // samples in the item
+    uint32_t at0;                // position within the read of the item's first sample (RNA: counted from the read's end)
+    int ev_read0;                // index within the read of the item's first event
+    int read;                    // read index (fix-up overflow path)
+    int pad;
+};
+
 struct SigParams {
     const ReadDesc* reads;
     const int* chain_off;        // [n_chains+1]
@@ -158,6 +171,7 @@ struct SigParams {
     uint32_t* tile_so;           // per 64-event tile: its first sample within the read
     const int* tile_read;        // per tile: read index
     const int* stile_read;       // per 256-event super tile (lean kernel work item): read index
+    ItemDesc* items;             // per super tile: what k_samples_lean needs, in one 48-B record
     int* slow_tiles;             // tiles the lean sample kernel left to the generic one
     unsigned int* slow_count;
     uint4* tfix;                 // lean kernel: FIX_SLOTS undecided samples per tile {index in read, c1, event in read, 0}
@@ -323,20 +337,34 @@ __global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restr
 #define MULT_N 512         // LDS jump constants cover events of up to 512 samples
 #define BIN_EMPTY 0xffffffffu
 
+// inclusive wave scan with DPP row shifts/broadcasts (6 VALU, no LDS)
+__device__ static inline int wave_incl_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 __device__ static inline int wave_incl_scan(int v, int lane) {
     for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(v, o); if (lane >= o) v += y; }
     return v;
 }
 
 #define EV_NIL 0xffffu
+#define ROW_BUSY 0x80000000u
 #define EV_HALO 20          // 2*(k_max-1)+2 extra base codes per segment (segment-0/1 boundary)
 
 // DIRECT (k <= 6): one bin per k-mer rank, no keys, no probing; otherwise an open-addressing hash of 2*NT bins
 template <int NT, bool DIRECT>
 struct EvLds {
     uint32_t keys[DIRECT ? 1 : 2 * NT];      // hash bins: k-mer rank
-    uint32_t head[DIRECT ? 4096 : 2 * NT];   // bin -> most recently inserted event of the segment (EV_NIL: none)
-    uint32_t row[DIRECT ? 4096 : 1];         // DIRECT: the worker's stream states, resident for the whole chain
+    uint32_t head[DIRECT ? 1 : 2 * NT];      // hash bin -> most recently inserted event of the segment (EV_NIL: none)
+    uint32_t row[DIRECT ? 4096 : 1];         // DIRECT: the worker's stream states, resident for the whole chain; while a segment
+                                             // is being handed out, ROW_BUSY | (most recently inserted event of the bin)
+    uint32_t st[DIRECT ? NT : 1];            // DIRECT: the state the bin's first event of the segment swapped out of row[]
     uint32_t nxt[NT];           // per event: (dwell << 16) | next event in the same bin
     uint32_t jump[(MULT_N > NT ? MULT_N : NT)];      // a^(2j)
     uint8_t codes[NT + EV_HALO + 4];   // 2-bit base codes of the segment
@@ -359,7 +387,6 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < (MULT_N > NT ? MULT_N : NT); i += NT) L.jump[i] = P.pw[2 * POW_N + i];
     for (int i = tid; i < 256; i += NT) L.lut[i] = (uint8_t)base_code((uint8_t)i);
-    if (DIRECT) for (int i = tid; i < 4096; i += NT) L.head[i] = EV_NIL;      // kept clean by the events themselves
 
     const int chain = P.chain_order[blockIdx.x];
     const int c_lo = P.chain_off[chain], c_hi = P.chain_off[chain + 1];
@@ -382,7 +409,7 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
         // straddle the boundary, src/genread.c:87-88)
         #define EV_BASE(e_) ((long long)(e_) + ((e_) >= rd.ne0 ? (long long)rd.len0 - rd.ne0 : 0LL))
         uint32_t done = 0;                                            // samples before this segment
-        uint32_t c_seg = rd.time_c0;                                  // time-stream state at the segment's first event
+        uint32_t c_seg = DW ? lcg_mul(rd.time_c0, LCG_A) : 0u;        // a * (time-stream state at the segment's first event)
         if (DW && tid == 0) n1_sh = -1;
         // prefetch of segment 0: one base byte per thread (+ halo), one dwell per thread
         uint8_t b_cur = 'A', b_halo = 'A';
@@ -397,14 +424,13 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
             const int e = s0 + tid;
             const bool valid = e < ne;
             const long long bseg = EV_BASE(s0);
-            L.codes[tid] = L.lut[b_cur];
-            if (tid < EV_HALO) L.codes[NT + tid] = L.lut[b_halo];
+            const uint8_t code_cur = L.lut[b_cur], code_halo = L.lut[tid < EV_HALO ? b_halo : (uint8_t)'A'];   // consumed after the dwell draw
             int sps = 0;
             if (DW == 0) {
                 sps = valid ? (P.dwell ? (int)d_cur : P.const_sps) : 0;
             } else if (valid) {
                 // event e uses draws 2e+1, 2e+2 of the worker's time stream after the read's first state
-                const uint32_t c1 = lcg_mul(lcg_mul(c_seg, L.jump[tid]), LCG_A);
+                const uint32_t c1 = lcg_mul(c_seg, L.jump[tid]);
                 bool decided = false;
                 if (DW == 1) {
                     // v' = x'*s + m in fp32; round(v) = floor(v+1/2) unless v is within eps of a half-integer
@@ -416,10 +442,16 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
                 if (!decided) sps = dwell_exact(c1, P.dstd, P.dmean);    // src/gensig.c:255
                 sps = sps < 1 ? -sps + 1 : sps;                          // src/gensig.c:256
                 if (sps > 65535) { atomicOr(P.err, 1u); sps = 65535; }
+#if !defined(SQG_ABL_EV_NOSTORE)
                 P.dwell_out[rd.ev_off + e] = (uint16_t)sps;
+#else
+                if (sps == 123456) P.dwell_out[rd.ev_off + e] = (uint16_t)sps;
+#endif
             }
             if (DW) c_seg = lcg_mul(c_seg, a2nt);
-            const int incl = wave_incl_scan(sps, lane);
+            L.codes[tid] = code_cur;
+            if (tid < EV_HALO) L.codes[NT + tid] = code_halo;
+            const int incl = wave_incl_scan_dpp(sps);
             if (lane == 63) L.wsum[wid] = incl;
             if (!DIRECT && P.use_streams) for (int i = tid; i < HT; i += NT) { L.keys[i] = BIN_EMPTY; L.head[i] = EV_NIL; }
             lds_barrier();                                                                    // (1)
@@ -428,19 +460,33 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
             uint32_t rank = 0;
             if (valid) {
                 const int cb = (int)(EV_BASE(e) - bseg);
-                for (int i = 0; i < k; i++) rank = (rank << 2) | L.codes[cb + i];               // src/seq.h:31-42
+                // src/seq.h:31-42; the usual k are unrolled so that the byte reads are in flight together
+                #define EV_RANK(K_) { _Pragma("unroll") for (int i = 0; i < K_; i++) rank = (rank << 2) | L.codes[cb + i]; }
+                switch (k) {
+                case 6: EV_RANK(6) break;
+                case 9: EV_RANK(9) break;
+                case 5: EV_RANK(5) break;
+                default: for (int i = 0; i < k; i++) rank = (rank << 2) | L.codes[cb + i];
+                }
+                #undef EV_RANK
             }
             uint32_t h = DIRECT ? rank : (rank * 2654435761u) >> (32 - (31 - __builtin_clz(HT)));
+            uint32_t swapped = 0;                                      // DIRECT: what my exchange found in row[rank]
             if (P.use_streams && valid) {
-                if (!DIRECT) {
+                if (DIRECT) {
+                    // the bin's members chain through row[rank]; the first one of the segment takes the state out
+                    swapped = atomicExch(&L.row[rank], ROW_BUSY | (uint32_t)tid);
+                    L.nxt[tid] = ((uint32_t)sps << 16) | ((swapped & ROW_BUSY) ? (swapped & 0xffffu) : EV_NIL);
+                    if (!(swapped & ROW_BUSY)) L.st[tid] = swapped;
+                } else {
                     for (;;) {
                         const uint32_t old = atomicCAS(&L.keys[h], BIN_EMPTY, rank);
                         if (old == BIN_EMPTY || old == rank) break;
                         h = (h + 1) & (HT - 1);
                     }
+                    const uint32_t prev = atomicExch(&L.head[h], (uint32_t)tid);
+                    L.nxt[tid] = ((uint32_t)sps << 16) | prev;
                 }
-                const uint32_t prev = atomicExch(&L.head[h], (uint32_t)tid);
-                L.nxt[tid] = ((uint32_t)sps << 16) | prev;
             }
             if (DIRECT) lds_barrier(); else __syncthreads();                                  // (2) global rows: + earlier row stores have landed
             // prefetch the next segment's inputs; they land while this segment waits for its states
@@ -463,19 +509,26 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
                 bool last = true;
                 uint32_t c_row = 0;
                 if (valid) {
-                    c_row = DIRECT ? L.row[rank] : __builtin_nontemporal_load(&row[rank]);   // global: L2-served (bypasses the CU's L1)
-                    uint32_t t = L.head[h];
+                    uint32_t t;
+                    if (DIRECT) {
+                        c_row = swapped;                                                     // the state itself if I was first
+                        t = L.row[rank] & 0xffffu;                                           // most recently inserted event
+                        if (t == (uint32_t)tid && !(swapped & ROW_BUSY)) { total = (uint32_t)sps; t = EV_NIL; }   // alone in the bin
+                    } else {
+                        c_row = __builtin_nontemporal_load(&row[rank]);                      // global: L2-served (bypasses the CU's L1)
+                        t = L.head[h];
+                    }
                     while (t != EV_NIL) {
                         const uint32_t v = L.nxt[t];
                         const uint32_t s2 = v >> 16;
                         total += s2;
                         if (t < (uint32_t)tid) prior += s2;
                         if (t > (uint32_t)tid) last = false;
+                        if (DIRECT && (v & 0xffffu) == EV_NIL && t != (uint32_t)tid) c_row = L.st[t];   // the first one holds the state
                         t = v & 0xffffu;
                     }
                 }
                 if (DIRECT) lds_barrier(); else __syncthreads();                                // (3) every state read before any is advanced
-                if (DIRECT && valid) L.head[h] = EV_NIL;                                       // leave the table clean for the next segment
                 if (valid) {
                     c_ev = prior ? lcg_mul(c_row, prior < MULT_N ? L.jump[prior] : lcg_jump2(P.pw, prior)) : c_row;
                     if (last) {
@@ -484,7 +537,11 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
                     }
                 }
             }
+#if !defined(SQG_ABL_EV_NOSTORE)
             if (valid) P.evrec[rd.ev_off + e] = make_uint2(c_ev, rank);
+#else
+            if (valid && c_ev == 0x7fffffffu) P.evrec[rd.ev_off + e] = make_uint2(c_ev, rank);
+#endif
             done += (uint32_t)seg_total;
             // no barrier here: every LDS structure rewritten at the top of the next segment (codes, wsum, bins) was last
             // read before barrier (2)/(3) of this one, which every thread has passed
@@ -540,20 +597,50 @@ __device__ static inline void push_fix_one(const SigParams& P, long long at, uin
     } else atomicOr(P.err, 8u);
 }
 
-// inclusive wave scan with DPP row shifts/broadcasts (6 VALU, no LDS)
-__device__ static inline int wave_incl_scan_dpp(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
-    return v;
-}
-
 #define LEAN_EPL 4                         // events per lane
 #define LEAN_EV (64 * LEAN_EPL)            // events per wavefront work item ("super tile" = 4 consecutive 64-event tiles of one read)
 #define FIX_SLOTS 8                        // parked undecided samples per super tile (expected ~0.5); overflow -> global list
+#define LEAN_MAX_SAMPLES 4096              // samples per work item the 64x64-bit start map covers
+#define LEAN_MAGIC 12582912.0f             // 1.5 * 2^23: t = v + MAGIC rounds v to the nearest integer, in the low bits of t
+
+// k_items: one thread per 256-event super tile.  Collapses the dependent look-ups of the lean kernel's set-up
+// (tile -> read -> tile_so / sig_off / seglen) into one record per item and decides which items the lean
+// kernel takes; the others are queued (as 64-event tiles) for k_samples<MODE, GENERIC>.
+__global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_stiles) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_stiles) return;
+    const int r = P.stile_read[g];
+    const ReadDesc rd = P.reads[r];
+    const int lt = g - rd.stile_off;                                   // super tile within the read
+    const int ne = rd.ne0 + rd.ne1;
+    const int n_ev = min(LEAN_EV, ne - lt * LEAN_EV);
+    const long long sig_base = P.sig_off[r];
+    const uint32_t read_len = (uint32_t)(P.sig_off[r + 1] - sig_base);
+    const uint32_t base_pos = P.tile_so[rd.tile_off + lt * LEAN_EPL];
+    const uint32_t next_pos = (lt + 1) * LEAN_EV < ne ? P.tile_so[rd.tile_off + (lt + 1) * LEAN_EPL] : read_len;
+    const int n_samples = (int)(next_pos - base_pos);
+    bool take = rd.fast != 0 && n_samples <= LEAN_MAX_SAMPLES;
+    if (P.shift_len > 0) {                                             // RNA adaptor level-shift window (src/genread.c:79-86)
+        const long long n1 = (long long)P.seglen[2 * r];
+        if ((long long)base_pos + n_samples > n1 - P.shift_len && (long long)base_pos < n1) take = false;
+    }
+    if (!take) {                                                       // leave these (up to 4) 64-event tiles to the generic kernel
+        const int nt = (n_ev + 63) >> 6;
+        const unsigned int q = atomicAdd(P.slow_count, (unsigned int)nt);
+        for (int i = 0; i < nt; i++) P.slow_tiles[q + i] = rd.tile_off + lt * LEAN_EPL + i;
+    }
+    ItemDesc d;
+    d.ev_first = rd.ev_off + (long long)lt * LEAN_EV;
+    d.sig_base = sig_base;
+    d.offset = rd.offset;
+    d.n_ev = (take && n_samples > 0) ? n_ev : 0;
+    d.n_samples = n_samples;
+    d.at0 = P.rna ? read_len - 1u - base_pos : base_pos;
+    d.ev_read0 = lt * LEAN_EV;
+    d.read = r;
+    d.pad = 0;
+    P.items[g] = d;
+}
 
 struct LeanWaveLds {
     uint4 rec[LEAN_EV];                 // {c_ev, ((8*first sample) & 0xfff) << 16 | I (16 bits), F - 1/2, sdk}
@@ -565,8 +652,6 @@ struct LeanLds {
     uint2 mult[MULT_N];                 // {a^(2j+1), a^(2j+2)}
     LeanWaveLds w[4];
 };
-#define LEAN_MAX_SAMPLES 4096           // samples per work item the 64x64-bit start map covers
-#define LEAN_MAGIC 12582912.0f          // 1.5 * 2^23: t = v + MAGIC rounds v to the nearest integer, in the low bits of t
 
 // k_samples_lean: the hot kernel.  Certified fp32 path only, for reads whose ADC values are provably in
 // (2, 65000) (ReadDesc.fast), events of <= MULT_N samples, outside the RNA level-shift window; everything
@@ -592,21 +677,37 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
     const char* mult_b = reinterpret_cast<const char*>(L.mult);
 
     for (int g = blockIdx.x * 4 + wid; g < n_stiles; g += gridDim.x * 4) {
-        const int r = P.stile_read[g];
-        const ReadDesc rd = P.reads[r];
-        const int lt = g - rd.stile_off;                               // super tile within the read
-        const int ne = rd.ne0 + rd.ne1;
-        const int e0 = lt * LEAN_EV + lane * LEAN_EPL;                 // my first event (within the read)
-        const long long gev = rd.ev_off + e0;
+        // the item's descriptor is wave-uniform: scalar load (the constant address space forces s_load; k_items wrote it
+        // before this kernel started)
+        ItemDesc it;
+        {
+            const __attribute__((address_space(4))) uint32_t* src =
+                reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(P.items + g));
+            uint32_t w[sizeof(ItemDesc) / 4];
+#pragma unroll
+            for (int q = 0; q < (int)(sizeof(ItemDesc) / 4); q++) w[q] = src[q];
+            __builtin_memcpy(&it, w, sizeof it);
+        }
+        const int ne = it.n_ev;                                         // events of this item
+        if (ne == 0) continue;                                         // not taken, or empty
+        const int wave_total = it.n_samples;
+        const int e0 = lane * LEAN_EPL;                                // my first event (within the item)
+        const long long gev = it.ev_first + e0;
         // ---- set-up: 4 consecutive events per lane ----
         uint2 er[LEAN_EPL];
         int sps[LEAN_EPL];
         if (e0 + LEAN_EPL <= ne) {
-            const uint4 a = *reinterpret_cast<const uint4*>(P.evrec + gev);          // ev_off is even: 16-B aligned
+            const uint4 a = *reinterpret_cast<const uint4*>(P.evrec + gev);          // 8-B aligned 16-B loads
             const uint4 b = *reinterpret_cast<const uint4*>(P.evrec + gev + 2);
             er[0] = make_uint2(a.x, a.y); er[1] = make_uint2(a.z, a.w); er[2] = make_uint2(b.x, b.y); er[3] = make_uint2(b.z, b.w);
+            if (P.dwell) {
+                uint2 dw;
+                __builtin_memcpy(&dw, P.dwell + gev, 8);                              // 2-B aligned 8-B load
+                sps[0] = (int)(dw.x & 0xffffu); sps[1] = (int)(dw.x >> 16); sps[2] = (int)(dw.y & 0xffffu); sps[3] = (int)(dw.y >> 16);
+            } else {
 #pragma unroll
-            for (int q = 0; q < LEAN_EPL; q++) sps[q] = P.dwell ? (int)P.dwell[gev + q] : P.const_sps;
+                for (int q = 0; q < LEAN_EPL; q++) sps[q] = P.const_sps;
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < LEAN_EPL; q++) {
@@ -620,20 +721,6 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         for (int q = 0; q < LEAN_EPL; q++) md[q] = (e0 + q < ne) ? P.model[er[q].y] : make_float2(0.f, 0.f);
         const int lane_total = sps[0] + sps[1] + sps[2] + sps[3];
         const int incl = wave_incl_scan_dpp(lane_total);
-        const int wave_total = __builtin_amdgcn_readlane(incl, 63);
-        const uint32_t base_pos = P.tile_so[rd.tile_off + lt * LEAN_EPL];
-        const long long sig_base = P.sig_off[r];
-        bool take = rd.fast != 0 && wave_total <= LEAN_MAX_SAMPLES;
-        if (P.shift_len > 0) {                                         // RNA adaptor level-shift window (src/genread.c:79-86)
-            const long long n1 = (long long)P.seglen[2 * r];
-            if ((long long)base_pos + wave_total > n1 - P.shift_len && (long long)base_pos < n1) take = false;
-        }
-        if (!take) {                                                   // leave these (up to 4) 64-event tiles to the generic kernel
-            const int nt = min(LEAN_EPL, (ne - lt * LEAN_EV + 63) >> 6);
-            if (lane < nt) { const unsigned int q = atomicAdd(P.slow_count, 1u); P.slow_tiles[q] = rd.tile_off + lt * LEAN_EPL + lane; }
-            continue;
-        }
-        if (wave_total <= 0) continue;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // previous item's LDS reads are done
         W.bm[lane] = 0ull;
         if (lane == 0) W.nfix = 0;
@@ -644,7 +731,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
             for (int q = 0; q < LEAN_EPL; q++) {
                 const int so = run; run += sps[q];
                 // v = s_f*dig/range - offset  ~  x*(sd*kd) + (m*kd - offset) = x*sdk + (I + F), I = floor(.) in (2, 65000)
-                const double mk = (double)md[q].x * P.kd - rd.offset;
+                const double mk = (double)md[q].x * P.kd - it.offset;
                 const double fl0 = floor(mk);
                 const float Fh = (float)(mk - fl0 - 0.5);
                 const float sdk = (float)((double)md[q].y * P.kd);
@@ -657,16 +744,16 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         const unsigned long long my_bm = W.bm[lane];
         const uint32_t bm_lo = (uint32_t)my_bm, bm_hi = (uint32_t)(my_bm >> 32);
-        const uint32_t read_len = (uint32_t)(P.sig_off[r + 1] - sig_base);
-        // wave-uniform output base: keep it in SGPRs (global_store saddr + 32-bit lane offset)
-        const long long sig_base_u = (long long)(((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)sig_base >> 32)) << 32) |
-                                                 (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)sig_base));
-        char* const out_b = reinterpret_cast<char*>(P.sig + sig_base_u);
-        // byte offset of my sample of step 0 within the read: generation index i is stored at base_pos + i (RNA: read_len-1-base_pos-i)
-        uint32_t voff = RNA ? 2u * (read_len - 1u - base_pos - (uint32_t)lane) : 2u * (base_pos + (uint32_t)lane);
+        char* const out_b = reinterpret_cast<char*>(P.sig + it.sig_base);               // wave-uniform: global_store saddr + 32-bit lane offset
+        // byte offset of my sample of step 0 within the read: generation index i is stored at at0 + i (RNA: at0 - i)
+        uint32_t voff = RNA ? 2u * (it.at0 - (uint32_t)lane) : 2u * (it.at0 + (uint32_t)lane);
         uint32_t idx8 = (uint32_t)lane << 3;                           // 8 * (my sample index within the item)
-        const int ev_read0 = lt * LEAN_EV;                             // event index (within the read) of rec[0]
+        const int ev_read0 = it.ev_read0;                               // event index (within the read) of rec[0]
+#if defined(SQG_ABL_NOLOOP)
+        const int nfull = 0, rem = wave_total & 1;
+#else
         const int nfull = wave_total >> 6, rem = wave_total & 63;
+#endif
         int base_ev;
 
         // event of my sample in step c: events begun in earlier steps + start bits below my lane
@@ -678,21 +765,19 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         #define LEAN_STEP(TAIL, c_, RA, MU, EV, RN, MN, EN) {                                                    \
             LEAN_MAP(min((c_) + 1, 63), EN)                                                                       \
             RN = W.rec[EN];                                                                                       \
-            const uint32_t c1 = lcg_mul(RA.x, MU.x);                                                              \
-            const uint32_t r2 = lcg_mul_lazy(RA.x, MU.y);                                                         \
-            const float x = box_muller_fast(c1, r2);                                                              \
+            LEAN_ARITH(RA, MU)                                                                                    \
             const float vh = __builtin_fmaf(x, __uint_as_float(RA.w), __uint_as_float(RA.z));                     \
             const float t = vh + LEAN_MAGIC;                                                                      \
             const float d = vh - (t - LEAN_MAGIC);                                                                \
             const bool act = !(TAIL) || (int)(idx8 >> 3) < wave_total;                                            \
             const bool ok = fabsf(d) < thr && c1 <= LCG_M - (1u << NEAR_ONE_BITS);                                \
-            if (act && ok) *reinterpret_cast<uint16_t*>(out_b + voff) = (uint16_t)((__float_as_uint(t) + RA.y) & 0xffffu); \
+            if (act && ok LEAN_STORE_COND) *reinterpret_cast<uint16_t*>(out_b + voff) = (uint16_t)((__float_as_uint(t) + RA.y) & 0xffffu); \
             else if (act) {                                        /* ~1 % of steps: park the undecided samples (no round trip) */ \
                 const unsigned long long am = __builtin_amdgcn_ballot_w64(true);                                  \
                 const int n0 = W.nfix;                                                                            \
                 const int slot = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)); \
                 if (slot < FIX_SLOTS) P.tfix[(size_t)g * FIX_SLOTS + slot] = make_uint4(voff >> 1, c1, (uint32_t)(ev_read0 + EV), 0u); \
-                else push_fix_one(P, sig_base + (voff >> 1), c1, rd.ev_off + ev_read0 + EV, r, 0);   /* overflow (never in practice): global list */ \
+                else push_fix_one(P, it.sig_base + (voff >> 1), c1, it.ev_first + EV, it.read, 0);   /* overflow (never in practice): global list */ \
                 if (slot + 1 == n0 + __popcll(am)) W.nfix = slot + 1;          /* the last of them publishes the new count */ \
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                            \
             }                                                                                                     \
@@ -700,6 +785,17 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
             voff = RNA ? voff - 128u : voff + 128u;                                                               \
             MN = *reinterpret_cast<const uint2*>(mult_b + ((idx8 - (RN.y >> 16)) & 0xff8u)); }
 
+        /* ablation builds (tools/ab_variants.sh; results are wrong): -DSQG_ABL_NOARITH, -DSQG_ABL_NOSTORE, -DSQG_ABL_NOLOOP */
+#if defined(SQG_ABL_NOSTORE)
+        #define LEAN_STORE_COND && (__float_as_uint(t) == 0x12345u)
+#else
+        #define LEAN_STORE_COND
+#endif
+#if defined(SQG_ABL_NOARITH)
+        #define LEAN_ARITH(RA, MU) const uint32_t c1 = (RA.x ^ MU.x) & 0x3fffffffu; const float x = __uint_as_float((RA.x + MU.y) & 0x3fffffffu);
+#else
+        #define LEAN_ARITH(RA, MU) const uint32_t c1 = lcg_mul(RA.x, MU.x); const uint32_t r2 = lcg_mul_lazy(RA.x, MU.y); const float x = box_muller_fast(c1, r2);
+#endif
         uint4 ra, rb; uint2 ma, mb; int eva, evb;
         base_ev = 0;
         LEAN_MAP(0, eva)
@@ -717,6 +813,8 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         if (rem) LEAN_STEP(true, c, ra, ma, eva, rb, mb, evb)
         #undef LEAN_STEP
         #undef LEAN_MAP
+        #undef LEAN_ARITH
+        #undef LEAN_STORE_COND
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         const int nfix = W.nfix;
         if (nfix && lane == 0) P.tfix_n[g] = (unsigned char)min(nfix, FIX_SLOTS);
