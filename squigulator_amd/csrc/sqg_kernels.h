@@ -67,15 +67,18 @@ __device__ static inline double box_muller_exact(uint32_t c1, uint32_t c2) {
     return sqrt(-2.0 * log(u)) * cos(t);
 }
 
-// fp32 evaluation of the same deviate.  c1 canonical; r2 = second draw, any representative in
-// [0, 2^32) of its residue.  v_log_f32 is log2, v_cos_f32 takes turns.  The 6.2831853-vs-2*pi
-// ratio (1 - 1.1e-9) is below fp32 resolution; the sweep prices it with everything else.
-__device__ static inline float box_muller_fast(uint32_t c1, uint32_t r2) {
+// fp32 evaluation of the same deviate from the canonical first draw c1 (the second one is a function of it).
+// v_log_f32 is log2, v_cos_f32 takes turns.  The 6.2831853-vs-2*pi ratio (1 - 1.1e-9) is below fp32
+// resolution; the sweep (k_certify) prices it with everything else.
+__device__ static inline float box_muller_fast(uint32_t c1) {
     const float uf = (float)c1 * 4.656612873077393e-10f;                  // c1 * 2^-31 (exact scaling)
     const float lg = __builtin_amdgcn_logf(uf);
     const float y = __builtin_fmaf(lg, -1.3862943611198906f, -9.313225750491594e-10f);   // -2 ln(c1/M)
     const float r = __builtin_amdgcn_sqrtf(y);
-    const float cs = __builtin_amdgcn_cosf((float)r2 * 4.656612873077393e-10f);
+    // second uniform c2/M = frac(a*c1/M): four full-rate FP64/convert instructions instead of a modular
+    // multiplication plus an int->float conversion (the product is exact to 2^-39, far below fp32 resolution)
+    const double t2 = (double)c1 * (16807.0 / 2147483647.0);                // a / M
+    const float cs = __builtin_amdgcn_cosf((float)__builtin_amdgcn_fract(t2));
     return r * cs;
 }
 
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256) void k_dwell(const ReadDesc* __restrict__ read
             bool decided = false;
             if (MODE == 1) {
                 // v' = x'*s + m in fp32; round(v) = floor(v+1/2) unless v is within eps of a half-integer
-                const float x = box_muller_fast(c1, lcg_mul_lazy(c1, LCG_A));
+                const float x = box_muller_fast(c1);
                 const float g = __builtin_fmaf(x, sf, mf) + 0.5f;
                 const float fl = floorf(g);
                 const float fr = g - fl;
@@ -333,6 +336,9 @@ __global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restr
 #ifndef SQG_EVENT_THREADS
 #define SQG_EVENT_THREADS 256
 #endif
+#ifndef SQG_EVENT_WAVES
+#define SQG_EVENT_WAVES 7   // waves per SIMD the register allocation of k_events aims at (LDS allows 7 workgroups per CU)
+#endif
 #define MK_W 1024          // marker window (samples) per wavefront
 #define MULT_N 512         // LDS jump constants cover events of up to 512 samples
 #define BIN_EMPTY 0xffffffffu
@@ -380,7 +386,7 @@ __device__ static inline void lds_barrier() {
 // DW: 0 = dwell comes from memory (k_dwell ran) or is constant; 1 = drawn here, certified fp32 path with
 // inline FP64 fallback; 2 = drawn here in FP64 (src/gensig.c:254-257)
 template <int NT, bool DIRECT, int DW>
-__global__ __launch_bounds__(NT) void k_events(const SigParams P) {
+__global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams P) {
     __shared__ EvLds<NT, DIRECT> L;
     __shared__ long long n1_sh;
     constexpr int NW = NT / 64, HT = 2 * NT;
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(NT) void k_events(const SigParams P) {
                 bool decided = false;
                 if (DW == 1) {
                     // v' = x'*s + m in fp32; round(v) = floor(v+1/2) unless v is within eps of a half-integer
-                    const float x = box_muller_fast(c1, lcg_mul_lazy(c1, LCG_A));
+                    const float x = box_muller_fast(c1);
                     const float g = __builtin_fmaf(x, dw_sf, dw_mf) + 0.5f;
                     const float fl = floorf(g);
                     if (fabsf(g - fl - 0.5f) < 0.5f - dw_eps && c1 <= LCG_M - (1u << NEAR_ONE_BITS) && fabsf(g) < 1.0e6f) { sps = (int)fl; decided = true; }
@@ -794,7 +800,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
 #if defined(SQG_ABL_NOARITH)
         #define LEAN_ARITH(RA, MU) const uint32_t c1 = (RA.x ^ MU.x) & 0x3fffffffu; const float x = __uint_as_float((RA.x + MU.y) & 0x3fffffffu);
 #else
-        #define LEAN_ARITH(RA, MU) const uint32_t c1 = lcg_mul(RA.x, MU.x); const uint32_t r2 = lcg_mul_lazy(RA.x, MU.y); const float x = box_muller_fast(c1, r2);
+        #define LEAN_ARITH(RA, MU) const uint32_t c1 = lcg_mul(RA.x, MU.x); const float x = box_muller_fast(c1);
 #endif
         uint4 ra, rb; uint2 ma, mb; int eva, evb;
         base_ev = 0;
@@ -925,8 +931,7 @@ __global__ __launch_bounds__(256) void k_samples(const SigParams P, const int n_
                     const uint32_t j = ((uint32_t)idx - qa.y) & (MULT_N - 1);
                     const uint2 mu = L.mult[j];
                     const uint32_t c1 = lcg_mul(qa.x, mu.x);
-                    const uint32_t r2 = lcg_mul_lazy(qa.x, mu.y);
-                    const float x = box_muller_fast(c1, r2);
+                    const float x = box_muller_fast(c1);
                     const float v = __builtin_fmaf(x, __uint_as_float(qa.w), __uint_as_float(qa.z));
                     const float fl = floorf(v);
                     const float fr = v - fl;
@@ -968,7 +973,7 @@ __global__ __launch_bounds__(256) void k_samples(const SigParams P, const int n_
                         if (j < MULT_N) c1 = lcg_mul(qa.x, L.mult[j].x);
                         else c1 = lcg_mul(lcg_mul(qa.x, lcg_jump2(P.pw, j)), LCG_A);
                         if (MODE == 1) {
-                            const float x = box_muller_fast(c1, lcg_mul_lazy(c1, LCG_A));
+                            const float x = box_muller_fast(c1);
                             const float v = __builtin_fmaf(x, __uint_as_float(qa.w), __uint_as_float(qa.z));
                             const float fl = floorf(v);
                             const float fr = v - fl;
@@ -1030,8 +1035,7 @@ __global__ __launch_bounds__(256) void k_fixup(const SigParams P) {
 }
 
 // ---- k_certify: max |x_fast - x_exact| over every state the fp32 path may accept ------------
-// The deviate is a function of c1 alone (c2 = a*c1 mod M), so the sweep is exhaustive.  Both
-// representatives of the lazily reduced second draw are tried.
+// The deviate is a function of c1 alone (c2 = a*c1 mod M), so the sweep is exhaustive.
 __global__ __launch_bounds__(256) void k_certify(unsigned int* __restrict__ max_bits) {
     float m = 0.f;
     const unsigned long long stride = (unsigned long long)gridDim.x * 256;
@@ -1039,10 +1043,9 @@ __global__ __launch_bounds__(256) void k_certify(unsigned int* __restrict__ max_
          c <= LCG_M - (1u << NEAR_ONE_BITS); c += stride) {
         const uint32_t c1 = (uint32_t)c, c2 = lcg_mul(c1, LCG_A);
         const double xe = box_muller_exact(c1, c2);
-        const float e0 = fabsf((float)((double)box_muller_fast(c1, c2) - xe));
-        const float e1 = fabsf((float)((double)box_muller_fast(c1, c2 + LCG_M) - xe));
-        m = fmaxf(m, fmaxf(e0, e1));
-        if (!(e0 == e0) || !(e1 == e1)) m = __builtin_inff();
+        const float e0 = fabsf((float)((double)box_muller_fast(c1) - xe));
+        m = fmaxf(m, e0);
+        if (!(e0 == e0)) m = __builtin_inff();
     }
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o));
     if ((threadIdx.x & 63) == 0) atomicMax(max_bits, __float_as_uint(m));
