@@ -82,9 +82,10 @@ struct sqg_batch {
     int* d_tile_read = nullptr;
     int* d_stile_read = nullptr;
     long long n_tiles = 0, n_stiles = 0;
-    long long* h_sigoff = nullptr;   // pinned
+    long long* h_sigoff = nullptr;   // pinned, device-mapped: k_scan writes it directly
+    long long* h_sigoff_dev = nullptr;   // its device-side address
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel-phase boundaries on the stream
-    bool ran = false, waited = false, lean_timed = false;
+    bool ran = false, waited = false, lean_timed = false, dwell_timed = false;
 };
 
 #define HIPCHK(ctx, call)                                                                      \
@@ -191,6 +192,7 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
 #define CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = (e_ == hipErrorOutOfMemory) ? SQG_ENOMEM : SQG_EDEVICE; fprintf(stderr, "[sqg] %s: %s\n", #call, hipGetErrorString(e_)); return fail(rc); } } while (0)
     CHK(hipSetDevice(cfg->device));
     CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+
 
     // pore model: {level_mean, (float)(level_stdv*amp_noise)}  (src/sim.c:249)
     std::vector<float2> hm((size_t)nk);
@@ -465,7 +467,8 @@ extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const 
     CHKB(hipMemcpyAsync(b->d_tile_read, tile_read.data(), tile_read.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     CHKB(hipMalloc(&b->d_chain_order, std::max<size_t>(1, chain_order.size()) * sizeof(int)));
     if (b->n_chains) CHKB(hipMemcpyAsync(b->d_chain_order, chain_order.data(), chain_order.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    CHKB(hipHostMalloc(&b->h_sigoff, ((size_t)n + 1) * sizeof(long long), hipHostMallocDefault));
+    CHKB(hipHostMalloc(&b->h_sigoff, ((size_t)n + 1) * sizeof(long long), hipHostMallocMapped));
+    CHKB(hipHostGetDevicePointer((void**)&b->h_sigoff_dev, b->h_sigoff, 0));
     for (auto& e : b->ev) CHKB(hipEventCreate(&e));
     CHKB(hipStreamSynchronize(c->stream));     // staging buffers above are stack-owned
 #undef CHKB
@@ -509,7 +512,6 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
         if ((rc = ensure(c, (void**)&c->d_tfix, &c->tfix_cap, (size_t)b->n_stiles * FIX_SLOTS + 64, sizeof(uint4)))) return rc;
         if ((rc = ensure(c, (void**)&c->d_tfix_n, &c->tfixn_cap, (size_t)b->n_stiles + 64, 1))) return rc;
         if ((rc = ensure(c, (void**)&c->d_items, &c->items_cap, (size_t)b->n_stiles + 64, sizeof(ItemDesc)))) return rc;
-        HIPCHK(c, hipMemsetAsync(c->d_tfix_n, 0, (size_t)b->n_stiles + 1, c->stream));
     }
 
     // Dwell draws are made inside k_events (SQG_SEPARATE_DWELL=1 keeps the stand-alone k_dwell for A/B runs).
@@ -555,8 +557,8 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
             HIPCHK(c, hipMemcpyAsync(c->d_seglen, b->seglen_host.data(), (size_t)2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
         }
     }
-    HIPCHK(c, hipEventRecord(b->ev[1], c->stream));
-    HIPCHK(c, hipEventRecord(b->ev[2], c->stream));
+    b->dwell_timed = c->use_dwell_stream && !inline_dwell;        // stand-alone k_dwell (A/B runs): two more timing events
+    if (b->dwell_timed) { HIPCHK(c, hipEventRecord(b->ev[1], c->stream)); HIPCHK(c, hipEventRecord(b->ev[2], c->stream)); }
     if (n > 0 && b->n_chains > 0) {
         launch_events(inline_dwell ? (certified ? 1 : 2) : 0);
         HIPCHK(c, hipGetLastError());
@@ -564,15 +566,17 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     }
     HIPCHK(c, hipEventRecord(b->ev[3], c->stream));
     if (n > 0) {
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_seglen, n, c->d_sigoff, c->d_err);
+        // the scan also writes the offsets through the batch's pinned host mapping (no copy between kernels)
+        // (k_items, when it runs, does that part with more parallelism)
+        const bool items_run = certified && c->use_kmer_streams && b->n_chains > 0 && c->dwell_hi * (double)b->n_events <= 4.0e10;
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, c->d_seglen, n, c->d_sigoff, items_run ? nullptr : b->h_sigoff_dev, c->d_err, c->d_fix_count);
         HIPCHK(c, hipGetLastError());
         if ((rc = dbg_sync(c, "k_scan"))) return rc;
-    }
+    } else HIPCHK(c, hipMemsetAsync(c->d_fix_count, 0, 4 * sizeof(unsigned int), c->stream));
     // Output size is data-dependent.  A hard bound exists (|z| <= sqrt(2 ln(2^31-1)) = 6.5546 for any
     // draw), so the slab is sized by it and the launches continue without a host round trip; only
     // if that bound is unreasonable (huge dwell spread) is the scan read back first.
-    if (n > 0) HIPCHK(c, hipMemcpyAsync(b->h_sigoff, c->d_sigoff, ((size_t)n + 1) * sizeof(long long), hipMemcpyDeviceToHost, c->stream));
-    else b->h_sigoff[0] = 0;
+    if (n == 0) b->h_sigoff[0] = 0;
     size_t need_samples;
     {
         const double hi = c->dwell_hi;
@@ -587,7 +591,6 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     if (certified && c->use_kmer_streams) {
         if ((rc = ensure(c, (void**)&c->d_fix, &c->fix_cap, (c->force_fix ? need_samples : need_samples / 256) + 65536, sizeof(FixEntry)))) return rc;
     }
-    HIPCHK(c, hipMemsetAsync(c->d_fix_count, 0, 4 * sizeof(unsigned int), c->stream));
 
     if (n > 0 && b->n_chains > 0) {
         P.sig = c->d_sig; P.fix = c->d_fix; P.fix_count = c->d_fix_count;
@@ -608,7 +611,7 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
             unsigned lgrid = (unsigned)((n_stiles + 3) / 4);
             static const int lean_grid_cap = getenv("SQG_LEAN_GRID") ? atoi(getenv("SQG_LEAN_GRID")) : 0;   // A/B knob
             if (lean_grid_cap > 0) lgrid = std::min(lgrid, (unsigned)lean_grid_cap);
-            hipLaunchKernelGGL(k_items, dim3((unsigned)((n_stiles + 255) / 256)), dim3(256), 0, c->stream, P, n_stiles);
+            hipLaunchKernelGGL(k_items, dim3((unsigned)((std::max(n_stiles, n + 1) + 255) / 256)), dim3(256), 0, c->stream, P, n_stiles, n, b->h_sigoff_dev);
             HIPCHK(c, hipEventRecord(b->ev[5], c->stream));
             if (P.rna) hipLaunchKernelGGL((k_samples_lean<true>), dim3(lgrid), dim3(256), 0, c->stream, P, n_stiles);
             else hipLaunchKernelGGL((k_samples_lean<false>), dim3(lgrid), dim3(256), 0, c->stream, P, n_stiles);
@@ -652,8 +655,8 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
             return (e & 12) ? SQG_EDEVICE : SQG_EOVERFLOW;
         }
         float d = 0, s = 0, t = 0, ee = 0;
-        HIPCHK(c, hipEventElapsedTime(&d, b->ev[0], b->ev[1]));
-        HIPCHK(c, hipEventElapsedTime(&ee, b->ev[2], b->ev[3]));
+        if (b->dwell_timed) HIPCHK(c, hipEventElapsedTime(&d, b->ev[0], b->ev[1]));
+        HIPCHK(c, hipEventElapsedTime(&ee, b->ev[b->dwell_timed ? 2 : 0], b->ev[3]));
         HIPCHK(c, hipEventElapsedTime(&s, b->ev[3], b->ev[4]));
         HIPCHK(c, hipEventElapsedTime(&t, b->ev[0], b->ev[4]));
         c->timing.events_ms = ee;

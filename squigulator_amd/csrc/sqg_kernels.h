@@ -288,33 +288,60 @@ __global__ __launch_bounds__(256) void k_dwell(const ReadDesc* __restrict__ read
 }
 
 // ---- k_scan: sig_off = exclusive scan of per-read totals (single workgroup) -----------------
+// sig_off goes to HBM for the kernels and, through the pinned host mapping, straight to the host (no D2H copy
+// between kernels): host_off is visible once the stream has been synchronised.
+#define SCAN_PER 8
 __global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restrict__ seglen, int n_reads,
-                                               long long* __restrict__ sig_off, unsigned int* __restrict__ err) {
+                                               long long* __restrict__ sig_off, long long* __restrict__ host_off,
+                                               unsigned int* __restrict__ err, unsigned int* __restrict__ counters) {
     __shared__ long long wsum[16];
-    __shared__ long long carry;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n_reads; base += 1024) {
-        const int i = base + tid;
-        long long v = 0;
-        if (i < n_reads) {
-            v = (long long)(seglen[2 * i] + seglen[2 * i + 1]);
-            if (v >= 4294967295LL) atomicOr(err, 2u);        // src/sim.c:559-562
+    if (tid < 4) counters[tid] = 0;                      // fix-up list / slow-tile list counters of this batch
+    // one pass: thread t owns reads [t*per, (t+1)*per)
+    const int per = (n_reads + 1023) / 1024;
+    const int lo = min(tid * per, n_reads), hi = min(lo + per, n_reads);
+    const ulonglong2* sl = reinterpret_cast<const ulonglong2*>(seglen);
+    long long len[SCAN_PER];
+    long long v = 0;
+    bool big = false;
+    if (per <= SCAN_PER) {                               // the usual case: all loads in flight together
+#pragma unroll
+        for (int j = 0; j < SCAN_PER; j++) {
+            ulonglong2 q = make_ulonglong2(0, 0);
+            if (lo + j < hi) q = sl[lo + j];
+            len[j] = (long long)(q.x + q.y);
+            big |= len[j] >= 4294967295LL;
+            v += len[j];
         }
-        long long x = v;
-        for (int o = 1; o < 64; o <<= 1) { long long y = __shfl_up(x, o); if (lane >= o) x += y; }
-        if (lane == 63) wsum[wid] = x;
-        __syncthreads();
-        long long woff = 0;
-        for (int w = 0; w < wid; w++) woff += wsum[w];
-        const long long c = carry;
-        if (i < n_reads) sig_off[i] = c + woff + x - v;
-        __syncthreads();
-        if (tid == 1023) carry = c + woff + x;
-        __syncthreads();
+    } else {
+        for (int i = lo; i < hi; i++) {
+            const ulonglong2 q = sl[i];
+            const long long l = (long long)(q.x + q.y);
+            big |= l >= 4294967295LL;
+            v += l;
+        }
     }
-    if (tid == 0) sig_off[n_reads] = carry;
+    if (big) atomicOr(err, 2u);                          // src/sim.c:559-562
+    long long x = v;
+    for (int o = 1; o < 64; o <<= 1) { long long y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    long long run = x - v;
+    for (int w = 0; w < wid; w++) run += wsum[w];
+    if (per <= SCAN_PER) {
+#pragma unroll
+        for (int j = 0; j < SCAN_PER; j++) {
+            if (lo + j < hi) { sig_off[lo + j] = run; if (host_off) host_off[lo + j] = run; }
+            run += len[j];
+        }
+    } else {
+        for (int i = lo; i < hi; i++) {
+            sig_off[i] = run; if (host_off) host_off[i] = run;
+            const ulonglong2 q = sl[i];
+            run += (long long)(q.x + q.y);
+        }
+    }
+    if (tid == 1023) { sig_off[n_reads] = run; if (host_off) host_off[n_reads] = run; }   // the last thread's running total is the grand total
 }
 
 // ---- k_events + k_samples ------------------------------------------------------------------
@@ -612,8 +639,9 @@ __device__ static inline void push_fix_one(const SigParams& P, long long at, uin
 // k_items: one thread per 256-event super tile.  Collapses the dependent look-ups of the lean kernel's set-up
 // (tile -> read -> tile_so / sig_off / seglen) into one record per item and decides which items the lean
 // kernel takes; the others are queued (as 64-event tiles) for k_samples<MODE, GENERIC>.
-__global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_stiles) {
+__global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_stiles, const int n_reads, long long* __restrict__ host_off) {
     const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g <= n_reads) host_off[g] = P.sig_off[g];                      // read offsets to the host through the pinned mapping
     if (g >= n_stiles) return;
     const int r = P.stile_read[g];
     const ReadDesc rd = P.reads[r];
@@ -646,6 +674,7 @@ __global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_st
     d.read = r;
     d.pad = 0;
     P.items[g] = d;
+    P.tfix_n[g] = 0;
 }
 
 struct LeanWaveLds {
@@ -1000,21 +1029,28 @@ __global__ __launch_bounds__(256) void k_samples(const SigParams P, const int n_
 // per-tile slots of the lean kernel: one thread per super tile walks its (0-8, typically 0-1) parked samples.
 // No atomics: a returning atomic per wavefront on one counter costs ~10 ns each and serialises.
 __global__ __launch_bounds__(256) void k_fixup_tiles(const SigParams P, const int n_stiles) {
+    __shared__ uint16_t work[4][64 * FIX_SLOTS];         // per wavefront: (lane of the item << 4) | slot
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= n_stiles) return;
-    const int n = (int)P.tfix_n[g];
-    if (n == 0) return;
-    const int r = P.stile_read[g];
-    const ReadDesc rd = P.reads[r];
-    const long long sig_base = P.sig_off[r];
-    for (int slot = 0; slot < n; slot++) {
-        const uint4 fe = P.tfix[(size_t)g * FIX_SLOTS + slot];
+    const int n = g < n_stiles ? (int)P.tfix_n[g] : 0;
+    // spread the wavefront's parked samples (0-8 per item, ~0.5 on average) evenly over its lanes
+    const int incl = wave_incl_scan_dpp(n);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total == 0) return;
+    for (int q = 0; q < n; q++) work[wid][incl - n + q] = (uint16_t)((lane << 4) | q);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (int w = lane; w < total; w += 64) {
+        const int code = work[wid][w];
+        const int gi = g - lane + (code >> 4), slot = code & 15;
+        const int r = P.stile_read[gi];
+        const ReadDesc rd = P.reads[r];
+        const uint4 fe = P.tfix[(size_t)gi * FIX_SLOTS + slot];
         const int e = (int)fe.z;
         const uint8_t* bp = P.bases + rd.base_off + (e < rd.ne0 ? (long long)e : (long long)rd.len0 + (e - rd.ne0));
         uint32_t rank = 0;
         for (int q = 0; q < P.k; q++) rank = (rank << 2) | base_code(bp[q]);
         const float2 md = P.model[rank];
-        P.sig[sig_base + fe.x] = sample_exact(fe.y, md.x, md.y, P.dig, P.range, rd.offset);
+        P.sig[P.sig_off[r] + fe.x] = sample_exact(fe.y, md.x, md.y, P.dig, P.range, rd.offset);
     }
 }
 
