@@ -51,6 +51,7 @@ struct sqg_ctx {
     float delta_x_measured = 0.f;
     double amp_floor = 0, amp_ceil = 0;    // min/max over k-mers of m*kd -/+ 7|sd*kd| (ADC value range before the offset)
     float thr_all = -1.f;                  // lean-kernel acceptance threshold (0.5 - largest eps over the table)
+    int lean_epl = 4;                      // events per lane of the lean kernel (work item = 64*lean_epl events)
     double dwell_hi = 1;                   // hard upper bound of a dwell draw
     bool force_fix = false;
     FixEntry* d_fix = nullptr; size_t fix_cap = 0;
@@ -264,6 +265,15 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
         const double a = std::floor(q.dwell_mean + 6.5546 * std::fabs(q.dwell_std) + 0.5);
         const double z = std::floor(std::fabs(q.dwell_mean - 6.5546 * std::fabs(q.dwell_std)) + 0.5) + 1.0;
         c->dwell_hi = c->use_dwell_stream ? std::max(std::max(a, z), 1.0) + 1.0 : (double)(int)q.dwell_mean;
+        // lean-kernel work item = 64*epl events: the largest epl whose items stay below LEAN_MAX_SAMPLES samples
+        // (mean + 6 sigma of the item total; the rare longer item is left to the generic kernel)
+        const double mu = std::fabs(q.dwell_mean) + 0.5, sg = c->use_dwell_stream ? std::fabs(q.dwell_std) : 0.0;
+        c->lean_epl = 1;
+        for (int epl = LEAN_EPL_MAX; epl >= 1; epl >>= 1) {
+            const double nev = 64.0 * epl;
+            if (nev * mu + 6.0 * std::sqrt(nev) * sg <= 0.97 * LEAN_MAX_SAMPLES) { c->lean_epl = epl; break; }
+        }
+        if (const char* ov = getenv("SQG_LEAN_EPL")) { const int v = atoi(ov); if (v == 1 || v == 2 || v == 4) c->lean_epl = v; }   // A/B knob
     }
 
     // per-(worker,k-mer) stream states
@@ -357,8 +367,9 @@ extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const 
     for (int i = 0; i < n; i++) { rd[(size_t)i].tile_off = (int)ntile; rd[(size_t)i].fast = 0; rd[(size_t)i].stile_off = 0; rd[(size_t)i].pad = 0; ntile += (rd[(size_t)i].ne0 + rd[(size_t)i].ne1 + 63) / 64; }
     if (ntile > 2000000000LL) { delete b; c->err = "batch too large"; return SQG_EINVAL; }
     b->n_tiles = ntile;
-    long long nst = 0;                                        // 256-event super tiles (work items of k_samples_lean)
-    for (int i = 0; i < n; i++) { rd[(size_t)i].stile_off = (int)nst; rd[(size_t)i].pad = 0; nst += (rd[(size_t)i].ne0 + rd[(size_t)i].ne1 + LEAN_EV - 1) / LEAN_EV; }
+    const int lean_ev = 64 * c->lean_epl;
+    long long nst = 0;                                        // super tiles of 64*lean_epl events (work items of k_samples_lean)
+    for (int i = 0; i < n; i++) { rd[(size_t)i].stile_off = (int)nst; rd[(size_t)i].pad = 0; nst += (rd[(size_t)i].ne0 + rd[(size_t)i].ne1 + lean_ev - 1) / lean_ev; }
     b->n_stiles = nst;
     std::vector<int> stile_read((size_t)std::max<long long>(nst, 1));
     for (int i = 0; i < n; i++) {
@@ -602,7 +613,7 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
             int32_t t = (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000u;
             P.shift = (int)(int16_t)(uint16_t)((uint32_t)t & 0xffffu);
         }
-        P.slow_tiles = nullptr; P.slow_count = c->d_fix_count + 1; P.tfix = c->d_tfix; P.tfix_n = c->d_tfix_n; P.items = c->d_items;
+        P.slow_tiles = nullptr; P.slow_count = c->d_fix_count + 1; P.tfix = c->d_tfix; P.tfix_n = c->d_tfix_n; P.items = c->d_items; P.lean_epl = c->lean_epl;
         const int n_tiles = (int)b->n_tiles;
         const unsigned sgrid = (unsigned)((n_tiles + 3) / 4);
         if (certified && c->use_kmer_streams) {
@@ -613,8 +624,10 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
             if (lean_grid_cap > 0) lgrid = std::min(lgrid, (unsigned)lean_grid_cap);
             hipLaunchKernelGGL(k_items, dim3((unsigned)((std::max(n_stiles, n + 1) + 255) / 256)), dim3(256), 0, c->stream, P, n_stiles, n, b->h_sigoff_dev);
             HIPCHK(c, hipEventRecord(b->ev[5], c->stream));
-            if (P.rna) hipLaunchKernelGGL((k_samples_lean<true>), dim3(lgrid), dim3(256), 0, c->stream, P, n_stiles);
-            else hipLaunchKernelGGL((k_samples_lean<false>), dim3(lgrid), dim3(256), 0, c->stream, P, n_stiles);
+#define LEANL(R, E) hipLaunchKernelGGL((k_samples_lean<R, E>), dim3(lgrid), dim3(256), 0, c->stream, P, n_stiles)
+            if (P.rna) { if (c->lean_epl == 4) LEANL(true, 4); else if (c->lean_epl == 2) LEANL(true, 2); else LEANL(true, 1); }
+            else { if (c->lean_epl == 4) LEANL(false, 4); else if (c->lean_epl == 2) LEANL(false, 2); else LEANL(false, 1); }
+#undef LEANL
             HIPCHK(c, hipEventRecord(b->ev[6], c->stream));
             b->lean_timed = true;
             if ((rc = dbg_sync(c, "k_samples_lean"))) return rc;

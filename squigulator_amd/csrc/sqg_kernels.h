@@ -175,6 +175,7 @@ struct SigParams {
     const int* tile_read;        // per tile: read index
     const int* stile_read;       // per 256-event super tile (lean kernel work item): read index
     ItemDesc* items;             // per super tile: what k_samples_lean needs, in one 48-B record
+    int lean_epl;                // events per lane of the lean kernel (4, 2 or 1): a super tile is 64*lean_epl events
     int* slow_tiles;             // tiles the lean sample kernel left to the generic one
     unsigned int* slow_count;
     uint4* tfix;                 // lean kernel: FIX_SLOTS undecided samples per tile {index in read, c1, event in read, 0}
@@ -630,8 +631,8 @@ __device__ static inline void push_fix_one(const SigParams& P, long long at, uin
     } else atomicOr(P.err, 8u);
 }
 
-#define LEAN_EPL 4                         // events per lane
-#define LEAN_EV (64 * LEAN_EPL)            // events per wavefront work item ("super tile" = 4 consecutive 64-event tiles of one read)
+#define LEAN_EPL_MAX 4                     // events per lane of the lean kernel: 4, 2 or 1 (SigParams.lean_epl, chosen per profile so
+                                           // that a work item -- 64*epl consecutive events of a read -- stays below LEAN_MAX_SAMPLES)
 #define FIX_SLOTS 8                        // parked undecided samples per super tile (expected ~0.5); overflow -> global list
 #define LEAN_MAX_SAMPLES 4096              // samples per work item the 64x64-bit start map covers
 #define LEAN_MAGIC 12582912.0f             // 1.5 * 2^23: t = v + MAGIC rounds v to the nearest integer, in the low bits of t
@@ -645,6 +646,7 @@ __global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_st
     if (g >= n_stiles) return;
     const int r = P.stile_read[g];
     const ReadDesc rd = P.reads[r];
+    const int LEAN_EPL = P.lean_epl, LEAN_EV = 64 * LEAN_EPL;
     const int lt = g - rd.stile_off;                                   // super tile within the read
     const int ne = rd.ne0 + rd.ne1;
     const int n_ev = min(LEAN_EV, ne - lt * LEAN_EV);
@@ -677,15 +679,17 @@ __global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_st
     P.tfix_n[g] = 0;
 }
 
+template <int EPL>
 struct LeanWaveLds {
-    uint4 rec[LEAN_EV];                 // {c_ev, ((8*first sample) & 0xfff) << 16 | I (16 bits), F - 1/2, sdk}
+    uint4 rec[64 * EPL];                // {c_ev, ((8*first sample) & 0xfff) << 16 | I (16 bits), F - 1/2, sdk}
     unsigned long long bm[64];          // bit s-1 set: an event (other than the item's first) starts at sample s
     int nfix;                           // undecided samples of the item so far
     int pad[3];
 };
+template <int EPL>
 struct LeanLds {
     uint2 mult[MULT_N];                 // {a^(2j+1), a^(2j+2)}
-    LeanWaveLds w[4];
+    LeanWaveLds<EPL> w[4];
 };
 
 // k_samples_lean: the hot kernel.  Certified fp32 path only, for reads whose ADC values are provably in
@@ -700,14 +704,14 @@ struct LeanLds {
 //   eps of an integer) -> acceptance test on v' - (t - 1.5*2^23) -> int16 store of the low half of bits(t) + I.
 // The loads of step i+1 are issued before the arithmetic of step i (software pipelining, two steps unrolled
 // so that the pipeline registers do not have to be copied).
-template <bool RNA>
+template <bool RNA, int LEAN_EPL>
 __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const int n_stiles) {
-    __shared__ LeanLds L;
+    __shared__ LeanLds<LEAN_EPL> L;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < MULT_N; i += 256) L.mult[i] = make_uint2(P.pw[i], P.pw[POW_N + i]);
     __syncthreads();
-    LeanWaveLds& W = L.w[wid];
+    LeanWaveLds<LEAN_EPL>& W = L.w[wid];
     const float thr = P.thr_all;
     const char* mult_b = reinterpret_cast<const char*>(L.mult);
 
@@ -728,17 +732,19 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         const int wave_total = it.n_samples;
         const int e0 = lane * LEAN_EPL;                                // my first event (within the item)
         const long long gev = it.ev_first + e0;
-        // ---- set-up: 4 consecutive events per lane ----
+        // ---- set-up: LEAN_EPL consecutive events per lane ----
         uint2 er[LEAN_EPL];
         int sps[LEAN_EPL];
         if (e0 + LEAN_EPL <= ne) {
-            const uint4 a = *reinterpret_cast<const uint4*>(P.evrec + gev);          // 8-B aligned 16-B loads
-            const uint4 b = *reinterpret_cast<const uint4*>(P.evrec + gev + 2);
-            er[0] = make_uint2(a.x, a.y); er[1] = make_uint2(a.z, a.w); er[2] = make_uint2(b.x, b.y); er[3] = make_uint2(b.z, b.w);
+            uint32_t ew[2 * LEAN_EPL];
+            __builtin_memcpy(ew, P.evrec + gev, 8 * LEAN_EPL);                        // 8-B aligned wide loads
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) er[q] = make_uint2(ew[2 * q], ew[2 * q + 1]);
             if (P.dwell) {
-                uint2 dw;
-                __builtin_memcpy(&dw, P.dwell + gev, 8);                              // 2-B aligned 8-B load
-                sps[0] = (int)(dw.x & 0xffffu); sps[1] = (int)(dw.x >> 16); sps[2] = (int)(dw.y & 0xffffu); sps[3] = (int)(dw.y >> 16);
+                uint16_t dw[LEAN_EPL];
+                __builtin_memcpy(dw, P.dwell + gev, 2 * LEAN_EPL);                    // 2-B aligned wide load
+#pragma unroll
+                for (int q = 0; q < LEAN_EPL; q++) sps[q] = (int)dw[q];
             } else {
 #pragma unroll
                 for (int q = 0; q < LEAN_EPL; q++) sps[q] = P.const_sps;
@@ -754,7 +760,9 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         float2 md[LEAN_EPL];
 #pragma unroll
         for (int q = 0; q < LEAN_EPL; q++) md[q] = (e0 + q < ne) ? P.model[er[q].y] : make_float2(0.f, 0.f);
-        const int lane_total = sps[0] + sps[1] + sps[2] + sps[3];
+        int lane_total = 0;
+#pragma unroll
+        for (int q = 0; q < LEAN_EPL; q++) lane_total += sps[q];
         const int incl = wave_incl_scan_dpp(lane_total);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // previous item's LDS reads are done
         W.bm[lane] = 0ull;
