@@ -571,7 +571,7 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     b->dwell_timed = c->use_dwell_stream && !inline_dwell;        // stand-alone k_dwell (A/B runs): two more timing events
     if (b->dwell_timed) { HIPCHK(c, hipEventRecord(b->ev[1], c->stream)); HIPCHK(c, hipEventRecord(b->ev[2], c->stream)); }
     if (n > 0 && b->n_chains > 0) {
-        launch_events(inline_dwell ? (certified ? 1 : 2) : 0);
+        launch_events(inline_dwell ? (certified && c->dwell_hi < 1.0e6 ? 1 : 2) : 0);
         HIPCHK(c, hipGetLastError());
         if ((rc = dbg_sync(c, "k_events"))) return rc;
     }

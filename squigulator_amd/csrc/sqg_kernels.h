@@ -387,6 +387,7 @@ __device__ static inline int wave_incl_scan(int v, int lane) {
     return v;
 }
 
+#define LEAN_MAGIC 12582912.0f             // 1.5 * 2^23: t = v + MAGIC rounds v to the nearest integer, in the low bits of t
 #define EV_NIL 0xffffu
 #define ROW_BUSY 0x80000000u
 #define EV_HALO 20          // 2*(k_max-1)+2 extra base codes per segment (segment-0/1 boundary)
@@ -438,18 +439,18 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
         const ReadDesc rd = P.reads[r];
         const int ne = rd.ne0 + rd.ne1;
         const uint8_t* rbases = P.bases + rd.base_off;
-        const long long nbytes = (long long)rd.len0 + rd.len1;
+        const int nbytes = rd.len0 + rd.len1;                           // <= 2^31 (checked at staging)
         // base index of event e: e in segment 0, e + (k-1) in segment 1 (the stall's k-mers do not
         // straddle the boundary, src/genread.c:87-88)
-        #define EV_BASE(e_) ((long long)(e_) + ((e_) >= rd.ne0 ? (long long)rd.len0 - rd.ne0 : 0LL))
+        #define EV_BASE(e_) ((int)(e_) + ((e_) >= rd.ne0 ? rd.len0 - rd.ne0 : 0))
         uint32_t done = 0;                                            // samples before this segment
-        uint32_t c_seg = DW ? lcg_mul(rd.time_c0, LCG_A) : 0u;        // a * (time-stream state at the segment's first event)
+        uint32_t c_seg = DW ? __builtin_amdgcn_readfirstlane(lcg_mul(rd.time_c0, LCG_A)) : 0u;   // a * (time-stream state at the segment's first event)
         if (DW && tid == 0) n1_sh = -1;
         // prefetch of segment 0: one base byte per thread (+ halo), one dwell per thread
         uint8_t b_cur = 'A', b_halo = 'A';
         uint16_t d_cur = 0;
         {
-            const long long b0 = EV_BASE(0);
+            const int b0 = EV_BASE(0);
             if (b0 + tid < nbytes) b_cur = rbases[b0 + tid];
             if (tid < EV_HALO && b0 + NT + tid < nbytes) b_halo = rbases[b0 + NT + tid];
             if (!DW && tid < ne && P.dwell) d_cur = P.dwell[rd.ev_off + tid];
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
         for (int s0 = 0; s0 < ne; s0 += NT) {
             const int e = s0 + tid;
             const bool valid = e < ne;
-            const long long bseg = EV_BASE(s0);
+            const int bseg = EV_BASE(s0);
             const uint8_t code_cur = L.lut[b_cur], code_halo = L.lut[tid < EV_HALO ? b_halo : (uint8_t)'A'];   // consumed after the dwell draw
             int sps = 0;
             if (DW == 0) {
@@ -468,10 +469,12 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
                 bool decided = false;
                 if (DW == 1) {
                     // v' = x'*s + m in fp32; round(v) = floor(v+1/2) unless v is within eps of a half-integer
+                    // round(v) is the integer nearest to v' unless v' is within eps of a half-integer
                     const float x = box_muller_fast(c1);
-                    const float g = __builtin_fmaf(x, dw_sf, dw_mf) + 0.5f;
-                    const float fl = floorf(g);
-                    if (fabsf(g - fl - 0.5f) < 0.5f - dw_eps && c1 <= LCG_M - (1u << NEAR_ONE_BITS) && fabsf(g) < 1.0e6f) { sps = (int)fl; decided = true; }
+                    const float g = __builtin_fmaf(x, dw_sf, dw_mf);
+                    const float t = g + LEAN_MAGIC;                  // |g| < 2^22: the host takes the FP64 variant (DW 2) when dwell_hi >= 1e6
+                    const float fl = t - LEAN_MAGIC;
+                    if (fabsf(g - fl) < 0.5f - dw_eps && c1 <= LCG_M - (1u << NEAR_ONE_BITS)) { sps = (int)__float_as_uint(t) - 0x4b400000; decided = true; }
                 }
                 if (!decided) sps = dwell_exact(c1, P.dstd, P.dmean);    // src/gensig.c:255
                 sps = sps < 1 ? -sps + 1 : sps;                          // src/gensig.c:256
@@ -482,18 +485,20 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
                 if (sps == 123456) P.dwell_out[rd.ev_off + e] = (uint16_t)sps;
 #endif
             }
-            if (DW) c_seg = lcg_mul(c_seg, a2nt);
+            if (DW) c_seg = __builtin_amdgcn_readfirstlane(lcg_mul(c_seg, a2nt));     // wave-uniform: scalar unit
             L.codes[tid] = code_cur;
             if (tid < EV_HALO) L.codes[NT + tid] = code_halo;
             const int incl = wave_incl_scan_dpp(sps);
             if (lane == 63) L.wsum[wid] = incl;
             if (!DIRECT && P.use_streams) for (int i = tid; i < HT; i += NT) { L.keys[i] = BIN_EMPTY; L.head[i] = EV_NIL; }
+#if !defined(SQG_ABL_NOBAR1)
             lds_barrier();                                                                    // (1)
+#endif
             int woff = 0, seg_total = 0;
             for (int w = 0; w < NW; w++) { const int x = L.wsum[w]; if (w < wid) woff += x; seg_total += x; }
             uint32_t rank = 0;
             if (valid) {
-                const int cb = (int)(EV_BASE(e) - bseg);
+                const int cb = EV_BASE(e) - bseg;
                 // src/seq.h:31-42; the usual k are unrolled so that the byte reads are in flight together
                 #define EV_RANK(K_) { _Pragma("unroll") for (int i = 0; i < K_; i++) rank = (rank << 2) | L.codes[cb + i]; }
                 switch (k) {
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
             {
                 const int s1 = s0 + NT;
                 if (s1 < ne) {
-                    const long long b1 = EV_BASE(s1);
+                    const int b1 = EV_BASE(s1);
                     b_cur = (b1 + tid < nbytes) ? rbases[b1 + tid] : (uint8_t)'A';
                     if (tid < EV_HALO) b_halo = (b1 + NT + tid < nbytes) ? rbases[b1 + NT + tid] : (uint8_t)'A';
                     if (!DW && s1 + tid < ne && P.dwell) d_cur = P.dwell[rd.ev_off + s1 + tid];
@@ -635,7 +640,6 @@ __device__ static inline void push_fix_one(const SigParams& P, long long at, uin
                                            // that a work item -- 64*epl consecutive events of a read -- stays below LEAN_MAX_SAMPLES)
 #define FIX_SLOTS 8                        // parked undecided samples per super tile (expected ~0.5); overflow -> global list
 #define LEAN_MAX_SAMPLES 4096              // samples per work item the 64x64-bit start map covers
-#define LEAN_MAGIC 12582912.0f             // 1.5 * 2^23: t = v + MAGIC rounds v to the nearest integer, in the low bits of t
 
 // k_items: one thread per 256-event super tile.  Collapses the dependent look-ups of the lean kernel's set-up
 // (tile -> read -> tile_so / sig_off / seglen) into one record per item and decides which items the lean
