@@ -544,7 +544,7 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     auto launch_events = [&](int dw) {
         const dim3 g((unsigned)b->n_chains), t(NT);
         const bool direct = c->k <= 6;
-#define EVL(D, W) hipLaunchKernelGGL((k_events<NT, D, W>), g, t, 0, c->stream, P)
+#define EVL(D, W) hipLaunchKernelGGL((k_events<NT, D, W, SQG_EVENT_EPT>), g, t, 0, c->stream, P)
         if (direct) { if (dw == 0) EVL(true, 0); else if (dw == 1) EVL(true, 1); else EVL(true, 2); }
         else { if (dw == 0) EVL(false, 0); else if (dw == 1) EVL(false, 1); else EVL(false, 2); }
 #undef EVL

@@ -364,8 +364,11 @@ __global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restr
 #ifndef SQG_EVENT_THREADS
 #define SQG_EVENT_THREADS 256
 #endif
+#ifndef SQG_EVENT_EPT
+#define SQG_EVENT_EPT 2     // consecutive events per thread of k_events (segment = SQG_EVENT_THREADS * SQG_EVENT_EPT events)
+#endif
 #ifndef SQG_EVENT_WAVES
-#define SQG_EVENT_WAVES 7   // waves per SIMD the register allocation of k_events aims at (LDS allows 7 workgroups per CU)
+#define SQG_EVENT_WAVES 6   // waves per SIMD the register allocation of k_events aims at (LDS allows 7 workgroups per CU)
 #endif
 #define MK_W 1024          // marker window (samples) per wavefront
 #define MULT_N 512         // LDS jump constants cover events of up to 512 samples
@@ -392,17 +395,19 @@ __device__ static inline int wave_incl_scan(int v, int lane) {
 #define ROW_BUSY 0x80000000u
 #define EV_HALO 20          // 2*(k_max-1)+2 extra base codes per segment (segment-0/1 boundary)
 
-// DIRECT (k <= 6): one bin per k-mer rank, no keys, no probing; otherwise an open-addressing hash of 2*NT bins
-template <int NT, bool DIRECT>
+// DIRECT (k <= 6): one bin per k-mer rank, no keys, no probing; otherwise an open-addressing hash of 2*SEG bins.
+// A segment is SEG = NT*EPT consecutive events of a read, EPT consecutive events per thread.
+template <int NT, bool DIRECT, int EPT>
 struct EvLds {
-    uint32_t keys[DIRECT ? 1 : 2 * NT];      // hash bins: k-mer rank
-    uint32_t head[DIRECT ? 1 : 2 * NT];      // hash bin -> most recently inserted event of the segment (EV_NIL: none)
+    static constexpr int SEG = NT * EPT;
+    uint32_t keys[DIRECT ? 1 : 2 * SEG];     // hash bins: k-mer rank
+    uint32_t head[DIRECT ? 1 : 2 * SEG];     // hash bin -> most recently inserted event of the segment (EV_NIL: none)
     uint32_t row[DIRECT ? 4096 : 1];         // DIRECT: the worker's stream states, resident for the whole chain; while a segment
                                              // is being handed out, ROW_BUSY | (most recently inserted event of the bin)
-    uint32_t st[DIRECT ? NT : 1];            // DIRECT: the state the bin's first event of the segment swapped out of row[]
-    uint32_t nxt[NT];           // per event: (dwell << 16) | next event in the same bin
-    uint32_t jump[(MULT_N > NT ? MULT_N : NT)];      // a^(2j)
-    uint8_t codes[NT + EV_HALO + 4];   // 2-bit base codes of the segment
+    uint32_t st[DIRECT ? SEG : 1];           // DIRECT: the state the bin's first event of the segment swapped out of row[]
+    uint32_t nxt[SEG];          // per event: (dwell << 16) | next event in the same bin
+    uint32_t jump[(MULT_N > SEG ? MULT_N : SEG)];    // a^(2j)
+    uint8_t codes[SEG + EV_HALO + 4];  // 2-bit base codes of the segment
     uint8_t lut[256];           // base -> 2-bit code (src/seq.h:14-27)
     int wsum[NT / 64];
 };
@@ -413,24 +418,26 @@ __device__ static inline void lds_barrier() {
 }
 
 // DW: 0 = dwell comes from memory (k_dwell ran) or is constant; 1 = drawn here, certified fp32 path with
-// inline FP64 fallback; 2 = drawn here in FP64 (src/gensig.c:254-257)
-template <int NT, bool DIRECT, int DW>
+// out-of-line FP64 fallback; 2 = drawn here in FP64 (src/gensig.c:254-257)
+template <int NT, bool DIRECT, int DW, int EPT>
 __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams P) {
-    __shared__ EvLds<NT, DIRECT> L;
+    typedef EvLds<NT, DIRECT, EPT> Lds;
+    __shared__ Lds L;
     __shared__ long long n1_sh;
-    constexpr int NW = NT / 64, HT = 2 * NT;
+    constexpr int NW = NT / 64, SEG = NT * EPT, HT = 2 * SEG, TL = 64 / EPT;   // TL: lanes per 64-event tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int i = tid; i < (MULT_N > NT ? MULT_N : NT); i += NT) L.jump[i] = P.pw[2 * POW_N + i];
+    for (int i = tid; i < (MULT_N > SEG ? MULT_N : SEG); i += NT) L.jump[i] = P.pw[2 * POW_N + i];
     for (int i = tid; i < 256; i += NT) L.lut[i] = (uint8_t)base_code((uint8_t)i);
 
     const int chain = P.chain_order[blockIdx.x];
     const int c_lo = P.chain_off[chain], c_hi = P.chain_off[chain + 1];
     uint32_t* row = P.rows ? P.rows + (size_t)P.reads[P.chain_reads[c_lo]].worker * P.num_kmer : nullptr;
     const int k = P.k;
+    const uint32_t kmask = (k >= 16) ? 0xffffffffu : ((1u << (2 * k)) - 1u);
     if (DIRECT && P.use_streams) for (int i = tid; i < P.num_kmer; i += NT) L.row[i] = row[i];
-    const uint32_t a2nt = DW ? lcg_jump2(P.pw, (uint32_t)NT) : 0u;       // time-stream jump over one segment
+    const uint32_t a2nt = DW ? lcg_jump2(P.pw, (uint32_t)SEG) : 0u;      // time-stream jump over one segment
     const float dw_sf = (float)P.dstd, dw_mf = (float)P.dmean;
-    // delta_x*s (swept) + float roundings of s, m, the fma and the +1/2 (each <= 2^-24 * mag) + slack
+    // delta_x*s (swept) + float roundings of s, m and the fma (each <= 2^-24 * mag) + slack
     const float dw_eps = P.delta_x * fabsf(dw_sf) + 4.0f * 5.9604645e-8f * (fabsf(dw_mf) + 7.0f * fabsf(dw_sf) + 1.0f) + 1e-6f;
     __syncthreads();
 
@@ -446,141 +453,185 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
         uint32_t done = 0;                                            // samples before this segment
         uint32_t c_seg = DW ? __builtin_amdgcn_readfirstlane(lcg_mul(rd.time_c0, LCG_A)) : 0u;   // a * (time-stream state at the segment's first event)
         if (DW && tid == 0) n1_sh = -1;
-        // prefetch of segment 0: one base byte per thread (+ halo), one dwell per thread
-        uint8_t b_cur = 'A', b_halo = 'A';
-        uint16_t d_cur = 0;
+        // prefetch of segment 0: EPT base bytes per thread (+ halo), EPT dwells per thread
+        uint8_t b_cur[EPT], b_halo = 'A';
+        uint16_t d_cur[EPT];
         {
             const int b0 = EV_BASE(0);
-            if (b0 + tid < nbytes) b_cur = rbases[b0 + tid];
-            if (tid < EV_HALO && b0 + NT + tid < nbytes) b_halo = rbases[b0 + NT + tid];
-            if (!DW && tid < ne && P.dwell) d_cur = P.dwell[rd.ev_off + tid];
+#pragma unroll
+            for (int q = 0; q < EPT; q++) {
+                const int bi = b0 + tid * EPT + q;
+                b_cur[q] = bi < nbytes ? rbases[bi] : (uint8_t)'A';
+                d_cur[q] = (!DW && tid * EPT + q < ne && P.dwell) ? P.dwell[rd.ev_off + tid * EPT + q] : (uint16_t)0;
+            }
+            if (tid < EV_HALO && b0 + SEG + tid < nbytes) b_halo = rbases[b0 + SEG + tid];
         }
-        for (int s0 = 0; s0 < ne; s0 += NT) {
-            const int e = s0 + tid;
-            const bool valid = e < ne;
+        for (int s0 = 0; s0 < ne; s0 += SEG) {
+            const int e0 = s0 + tid * EPT;                            // my first event
             const int bseg = EV_BASE(s0);
-            const uint8_t code_cur = L.lut[b_cur], code_halo = L.lut[tid < EV_HALO ? b_halo : (uint8_t)'A'];   // consumed after the dwell draw
-            int sps = 0;
-            if (DW == 0) {
-                sps = valid ? (P.dwell ? (int)d_cur : P.const_sps) : 0;
-            } else if (valid) {
-                // event e uses draws 2e+1, 2e+2 of the worker's time stream after the read's first state
-                const uint32_t c1 = lcg_mul(c_seg, L.jump[tid]);
-                bool decided = false;
-                if (DW == 1) {
-                    // v' = x'*s + m in fp32; round(v) = floor(v+1/2) unless v is within eps of a half-integer
-                    // round(v) is the integer nearest to v' unless v' is within eps of a half-integer
-                    const float x = box_muller_fast(c1);
-                    const float g = __builtin_fmaf(x, dw_sf, dw_mf);
-                    const float t = g + LEAN_MAGIC;                  // |g| < 2^22: the host takes the FP64 variant (DW 2) when dwell_hi >= 1e6
-                    const float fl = t - LEAN_MAGIC;
-                    if (fabsf(g - fl) < 0.5f - dw_eps && c1 <= LCG_M - (1u << NEAR_ONE_BITS)) { sps = (int)__float_as_uint(t) - 0x4b400000; decided = true; }
+            uint8_t code_cur[EPT];
+#pragma unroll
+            for (int q = 0; q < EPT; q++) code_cur[q] = L.lut[b_cur[q]];                     // consumed after the dwell draw
+            const uint8_t code_halo = L.lut[tid < EV_HALO ? b_halo : (uint8_t)'A'];
+            int sps[EPT];
+#pragma unroll
+            for (int q = 0; q < EPT; q++) {
+                const int e = e0 + q;
+                const bool valid = e < ne;
+                sps[q] = 0;
+                if (DW == 0) {
+                    sps[q] = valid ? (P.dwell ? (int)d_cur[q] : P.const_sps) : 0;
+                } else if (valid) {
+                    // event e uses draws 2e+1, 2e+2 of the worker's time stream after the read's first state
+                    const uint32_t c1 = lcg_mul(c_seg, L.jump[tid * EPT + q]);
+                    bool decided = false;
+                    int v = 0;
+                    if (DW == 1) {
+                        // round(v) is the integer nearest to v' unless v' is within eps of a half-integer
+                        const float x = box_muller_fast(c1);
+                        const float g = __builtin_fmaf(x, dw_sf, dw_mf);
+                        const float t = g + LEAN_MAGIC;              // |g| < 2^22: the host takes the FP64 variant (DW 2) when dwell_hi >= 1e6
+                        const float fl = t - LEAN_MAGIC;
+                        if (fabsf(g - fl) < 0.5f - dw_eps && c1 <= LCG_M - (1u << NEAR_ONE_BITS)) { v = (int)__float_as_uint(t) - 0x4b400000; decided = true; }
+                    }
+                    if (!decided) v = dwell_exact(c1, P.dstd, P.dmean);      // src/gensig.c:255
+                    v = v < 1 ? -v + 1 : v;                                  // src/gensig.c:256
+                    if (v > 65535) { atomicOr(P.err, 1u); v = 65535; }
+                    sps[q] = v;
+                    P.dwell_out[rd.ev_off + e] = (uint16_t)v;
                 }
-                if (!decided) sps = dwell_exact(c1, P.dstd, P.dmean);    // src/gensig.c:255
-                sps = sps < 1 ? -sps + 1 : sps;                          // src/gensig.c:256
-                if (sps > 65535) { atomicOr(P.err, 1u); sps = 65535; }
-#if !defined(SQG_ABL_EV_NOSTORE)
-                P.dwell_out[rd.ev_off + e] = (uint16_t)sps;
-#else
-                if (sps == 123456) P.dwell_out[rd.ev_off + e] = (uint16_t)sps;
-#endif
             }
             if (DW) c_seg = __builtin_amdgcn_readfirstlane(lcg_mul(c_seg, a2nt));     // wave-uniform: scalar unit
-            L.codes[tid] = code_cur;
-            if (tid < EV_HALO) L.codes[NT + tid] = code_halo;
-            const int incl = wave_incl_scan_dpp(sps);
+#pragma unroll
+            for (int q = 0; q < EPT; q++) L.codes[tid * EPT + q] = code_cur[q];
+            if (tid < EV_HALO) L.codes[SEG + tid] = code_halo;
+            int lane_total = 0;
+#pragma unroll
+            for (int q = 0; q < EPT; q++) lane_total += sps[q];
+            const int incl = wave_incl_scan_dpp(lane_total);
             if (lane == 63) L.wsum[wid] = incl;
             if (!DIRECT && P.use_streams) for (int i = tid; i < HT; i += NT) { L.keys[i] = BIN_EMPTY; L.head[i] = EV_NIL; }
-#if !defined(SQG_ABL_NOBAR1)
             lds_barrier();                                                                    // (1)
-#endif
             int woff = 0, seg_total = 0;
             for (int w = 0; w < NW; w++) { const int x = L.wsum[w]; if (w < wid) woff += x; seg_total += x; }
-            uint32_t rank = 0;
-            if (valid) {
-                const int cb = EV_BASE(e) - bseg;
-                // src/seq.h:31-42; the usual k are unrolled so that the byte reads are in flight together
-                #define EV_RANK(K_) { _Pragma("unroll") for (int i = 0; i < K_; i++) rank = (rank << 2) | L.codes[cb + i]; }
-                switch (k) {
-                case 6: EV_RANK(6) break;
-                case 9: EV_RANK(9) break;
-                case 5: EV_RANK(5) break;
-                default: for (int i = 0; i < k; i++) rank = (rank << 2) | L.codes[cb + i];
-                }
-                #undef EV_RANK
-            }
-            uint32_t h = DIRECT ? rank : (rank * 2654435761u) >> (32 - (31 - __builtin_clz(HT)));
-            uint32_t swapped = 0;                                      // DIRECT: what my exchange found in row[rank]
-            if (P.use_streams && valid) {
-                if (DIRECT) {
-                    // the bin's members chain through row[rank]; the first one of the segment takes the state out
-                    swapped = atomicExch(&L.row[rank], ROW_BUSY | (uint32_t)tid);
-                    L.nxt[tid] = ((uint32_t)sps << 16) | ((swapped & ROW_BUSY) ? (swapped & 0xffffu) : EV_NIL);
-                    if (!(swapped & ROW_BUSY)) L.st[tid] = swapped;
-                } else {
-                    for (;;) {
-                        const uint32_t old = atomicCAS(&L.keys[h], BIN_EMPTY, rank);
-                        if (old == BIN_EMPTY || old == rank) break;
-                        h = (h + 1) & (HT - 1);
+            const int lane_excl = woff + incl - lane_total;           // samples of this segment before my first event
+            uint32_t rank[EPT], h[EPT], swapped[EPT], my_prev[EPT];   // my_prev: the event inserted into my bin just before me
+#pragma unroll
+            for (int q = 0; q < EPT; q++) {
+                const int e = e0 + q;
+                rank[q] = 0; swapped[q] = 0; my_prev[q] = EV_NIL;
+                if (e < ne) {
+                    const int cb = EV_BASE(e) - bseg;
+                    if (q > 0 && e != rd.ne0) {
+                        rank[q] = ((rank[q - 1] << 2) | L.codes[cb + k - 1]) & kmask;          // my previous event's k-mer, shifted by one base
+                    } else {
+                        // src/seq.h:31-42; the usual k are unrolled so that the byte reads are in flight together
+                        uint32_t rk = 0;
+                        #define EV_RANK(K_) { _Pragma("unroll") for (int i = 0; i < K_; i++) rk = (rk << 2) | L.codes[cb + i]; }
+                        switch (k) {
+                        case 6: EV_RANK(6) break;
+                        case 9: EV_RANK(9) break;
+                        case 5: EV_RANK(5) break;
+                        default: for (int i = 0; i < k; i++) rk = (rk << 2) | L.codes[cb + i];
+                        }
+                        #undef EV_RANK
+                        rank[q] = rk;
                     }
-                    const uint32_t prev = atomicExch(&L.head[h], (uint32_t)tid);
-                    L.nxt[tid] = ((uint32_t)sps << 16) | prev;
+                }
+                h[q] = DIRECT ? rank[q] : (rank[q] * 2654435761u) >> (32 - (31 - __builtin_clz(HT)));
+                if (P.use_streams && e < ne) {
+                    const uint32_t id = (uint32_t)(tid * EPT + q);    // event within the segment, in event order
+                    if (DIRECT) {
+                        // the bin's members chain through row[rank]; the first one of the segment takes the state out
+                        swapped[q] = atomicExch(&L.row[rank[q]], ROW_BUSY | id);
+                        if (swapped[q] & ROW_BUSY) my_prev[q] = swapped[q] & 0xffffu; else L.st[id] = swapped[q];
+                        L.nxt[id] = ((uint32_t)sps[q] << 16) | my_prev[q];
+                    } else {
+                        for (;;) {
+                            const uint32_t old = atomicCAS(&L.keys[h[q]], BIN_EMPTY, rank[q]);
+                            if (old == BIN_EMPTY || old == rank[q]) break;
+                            h[q] = (h[q] + 1) & (HT - 1);
+                        }
+                        my_prev[q] = atomicExch(&L.head[h[q]], id);
+                        L.nxt[id] = ((uint32_t)sps[q] << 16) | my_prev[q];
+                    }
                 }
             }
             if (DIRECT) lds_barrier(); else __syncthreads();                                  // (2) global rows: + earlier row stores have landed
             // prefetch the next segment's inputs; they land while this segment waits for its states
             {
-                const int s1 = s0 + NT;
+                const int s1 = s0 + SEG;
                 if (s1 < ne) {
                     const int b1 = EV_BASE(s1);
-                    b_cur = (b1 + tid < nbytes) ? rbases[b1 + tid] : (uint8_t)'A';
-                    if (tid < EV_HALO) b_halo = (b1 + NT + tid < nbytes) ? rbases[b1 + NT + tid] : (uint8_t)'A';
-                    if (!DW && s1 + tid < ne && P.dwell) d_cur = P.dwell[rd.ev_off + s1 + tid];
+#pragma unroll
+                    for (int q = 0; q < EPT; q++) {
+                        const int bi = b1 + tid * EPT + q;
+                        b_cur[q] = bi < nbytes ? rbases[bi] : (uint8_t)'A';
+                        if (!DW && s1 + tid * EPT + q < ne && P.dwell) d_cur[q] = P.dwell[rd.ev_off + s1 + tid * EPT + q];
+                    }
+                    if (tid < EV_HALO) b_halo = (b1 + SEG + tid < nbytes) ? rbases[b1 + SEG + tid] : (uint8_t)'A';
                 }
             }
-            if (lane == 0 && s0 + wid * 64 < ne) P.tile_so[rd.tile_off + (s0 >> 6) + wid] = done + (uint32_t)woff;
-            if (DW && valid && e == rd.ne0) n1_sh = (long long)done + woff + incl - sps;      // samples of segment 0
-            uint32_t c_ev = 0;
+            // first sample of every 64-event tile (TL lanes) within the read
+            if ((lane & (TL - 1)) == 0 && e0 < ne) P.tile_so[rd.tile_off + (e0 >> 6)] = done + (uint32_t)lane_excl;
+            uint32_t c_ev[EPT];
+            {
+                int run = lane_excl;
+#pragma unroll
+                for (int q = 0; q < EPT; q++) {
+                    if (DW && e0 + q < ne && e0 + q == rd.ne0) n1_sh = (long long)done + run;   // samples of segment 0
+                    run += sps[q];
+                    c_ev[q] = 0;
+                }
+            }
             if (P.use_streams) {
                 // dwell drawn from my k-mer's stream by earlier events of this segment, by all of them,
                 // and whether I am the last one (who stores the advanced state)
-                uint32_t prior = 0, total = 0;
-                bool last = true;
-                uint32_t c_row = 0;
-                if (valid) {
-                    uint32_t t;
-                    if (DIRECT) {
-                        c_row = swapped;                                                     // the state itself if I was first
-                        t = L.row[rank] & 0xffffu;                                           // most recently inserted event
-                        if (t == (uint32_t)tid && !(swapped & ROW_BUSY)) { total = (uint32_t)sps; t = EV_NIL; }   // alone in the bin
-                    } else {
-                        c_row = __builtin_nontemporal_load(&row[rank]);                      // global: L2-served (bypasses the CU's L1)
-                        t = L.head[h];
-                    }
-                    while (t != EV_NIL) {
-                        const uint32_t v = L.nxt[t];
-                        const uint32_t s2 = v >> 16;
-                        total += s2;
-                        if (t < (uint32_t)tid) prior += s2;
-                        if (t > (uint32_t)tid) last = false;
-                        if (DIRECT && (v & 0xffffu) == EV_NIL && t != (uint32_t)tid) c_row = L.st[t];   // the first one holds the state
-                        t = v & 0xffffu;
+                // the bin's FIRST event (prior == 0) stores the advanced state, so that every event has exactly one
+                // modular multiplication: a^(2*prior) for its own state, or a^(2*total) for the bin's next state
+                uint32_t prior[EPT], total[EPT], c_row[EPT];
+                bool first[EPT];
+#pragma unroll
+                for (int q = 0; q < EPT; q++) {
+                    prior[q] = 0; total[q] = (uint32_t)sps[q]; c_row[q] = 0; first[q] = true;
+                    if (e0 + q < ne) {
+                        const uint32_t id = (uint32_t)(tid * EPT + q);
+                        // walk the bin's other members (bins hold 1-3 events; alone: no iteration)
+                        uint32_t t;
+                        if (DIRECT) {
+                            c_row[q] = swapped[q];                                           // the state itself if I was first to exchange
+                            t = L.row[rank[q]] & 0xffffu;                                    // most recently inserted event
+                        } else {
+                            c_row[q] = __builtin_nontemporal_load(&row[rank[q]]);            // global: L2-served (bypasses the CU's L1)
+                            t = L.head[h[q]];
+                        }
+                        if (t == id) t = my_prev[q];
+                        while (t != EV_NIL) {
+                            const uint32_t v = L.nxt[t];
+                            const uint32_t s2 = v >> 16, nx = v & 0xffffu;
+                            total[q] += s2;
+                            if (t < id) { prior[q] += s2; first[q] = false; }
+                            if (DIRECT && nx == EV_NIL) c_row[q] = L.st[t];                   // the first to exchange holds the state
+                            t = (nx == id) ? my_prev[q] : nx;
+                        }
                     }
                 }
                 if (DIRECT) lds_barrier(); else __syncthreads();                                // (3) every state read before any is advanced
-                if (valid) {
-                    c_ev = prior ? lcg_mul(c_row, prior < MULT_N ? L.jump[prior] : lcg_jump2(P.pw, prior)) : c_row;
-                    if (last) {
-                        const uint32_t nv = lcg_mul(c_row, total < MULT_N ? L.jump[total] : lcg_jump2(P.pw, total));
-                        if (DIRECT) L.row[rank] = nv; else row[rank] = nv;                     // global: plain store, merged in L2
+#pragma unroll
+                for (int q = 0; q < EPT; q++) {
+                    if (e0 + q < ne) {
+                        const uint32_t n = first[q] ? total[q] : prior[q];                      // > 0: every event has >= 1 sample
+                        const uint32_t m = lcg_mul(c_row[q], n < MULT_N ? L.jump[n] : lcg_jump2(P.pw, n));
+                        if (first[q]) {
+                            c_ev[q] = c_row[q];
+                            if (DIRECT) L.row[rank[q]] = m; else row[rank[q]] = m;               // global: plain store, merged in L2
+                        } else c_ev[q] = m;
                     }
                 }
             }
-#if !defined(SQG_ABL_EV_NOSTORE)
-            if (valid) P.evrec[rd.ev_off + e] = make_uint2(c_ev, rank);
-#else
-            if (valid && c_ev == 0x7fffffffu) P.evrec[rd.ev_off + e] = make_uint2(c_ev, rank);
-#endif
+#pragma unroll
+            for (int q = 0; q < EPT; q++)
+                if (e0 + q < ne) P.evrec[rd.ev_off + e0 + q] = make_uint2(c_ev[q], rank[q]);
             done += (uint32_t)seg_total;
             // no barrier here: every LDS structure rewritten at the top of the next segment (codes, wsum, bins) was last
             // read before barrier (2)/(3) of this one, which every thread has passed
