@@ -312,10 +312,13 @@ def main():
         if not args.no_store_probe:
             out["roofline"]["measured_store_peak_GBps"] = gen.probe_store_bandwidth(1 << 30, 10) / 1e9
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(prof, flags, k, mean, stdv, genome, args.rlen)
+            # the reference's own gensig.c/genread.c (oracle/_ref, kind "reference") when the harness travelled with the
+            # repo, else the oracle restatement (kind "port"); the other one is reported next to it
+            port = cpu_baseline(prof, flags, k, mean, stdv, genome, args.rlen)
             ref = cpu_reference(prof, flags, k, mean, stdv, nproc=min(os.cpu_count() or 1, 128), reads_per_proc=150)
+            out["cpu_baseline"] = ref or port
             if ref:
-                out["cpu_reference"] = ref
+                out["cpu_port"] = port
         print(json.dumps(out))
     for b in batches:
         b.free()

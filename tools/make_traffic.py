@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch from the FETCH_SIZE / WRITE_SIZE passes of tools/prof_pmc.sh.
+usage: python tools/make_traffic.py gpurun_out/r01 profiles/r01 [workload_key]
+Writes <dst>_traffic.json and profiles/traffic_latest.json (read by bench.py's roofline.traffic).
+Units: both counters are KiB; FETCH_SIZE is doubled (gfx950 correction, MI355X_MICROARCH.md, HBM section);
+WRITE_SIZE is calibrated in the same pass on k_store_probe, which writes exactly 1 GiB per launch."""
+import collections
+import csv
+import json
+import os
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+key = sys.argv[3] if len(sys.argv) > 3 else "dna-r9-prom|batch_reads=8192|rlen=10000|mode=certified"
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f, name in (("pmc4", "FETCH_SIZE"), ("pmc5", "WRITE_SIZE")):
+    path = os.path.join(src, f + "_counter_collection.csv")
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == name:
+            acc[r["Kernel_Name"]][name].append(float(r["Counter_Value"]))
+out = {"round": 1, "workload_key": key,
+       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/prof_pmc.sh); unit KiB; "
+                 "FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM); WRITE_SIZE checked on "
+                 "k_store_probe (1 GiB written per launch)",
+       "kernels": {}}
+for kn, d in acc.items():
+    short = kn.split("(")[0].split("<")[0].replace("void ", "").strip()
+    if not short.startswith("k_"):
+        continue
+    f = sum(d.get("FETCH_SIZE", [0])) / max(len(d.get("FETCH_SIZE", [0])), 1)
+    w = sum(d.get("WRITE_SIZE", [0])) / max(len(d.get("WRITE_SIZE", [0])), 1)
+    out["kernels"][short] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}
+for path in (dst + "_traffic.json", os.path.join(os.path.dirname(dst) or ".", "traffic_latest.json")):
+    json.dump(out, open(path, "w"), indent=1)
+print(json.dumps(out["kernels"], indent=1))
