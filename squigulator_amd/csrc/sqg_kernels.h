@@ -17,6 +17,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 #define LCG_M 2147483647u
@@ -466,7 +467,11 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
             }
             if (tid < EV_HALO && b0 + SEG + tid < nbytes) b_halo = rbases[b0 + SEG + tid];
         }
-        for (int s0 = 0; s0 < ne; s0 += SEG) {
+        // One segment.  FULL: every event of the segment exists (all but a read's last segment) -- the per-lane
+        // validity tests, and the exec-mask juggling they cost on the scalar unit, are compiled out.
+        #define EV_IN(e_) (FULL || (e_) < ne)
+        auto segment = [&](auto full_tag, const int s0) {
+            constexpr bool FULL = decltype(full_tag)::value;
             const int e0 = s0 + tid * EPT;                            // my first event
             const int bseg = EV_BASE(s0);
             uint8_t code_cur[EPT];
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
 #pragma unroll
             for (int q = 0; q < EPT; q++) {
                 const int e = e0 + q;
-                const bool valid = e < ne;
+                const bool valid = EV_IN(e);
                 sps[q] = 0;
                 if (DW == 0) {
                     sps[q] = valid ? (P.dwell ? (int)d_cur[q] : P.const_sps) : 0;
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
             for (int q = 0; q < EPT; q++) {
                 const int e = e0 + q;
                 rank[q] = 0; swapped[q] = 0; my_prev[q] = EV_NIL;
-                if (e < ne) {
+                if (EV_IN(e)) {
                     const int cb = EV_BASE(e) - bseg;
                     if (q > 0 && e != rd.ne0) {
                         rank[q] = ((rank[q - 1] << 2) | L.codes[cb + k - 1]) & kmask;          // my previous event's k-mer, shifted by one base
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
                     }
                 }
                 h[q] = DIRECT ? rank[q] : (rank[q] * 2654435761u) >> (32 - (31 - __builtin_clz(HT)));
-                if (P.use_streams && e < ne) {
+                if (P.use_streams && EV_IN(e)) {
                     const uint32_t id = (uint32_t)(tid * EPT + q);    // event within the segment, in event order
                     if (DIRECT) {
                         // the bin's members chain through row[rank]; the first one of the segment takes the state out
@@ -573,13 +578,13 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
                 }
             }
             // first sample of every 64-event tile (TL lanes) within the read
-            if ((lane & (TL - 1)) == 0 && e0 < ne) P.tile_so[rd.tile_off + (e0 >> 6)] = done + (uint32_t)lane_excl;
+            if ((lane & (TL - 1)) == 0 && EV_IN(e0)) P.tile_so[rd.tile_off + (e0 >> 6)] = done + (uint32_t)lane_excl;
             uint32_t c_ev[EPT];
             {
                 int run = lane_excl;
 #pragma unroll
                 for (int q = 0; q < EPT; q++) {
-                    if (DW && e0 + q < ne && e0 + q == rd.ne0) n1_sh = (long long)done + run;   // samples of segment 0
+                    if (DW && EV_IN(e0 + q) && e0 + q == rd.ne0) n1_sh = (long long)done + run;   // samples of segment 0
                     run += sps[q];
                     c_ev[q] = 0;
                 }
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
 #pragma unroll
                 for (int q = 0; q < EPT; q++) {
                     prior[q] = 0; total[q] = (uint32_t)sps[q]; c_row[q] = 0; first[q] = true;
-                    if (e0 + q < ne) {
+                    if (EV_IN(e0 + q)) {
                         const uint32_t id = (uint32_t)(tid * EPT + q);
                         // walk the bin's other members (bins hold 1-3 events; alone: no iteration)
                         uint32_t t;
@@ -619,7 +624,7 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
                 if (DIRECT) lds_barrier(); else __syncthreads();                                // (3) every state read before any is advanced
 #pragma unroll
                 for (int q = 0; q < EPT; q++) {
-                    if (e0 + q < ne) {
+                    if (EV_IN(e0 + q)) {
                         const uint32_t n = first[q] ? total[q] : prior[q];                      // > 0: every event has >= 1 sample
                         const uint32_t m = lcg_mul(c_row[q], n < MULT_N ? L.jump[n] : lcg_jump2(P.pw, n));
                         if (first[q]) {
@@ -631,10 +636,14 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
             }
 #pragma unroll
             for (int q = 0; q < EPT; q++)
-                if (e0 + q < ne) P.evrec[rd.ev_off + e0 + q] = make_uint2(c_ev[q], rank[q]);
+                if (EV_IN(e0 + q)) P.evrec[rd.ev_off + e0 + q] = make_uint2(c_ev[q], rank[q]);
             done += (uint32_t)seg_total;
             // no barrier here: every LDS structure rewritten at the top of the next segment (codes, wsum, bins) was last
             // read before barrier (2)/(3) of this one, which every thread has passed
+        };
+        #undef EV_IN
+        for (int s0 = 0; s0 < ne; s0 += SEG) {
+            if (s0 + SEG <= ne) segment(std::true_type{}, s0); else segment(std::false_type{}, s0);
         }
         #undef EV_BASE
         __syncthreads();                                // the chain's next read starts with this read's stores landed
