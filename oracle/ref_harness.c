@@ -39,6 +39,8 @@ void set_record_aux_fields(slow5_rec_t *rec, slow5_file_t *sp, double median_bef
 
 typedef struct {
     char fasta[4096], model[4096], out[4096], slow5[4096], fasta_out[4096], paf[4096], sam[4096], trans_count[4096];
+    char svb_out[4096];      /* per read: int64 nbytes + slow5lib's own svb-zd encoding of the raw signal */
+    char svb_in[4096];       /* stand-alone mode: int32 n, then n x (int64 len, int16[len]) -> svb_out in the same framing */
     profile_t p;
     uint32_t flags;
     float amp_noise;
@@ -60,7 +62,7 @@ static void parse_cfg(const char *path, cfg_t *c) {
         const char *k = line;
 #define STR(name) if (!strcmp(k, #name)) { strncpy(c->name, v, sizeof c->name - 1); continue; }
 #define DBL(name) if (!strcmp(k, #name)) { c->p.name = strtod(v, NULL); continue; }
-        STR(fasta) STR(model) STR(out) STR(slow5) STR(fasta_out) STR(paf) STR(sam) STR(trans_count)
+        STR(fasta) STR(model) STR(out) STR(slow5) STR(fasta_out) STR(paf) STR(sam) STR(trans_count) STR(svb_out) STR(svb_in)
         DBL(digitisation) DBL(sample_rate) DBL(bps) DBL(range) DBL(offset_mean) DBL(offset_std)
         DBL(median_before_mean) DBL(median_before_std) DBL(dwell_mean) DBL(dwell_std)
         if (!strcmp(k, "flags")) { c->flags = (uint32_t)strtoul(v, NULL, 0); continue; }
@@ -126,6 +128,27 @@ int main(int argc, char **argv) {
     cfg_t cfg; parse_cfg(argv[1], &cfg);
     set_log_level(LOG_ERR);
 
+    if (cfg.svb_in[0]) {         /* compress arbitrary int16 arrays with the library's svb-zd coder, nothing else */
+        FILE *fi = fopen(cfg.svb_in, "rb"), *fo = fopen(cfg.svb_out, "wb");
+        if (!fi || !fo) { perror("svb_in/svb_out"); return 2; }
+        int32_t na = 0;
+        if (fread(&na, 4, 1, fi) != 1) return 2;
+        for (int32_t a = 0; a < na; a++) {
+            int64_t len = 0;
+            if (fread(&len, 8, 1, fi) != 1) return 2;
+            int16_t *buf = malloc((size_t)(len > 0 ? len : 1) * sizeof *buf);
+            if (len && fread(buf, 2, (size_t)len, fi) != (size_t)len) return 2;
+            size_t nb = 0;
+            void *z = slow5_ptr_compress_solo(SLOW5_COMPRESS_SVB_ZD, buf, (size_t)len * sizeof *buf, &nb);
+            if (!z) { fprintf(stderr, "svb-zd failed\n"); return 2; }
+            int64_t nb64 = (int64_t)nb;
+            put(fo, &nb64, 8); put(fo, z, nb);
+            free(z); free(buf);
+        }
+        fclose(fi); fclose(fo);
+        return 0;
+    }
+
     core_t *core = calloc(1, sizeof *core);
     core->opt.rlen = (int32_t)cfg.rlen; core->opt.seed = cfg.seed; core->opt.flag = cfg.flags;
     core->opt.num_thread = (int32_t)cfg.threads; core->opt.batch_size = (int32_t)cfg.batch;
@@ -141,6 +164,7 @@ int main(int argc, char **argv) {
     const int8_t rna = (cfg.flags & SQ_RNA) ? 1 : 0, ont = (cfg.flags & SQ_ONT) ? 1 : 0;
     FILE *fout = cfg.out[0] ? fopen(cfg.out, "wb") : NULL;
     FILE *ffa = cfg.fasta_out[0] ? fopen(cfg.fasta_out, "w") : NULL;
+    FILE *fsvb = cfg.svb_out[0] ? fopen(cfg.svb_out, "wb") : NULL;
     FILE *fpaf = cfg.paf[0] ? fopen(cfg.paf, "w") : NULL;
     FILE *fsam = cfg.sam[0] ? fopen(cfg.sam, "w") : NULL;
     if (fsam) sam_hdr_wr(fsam, core->ref);
@@ -195,6 +219,14 @@ int main(int argc, char **argv) {
                 put(fout, sig, (size_t)len * 2);
                 put(fout, aln->ss, (size_t)ssn * 4);
             }
+            if (fsvb) {      /* the library's signal compression as slow5_rec_to_mem applies it (slow5_press.c:317,1055) */
+                size_t nb_svb = 0;
+                void *z = slow5_ptr_compress_solo(SLOW5_COMPRESS_SVB_ZD, sig, (size_t)len * sizeof *sig, &nb_svb);
+                if (!z) { fprintf(stderr, "svb-zd failed\n"); return 2; }
+                int64_t nb64 = (int64_t)nb_svb;
+                put(fsvb, &nb64, 8); put(fsvb, z, nb_svb);
+                free(z);
+            }
             if (ffa) fprintf(ffa, ">%s\n%s\n", read_id, seq);
             if (fpaf || fsam) {
                 const int64_t nk = rlen - core->kmer_size + 1;
@@ -231,6 +263,7 @@ int main(int argc, char **argv) {
     if (sp) slow5_close(sp);
     if (fout) fclose(fout);
     if (ffa) fclose(ffa);
+    if (fsvb) fclose(fsvb);
     if (fpaf) fclose(fpaf);
     if (fsam) fclose(fsam);
     return 0;

@@ -648,3 +648,35 @@ void orc_batch_free(orc_batch_t *b) {
     for (int32_t i = 0; i < b->n; i++) { free(b->reads[i].seq); free(b->reads[i].raw_signal); free(b->reads[i].ss); }
     free(b->reads); free(b);
 }
+
+/* ------------------------------------------------------------------ */
+/* svb-zd (slow5lib's signal compression), "next" row                   */
+/* ------------------------------------------------------------------ */
+
+/* streamvbyte.h: __slow5_streamvbyte_max_compressedbytes = key bytes + 4 per value; + the count word of
+ * slow5_press.c:1040 */
+size_t orc_svb_zd_bound(int64_t n) {
+    return sizeof(uint32_t) + (size_t)((n + 3) / 4) + 4 * (size_t)n;
+}
+
+/* slow5_press.c:1055-1087 -> streamvbyte_zigzag.c (delta, zig-zag) -> streamvbyte_encode.c (scalar coder;
+ * the SSSE3/NEON coders produce the same bytes) */
+size_t orc_svb_zd(const int16_t *sig, int64_t n, uint8_t *out) {
+    const uint32_t count = (uint32_t)n;
+    memcpy(out, &count, sizeof count);                               /* slow5_press.c:1047 */
+    uint8_t *key = out + sizeof count;
+    uint8_t *data = key + (count + 3) / 4;
+    int32_t prev = 0;
+    uint8_t kb = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        const int32_t v = (int32_t)sig[i] - prev;                    /* zigzag_delta_encode */
+        prev = sig[i];
+        const uint32_t z = ((uint32_t)v + (uint32_t)v) ^ (uint32_t)(v >> 31);
+        const unsigned code = z < (1u << 8) ? 0 : z < (1u << 16) ? 1 : z < (1u << 24) ? 2 : 3;
+        for (unsigned b = 0; b <= code; b++) *data++ = (uint8_t)(z >> (8 * b));    /* little endian */
+        kb |= (uint8_t)(code << (2 * (i & 3)));
+        if ((i & 3) == 3) { *key++ = kb; kb = 0; }
+    }
+    if (count & 3) *key = kb;                                        /* the last, partial key byte */
+    return (size_t)(data - out);
+}

@@ -173,6 +173,15 @@ orc_batch_t *orc_batch_run_assigned(orc_core_t *c, int32_t n_rec, const char *co
                                     const int32_t *lens, const int32_t *workers, int want_ss);
 void     orc_batch_free(orc_batch_t *b);
 
+/* ---- "next" row: the signal compression slow5lib applies to raw_signal in BLOW5 (svb-zd) ----
+ * slow5lib/src/slow5_press.c:1055-1087 (ptr_compress_svb_zd): int16 -> int32, zig-zag of the delta to the
+ * previous sample (first: to 0; thirdparty/streamvbyte/src/streamvbyte_zigzag.c), then StreamVByte
+ * (thirdparty/streamvbyte/src/streamvbyte_encode.c): uint32 count | ceil(count/4) key bytes (2 bits per value =
+ * bytes-1, first value in the low bits) | the values' 1-4 little-endian bytes.
+ * orc_svb_zd_bound: bytes the output can need; orc_svb_zd: encodes, returns the bytes written. */
+size_t   orc_svb_zd_bound(int64_t n_samples);
+size_t   orc_svb_zd(const int16_t *sig, int64_t n_samples, uint8_t *out);
+
 /* worker id of read i in a batch of n_rec under -t T (src/thread.c:80-99,122-125) */
 int32_t  orc_worker_of(int32_t i, int32_t n_rec, int32_t T);
 

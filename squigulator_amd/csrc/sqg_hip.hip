@@ -279,7 +279,12 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     // per-(worker,k-mer) stream states
     if (c->use_kmer_streams) {
         const long long total = (long long)c->nw * nk;
-        CHK(hipMalloc(&c->d_rows, (size_t)total * sizeof(uint32_t)));
+        {   // A/B knob: SQG_ROWS_MTYPE=uncached|finegrained allocates the state rows with that memory type
+            const char* mt = getenv("SQG_ROWS_MTYPE");
+            if (mt && !strcmp(mt, "uncached")) CHK(hipExtMallocWithFlags((void**)&c->d_rows, (size_t)total * sizeof(uint32_t), hipDeviceMallocUncached));
+            else if (mt && !strcmp(mt, "finegrained")) CHK(hipExtMallocWithFlags((void**)&c->d_rows, (size_t)total * sizeof(uint32_t), hipDeviceMallocFinegrained));
+            else CHK(hipMalloc(&c->d_rows, (size_t)total * sizeof(uint32_t)));
+        }
         const int blocks = (int)((total + 255) / 256);
         hipLaunchKernelGGL(k_init_rows, dim3(blocks), dim3(256), 0, c->stream, c->d_rows, (int)nk, (long long)cfg->seed, c->wlo, total);
         CHK(hipGetLastError());

@@ -102,6 +102,10 @@ def lib():
         L.orc_batch_free.argtypes = [C.POINTER(Batch)]
         L.orc_worker_of.restype = C.c_int32
         L.orc_worker_of.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+        L.orc_svb_zd_bound.restype = C.c_size_t
+        L.orc_svb_zd_bound.argtypes = [C.c_int64]
+        L.orc_svb_zd.restype = C.c_size_t
+        L.orc_svb_zd.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         _lib = L
     return _lib
 
@@ -208,3 +212,31 @@ class Oracle:
             self.close()
         except Exception:
             pass
+
+
+def svb_zd(sig):
+    """slow5lib's svb-zd encoding of an int16 array (oracle restatement, oracle/sqg_oracle.c)."""
+    import numpy as np
+    sig = np.ascontiguousarray(sig, np.int16)
+    L = lib()
+    out = np.zeros(L.orc_svb_zd_bound(len(sig)), np.uint8)
+    n = L.orc_svb_zd(sig.ctypes.data, len(sig), out.ctypes.data)
+    return out[:n].copy()
+
+
+def svb_zd_decode(enc):
+    """Decoder for the round-trip tests (format: uint32 count | ceil(count/4) key bytes | data)."""
+    import numpy as np
+    enc = np.ascontiguousarray(enc, np.uint8)
+    count = int(enc[:4].view(np.uint32)[0])
+    nkey = (count + 3) // 4
+    keys = enc[4:4 + nkey]
+    codes = ((keys[:, None] >> (2 * np.arange(4, dtype=np.uint8))) & 3).reshape(-1)[:count].astype(np.int64)
+    lens = codes + 1
+    off = np.concatenate(([0], np.cumsum(lens)))[:-1] + 4 + nkey
+    data = np.concatenate((enc, np.zeros(4, np.uint8))).astype(np.uint32)
+    z = np.zeros(count, np.uint32)
+    for b in range(4):
+        z |= np.where(lens > b, data[off + b] << np.uint32(8 * b), np.uint32(0)).astype(np.uint32)
+    d = (z >> np.uint32(1)).astype(np.int64) ^ -(z & np.uint32(1)).astype(np.int64)
+    return np.cumsum(d).astype(np.int16), int(off[-1] + lens[-1]) if count else 4
