@@ -155,6 +155,20 @@ int  sqg_submit(sqg_ctx_t *ctx, int32_t n_reads, const char *seqs, const int64_t
  * under -t T when no work is stolen (src/thread.c:80-99,122-125). */
 int32_t sqg_worker_of(int32_t i, int32_t n_rec, int32_t T);
 
+/* ---- next row: the signal compression of BLOW5 records, on the device ----
+ * For every read of the batch, the bytes slow5lib's ptr_compress_svb_zd (slow5lib/src/slow5_press.c:1055-1087,
+ * reached from slow5_rec_to_mem -> slow5_ptr_compress for the raw_signal field when the file's signal method is
+ * svb-zd) would produce from its raw_signal: uint32 count | StreamVByte keys | data of the zig-zag deltas.
+ * A host that writes BLOW5 copies read i's bytes [svb_off[i], svb_off[i+1]) instead of the 2-byte samples:
+ * ~1.3 B/sample over PCIe instead of 2, and no svb encode on the CPU.  Call after sqg_batch_run; blocks. */
+typedef struct {
+    int64_t n_bytes;            /* total encoded bytes of the batch                              */
+    const int64_t *svb_off;     /* [n_reads+1] byte offsets (host, owned by the batch)           */
+    const uint8_t *d_svb;       /* device: the encodings, valid until the next sqg_batch_compress */
+} sqg_svb_t;
+int  sqg_batch_compress(sqg_ctx_t *ctx, sqg_batch_t *b, sqg_svb_t *out);
+int  sqg_fetch_svb(sqg_ctx_t *ctx, sqg_batch_t *b, uint8_t *dst /* n_bytes */);
+
 /* HBM streaming-store probe used by bench.py to state the measured write
  * ceiling next to the 8 TB/s spec figure: writes `bytes` of int16 `iters`
  * times and returns the average milliseconds per pass. */

@@ -56,9 +56,14 @@ class CTiming(C.Structure):
                 ("lean_ms", C.c_float), ("total_ms", C.c_float), ("fallback_samples", C.c_int64)]
 
 
+class CSvb(C.Structure):
+    _fields_ = [("n_bytes", C.c_int64), ("svb_off", C.POINTER(C.c_int64)), ("d_svb", C.c_void_p)]
+
+
 EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_device_count",
            "sqg_batch_stage", "sqg_batch_run", "sqg_batch_wait", "sqg_fetch_signal", "sqg_fetch_dwell",
-           "sqg_batch_free", "sqg_get_timing", "sqg_submit", "sqg_worker_of", "sqg_probe_store_bandwidth")
+           "sqg_batch_free", "sqg_get_timing", "sqg_submit", "sqg_worker_of", "sqg_probe_store_bandwidth",
+           "sqg_batch_compress", "sqg_fetch_svb")
 
 _lib = None
 
@@ -103,6 +108,10 @@ def load_library(path: str | None = None):
     L.sqg_worker_of.argtypes = [i32, i32, i32]
     L.sqg_probe_store_bandwidth.restype = C.c_int
     L.sqg_probe_store_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
+    L.sqg_batch_compress.restype = C.c_int
+    L.sqg_batch_compress.argtypes = [vp, vp, C.POINTER(CSvb)]
+    L.sqg_fetch_svb.restype = C.c_int
+    L.sqg_fetch_svb.argtypes = [vp, vp, vp]
     if path == _build.LIB:
         _lib = L
     return L
@@ -140,6 +149,18 @@ class Batch:
         out = np.empty(self.n_events, np.int32)
         self.gen._chk(self.gen.L.sqg_fetch_dwell(self.gen.ctx, self.handle, out.ctypes.data), "sqg_fetch_dwell")
         return out
+
+    def compress(self, fetch=True):
+        """svb-zd encodings of the batch's signals (slow5lib's signal compression), made on the device.
+        Returns (bytes as uint8 array, offsets[n_reads+1]); fetch=False leaves the bytes on the device."""
+        r = CSvb()
+        self.gen._chk(self.gen.L.sqg_batch_compress(self.gen.ctx, self.handle, C.byref(r)), "sqg_batch_compress")
+        off = np.ctypeslib.as_array(r.svb_off, shape=(self.n_reads + 1,)).copy()
+        if not fetch:
+            return None, off
+        out = np.empty(r.n_bytes, np.uint8)
+        self.gen._chk(self.gen.L.sqg_fetch_svb(self.gen.ctx, self.handle, out.ctypes.data), "sqg_fetch_svb")
+        return out, off
 
     def free(self):
         if self.handle:

@@ -62,6 +62,9 @@ struct sqg_ctx {
     uint4* d_tfix = nullptr; size_t tfix_cap = 0;
     unsigned char* d_tfix_n = nullptr; size_t tfixn_cap = 0;
     ItemDesc* d_items = nullptr; size_t items_cap = 0;          // [n_stiles] work items of the lean kernel (k_items)
+    uint8_t* d_svb = nullptr; size_t svb_cap = 0;               // svb-zd encodings of the last compressed batch
+    long long* d_svb_size = nullptr; size_t svb_size_cap = 0;   // per read
+    long long* d_svb_off = nullptr; size_t svb_off_cap = 0;
     long long tile_fix = 0;                // undecided samples parked per tile in the last batch (timing info)
     std::string err;
 };
@@ -85,6 +88,8 @@ struct sqg_batch {
     long long n_tiles = 0, n_stiles = 0;
     long long* h_sigoff = nullptr;   // pinned, device-mapped: k_scan writes it directly
     long long* h_sigoff_dev = nullptr;   // its device-side address
+    long long* h_svboff = nullptr;       // pinned, device-mapped: offsets of the svb-zd encodings (sqg_batch_compress)
+    long long n_svb = -1;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel-phase boundaries on the stream
     bool ran = false, waited = false, lean_timed = false, dwell_timed = false;
 };
@@ -157,6 +162,7 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     (void)hipFree(ctx->d_fix); (void)hipFree(ctx->d_fix_count);
     (void)hipFree(ctx->d_evrec); (void)hipFree(ctx->d_tile_so); (void)hipFree(ctx->d_slow);
     (void)hipFree(ctx->d_tfix); (void)hipFree(ctx->d_tfix_n); (void)hipFree(ctx->d_items);
+    (void)hipFree(ctx->d_svb); (void)hipFree(ctx->d_svb_size); (void)hipFree(ctx->d_svb_off);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -325,6 +331,7 @@ extern "C" void sqg_batch_free(sqg_ctx_t* ctx, sqg_batch_t* b) {
     (void)hipFree(b->d_bases); (void)hipFree(b->d_reads); (void)hipFree(b->d_blk_read);
     (void)hipFree(b->d_chain_off); (void)hipFree(b->d_chain_reads); (void)hipFree(b->d_chain_order); (void)hipFree(b->d_tile_read); (void)hipFree(b->d_stile_read);
     if (b->h_sigoff) (void)hipHostFree(b->h_sigoff);
+    if (b->h_svboff) (void)hipHostFree(b->h_svboff);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
     delete b;
 }
@@ -740,6 +747,46 @@ extern "C" int sqg_submit(sqg_ctx_t* c, int32_t n, const char* seqs, const int64
     if (rc) return rc;
     if ((rc = sqg_batch_run(c, *out)) || (rc = sqg_batch_wait(c, *out, res))) { sqg_batch_free(c, *out); *out = nullptr; }
     return rc;
+}
+
+extern "C" int sqg_batch_compress(sqg_ctx_t* c, sqg_batch_t* b, sqg_svb_t* out) {
+    if (!c || !b || !b->ran || !out) return SQG_EINVAL;
+    if (b->seq + 1 != c->next_run) return SQG_ESEQUENCE;      // the signals of an older batch are gone
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc;
+    const int n = b->n;
+    if (!b->h_svboff) {
+        HIPCHK(c, hipHostMalloc(&b->h_svboff, ((size_t)n + 1) * sizeof(long long), hipHostMallocMapped));
+    }
+    long long* h_dev = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer((void**)&h_dev, b->h_svboff, 0));
+    b->h_svboff[0] = 0;
+    if (n > 0) {
+        if ((rc = ensure(c, (void**)&c->d_svb_size, &c->svb_size_cap, (size_t)n + 64, sizeof(long long)))) return rc;
+        if ((rc = ensure(c, (void**)&c->d_svb_off, &c->svb_off_cap, (size_t)n + 64, sizeof(long long)))) return rc;
+        hipLaunchKernelGGL(k_svb_size, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_sig, c->d_sigoff, n, c->d_svb_size);
+        hipLaunchKernelGGL(k_svb_scan, dim3(1), dim3(1024), 0, c->stream, c->d_svb_size, n, c->d_svb_off, h_dev);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));           // the total sizes the output buffer
+        const long long total = b->h_svboff[n];
+        if ((rc = ensure(c, (void**)&c->d_svb, &c->svb_cap, (size_t)total + 64, 1))) return rc;
+        hipLaunchKernelGGL(k_svb_encode, dim3((unsigned)n), dim3(256), 0, c->stream, c->d_sig, c->d_sigoff, n, c->d_svb_off, c->d_svb);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    b->n_svb = b->h_svboff[n];
+    out->n_bytes = b->n_svb;
+    out->svb_off = (const int64_t*)b->h_svboff;
+    out->d_svb = c->d_svb;
+    return SQG_OK;
+}
+
+extern "C" int sqg_fetch_svb(sqg_ctx_t* c, sqg_batch_t* b, uint8_t* dst) {
+    if (!c || !b || !dst || b->n_svb < 0) return SQG_EINVAL;
+    if (b->seq + 1 != c->next_run) return SQG_ESEQUENCE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (b->n_svb > 0) HIPCHK(c, hipMemcpy(dst, c->d_svb, (size_t)b->n_svb, hipMemcpyDeviceToHost));
+    return SQG_OK;
 }
 
 extern "C" int sqg_probe_store_bandwidth(sqg_ctx_t* c, size_t bytes, int iters, float* ms_per_pass) {

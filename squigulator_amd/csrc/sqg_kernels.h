@@ -1142,6 +1142,108 @@ __global__ __launch_bounds__(256) void k_fixup(const SigParams P) {
     }
 }
 
+// ---- svb-zd: slow5lib's signal compression, per read ("next" row) -----
+// slow5lib/src/slow5_press.c:1055-1087: int16 -> zig-zag of the delta to the previous sample (first: to 0) ->
+// StreamVByte: uint32 count | ceil(count/4) key bytes (2 bits per value = bytes-1, first value in the low
+// bits) | the values' 1-4 little-endian bytes.  One quad of samples (= one key byte) per thread.
+__device__ static inline void svb_quad(const int16_t* __restrict__ sig, long long n, long long q, uint32_t z[4], uint32_t& key, uint32_t& nbytes) {
+    // samples 4q-1 .. 4q+3 of the read (the quad and its predecessor)
+    int32_t v[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const long long i = 4 * q - 1 + j;
+        v[j] = (i >= 0 && i < n) ? (int32_t)sig[i] : 0;
+    }
+    key = 0; nbytes = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int32_t d = v[j + 1] - v[j];
+        z[j] = ((uint32_t)d + (uint32_t)d) ^ (uint32_t)(d >> 31);       // streamvbyte_zigzag.c
+        const uint32_t code = z[j] < (1u << 8) ? 0u : z[j] < (1u << 16) ? 1u : z[j] < (1u << 24) ? 2u : 3u;
+        if (4 * q + j < n) { key |= code << (2 * j); nbytes += code + 1; }
+    }
+}
+
+// bytes each read's encoding takes: 4 + ceil(n/4) + data bytes
+__global__ __launch_bounds__(256) void k_svb_size(const int16_t* __restrict__ sig, const long long* __restrict__ sig_off,
+                                                  int n_reads, long long* __restrict__ size) {
+    __shared__ unsigned long long wsum[4];
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const long long n = sig_off[r + 1] - sig_off[r], nq = (n + 3) / 4;
+    const int16_t* s = sig + sig_off[r];
+    unsigned long long sum = 0;
+    for (long long q = threadIdx.x; q < nq; q += 256) {
+        uint32_t z[4], key, nb;
+        svb_quad(s, n, q, z, key, nb);
+        sum += nb;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) size[r] = 4 + nq + (long long)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+}
+
+// exclusive scan of the per-read sizes (single workgroup), also through the pinned host mapping
+__global__ __launch_bounds__(1024) void k_svb_scan(const long long* __restrict__ size, int n, long long* __restrict__ off, long long* __restrict__ host_off) {
+    __shared__ long long wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int per = (n + 1023) / 1024;
+    const int lo = min(tid * per, n), hi = min(lo + per, n);
+    long long v = 0;
+    for (int i = lo; i < hi; i++) v += size[i];
+    long long x = v;
+    for (int o = 1; o < 64; o <<= 1) { long long y = __shfl_up(x, o); if (lane >= o) x += y; }
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    long long run = x - v;
+    for (int w = 0; w < wid; w++) run += wsum[w];
+    for (int i = lo; i < hi; i++) { off[i] = run; host_off[i] = run; run += size[i]; }
+    if (tid == 1023) { off[n] = run; host_off[n] = run; }
+}
+
+__global__ __launch_bounds__(256) void k_svb_encode(const int16_t* __restrict__ sig, const long long* __restrict__ sig_off, int n_reads,
+                                                    const long long* __restrict__ svb_off, uint8_t* __restrict__ out) {
+    __shared__ uint32_t wsum[2][4];
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const long long n = sig_off[r + 1] - sig_off[r], nq = (n + 3) / 4;
+    const int16_t* s = sig + sig_off[r];
+    uint8_t* o = out + svb_off[r];
+    if (tid < 4) o[tid] = (uint8_t)((uint32_t)n >> (8 * tid));          // slow5_press.c:1047: the count word
+    uint8_t* keys = o + 4;
+    uint8_t* data = keys + nq;
+    long long base = 0;                                                  // data bytes of the chunks before this one
+    int buf = 0;
+    for (long long q0 = 0; q0 < nq; q0 += 256, buf ^= 1) {
+        const long long q = q0 + tid;
+        uint32_t z[4] = {0, 0, 0, 0}, key = 0, nb = 0;
+        if (q < nq) svb_quad(s, n, q, z, key, nb);
+        const int incl = wave_incl_scan_dpp((int)nb);
+        if (lane == 63) wsum[buf][wid] = (uint32_t)incl;
+        __syncthreads();                                                 // one barrier per chunk: the sums are double-buffered
+        uint32_t woff = 0, tot = 0;
+        for (int w = 0; w < 4; w++) { const uint32_t x = wsum[buf][w]; if (w < wid) woff += x; tot += x; }
+        if (q < nq) {
+            keys[q] = (uint8_t)key;
+            uint8_t* d = data + base + woff + (uint32_t)incl - nb;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (4 * q + j < n) {
+                    const uint32_t code = (key >> (2 * j)) & 3u;
+                    d[0] = (uint8_t)z[j];
+                    if (code >= 1) d[1] = (uint8_t)(z[j] >> 8);
+                    if (code >= 2) d[2] = (uint8_t)(z[j] >> 16);
+                    if (code >= 3) d[3] = (uint8_t)(z[j] >> 24);
+                    d += code + 1;
+                }
+            }
+        }
+        base += tot;
+    }
+}
+
 // ---- k_certify: max |x_fast - x_exact| over every state the fp32 path may accept ------------
 // The deviate is a function of c1 alone (c2 = a*c1 mod M), so the sweep is exhaustive.
 __global__ __launch_bounds__(256) void k_certify(unsigned int* __restrict__ max_bits) {
