@@ -169,6 +169,39 @@ typedef struct {
 int  sqg_batch_compress(sqg_ctx_t *ctx, sqg_batch_t *b, sqg_svb_t *out);
 int  sqg_fetch_svb(sqg_ctx_t *ctx, sqg_batch_t *b, uint8_t *dst /* n_bytes */);
 
+/* ---- next row: device-resident genome + read sampling on the device ----
+ * sqg_genome_load keeps the reference sequences (ref_t after load_ref, src/ref.c:54-117) in HBM;
+ * sqg_batch_sample then does what the host loop `gen_read(core, ...)` (src/genread.c:358-370, called from
+ * work_per_single_read, src/sim.c:550) does for every read of a batch -- with the workers' ref_pos / rand_strand /
+ * rand_rlen streams (src/sim.c:238-247) living on the device -- and stages the batch exactly as sqg_batch_stage
+ * would have staged those reads: no sequence bytes cross PCIe. */
+#define SQG_SAMPLE_DNA    0u   /* gen_read_dna, src/genread.c:243-281                              */
+#define SQG_SAMPLE_RNA    1u   /* whole transcripts, '+' strand, src/genread.c:311-355             */
+#define SQG_SAMPLE_CDNA   2u   /* transcripts with a strand draw (--cdna)                          */
+#define SQG_SAMPLE_TRUNC  4u   /* --trans-trunc, src/genread.c:303-309                             */
+typedef struct {
+    int32_t n_contigs;
+    const char *seqs;           /* contigs back to back, as loaded (no terminators)                 */
+    const int64_t *contig_off;  /* [n_contigs+1]                                                    */
+    int32_t rlen;               /* -r: mean read length (opt.rlen)                                  */
+    uint32_t mode;              /* SQG_SAMPLE_* bits                                                */
+    int32_t n_trans;            /* --trans-count table (src/ref.c:206-273), 0 if none               */
+    const float *trans_csum;    /* [n_trans] cumulative abundance                                   */
+    const int32_t *trans_idx;   /* [n_trans] contig of each entry                                   */
+} sqg_genome_t;
+typedef struct {                /* what gen_read returned, per read (host arrays owned by the batch) */
+    const int32_t *ref_idx;     /* contig                                                           */
+    const int32_t *ref_len;     /* *ref_len                                                         */
+    const int32_t *ref_pos;     /* *ref_pos (0-based start on the forward strand)                   */
+    const int32_t *rlen;        /* bases in the read                                                */
+    const char *strand;         /* '+' / '-'                                                        */
+    const int64_t *seq_off;     /* [n_reads+1] offsets of the reads in the sqg_fetch_reads() array  */
+} sqg_sample_t;
+int  sqg_genome_load(sqg_ctx_t *ctx, const sqg_genome_t *g);
+int  sqg_batch_sample(sqg_ctx_t *ctx, int32_t n_reads, const int32_t *worker, sqg_batch_t **out, sqg_sample_t *info);
+/* the sampled reads as gen_read returned them (after N substitution and revcomp), for the FASTA/SAM writers */
+int  sqg_fetch_reads(sqg_ctx_t *ctx, sqg_batch_t *b, char *dst /* seq_off[n_reads] bytes */);
+
 /* HBM streaming-store probe used by bench.py to state the measured write
  * ceiling next to the 8 TB/s spec figure: writes `bytes` of int16 `iters`
  * times and returns the average milliseconds per pass. */

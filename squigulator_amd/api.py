@@ -60,10 +60,23 @@ class CSvb(C.Structure):
     _fields_ = [("n_bytes", C.c_int64), ("svb_off", C.POINTER(C.c_int64)), ("d_svb", C.c_void_p)]
 
 
+class CGenome(C.Structure):
+    _fields_ = [("n_contigs", C.c_int32), ("seqs", C.c_char_p), ("contig_off", C.POINTER(C.c_int64)),
+                ("rlen", C.c_int32), ("mode", C.c_uint32), ("n_trans", C.c_int32),
+                ("trans_csum", C.POINTER(C.c_float)), ("trans_idx", C.POINTER(C.c_int32))]
+
+
+class CSample(C.Structure):
+    _fields_ = [("ref_idx", C.POINTER(C.c_int32)), ("ref_len", C.POINTER(C.c_int32)), ("ref_pos", C.POINTER(C.c_int32)),
+                ("rlen", C.POINTER(C.c_int32)), ("strand", C.POINTER(C.c_char)), ("seq_off", C.POINTER(C.c_int64))]
+
+
+SAMPLE_DNA, SAMPLE_RNA, SAMPLE_CDNA, SAMPLE_TRUNC = 0, 1, 2, 4
+
 EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_device_count",
            "sqg_batch_stage", "sqg_batch_run", "sqg_batch_wait", "sqg_fetch_signal", "sqg_fetch_dwell",
            "sqg_batch_free", "sqg_get_timing", "sqg_submit", "sqg_worker_of", "sqg_probe_store_bandwidth",
-           "sqg_batch_compress", "sqg_fetch_svb")
+           "sqg_batch_compress", "sqg_fetch_svb", "sqg_genome_load", "sqg_batch_sample", "sqg_fetch_reads")
 
 _lib = None
 
@@ -112,6 +125,12 @@ def load_library(path: str | None = None):
     L.sqg_batch_compress.argtypes = [vp, vp, C.POINTER(CSvb)]
     L.sqg_fetch_svb.restype = C.c_int
     L.sqg_fetch_svb.argtypes = [vp, vp, vp]
+    L.sqg_genome_load.restype = C.c_int
+    L.sqg_genome_load.argtypes = [vp, C.POINTER(CGenome)]
+    L.sqg_batch_sample.restype = C.c_int
+    L.sqg_batch_sample.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(vp), C.POINTER(CSample)]
+    L.sqg_fetch_reads.restype = C.c_int
+    L.sqg_fetch_reads.argtypes = [vp, vp, vp]
     if path == _build.LIB:
         _lib = L
     return L
@@ -149,6 +168,14 @@ class Batch:
         out = np.empty(self.n_events, np.int32)
         self.gen._chk(self.gen.L.sqg_fetch_dwell(self.gen.ctx, self.handle, out.ctypes.data), "sqg_fetch_dwell")
         return out
+
+    def reads(self):
+        """The sampled reads as gen_read returned them (list of bytes); only for batches made by sample()."""
+        off = self.sampled["seq_off"]
+        buf = np.empty(max(int(off[-1]), 1), np.uint8)
+        self.gen._chk(self.gen.L.sqg_fetch_reads(self.gen.ctx, self.handle, buf.ctypes.data), "sqg_fetch_reads")
+        raw = buf.tobytes()
+        return [raw[off[i]:off[i + 1]] for i in range(self.n_reads)]
 
     def compress(self, fetch=True):
         """svb-zd encodings of the batch's signals (slow5lib's signal compression), made on the device.
@@ -234,6 +261,36 @@ class SignalGenerator:
 
     def submit(self, seqs, workers=None) -> Batch:
         return self.stage(seqs, workers).run().wait()
+
+    def load_genome(self, contigs, rlen: int, mode: int = SAMPLE_DNA, trans=None):
+        """Keep the reference (list of bytes, as load_ref returned it) on the device for sample()."""
+        blob = b"".join(contigs)
+        off = np.zeros(len(contigs) + 1, np.int64)
+        off[1:] = np.cumsum([len(x) for x in contigs])
+        g = CGenome(len(contigs), blob, off.ctypes.data_as(C.POINTER(C.c_int64)), rlen, mode, 0, None, None)
+        if trans is not None:
+            csum = np.ascontiguousarray(trans[0], np.float32)
+            idx = np.ascontiguousarray(trans[1], np.int32)
+            g.n_trans = len(csum)
+            g.trans_csum = csum.ctypes.data_as(C.POINTER(C.c_float))
+            g.trans_idx = idx.ctypes.data_as(C.POINTER(C.c_int32))
+        self._chk(self.L.sqg_genome_load(self.ctx, C.byref(g)), "sqg_genome_load")
+
+    def sample(self, n: int, workers=None) -> Batch:
+        """gen_read for n reads on the device + staging; the returned batch carries .sampled (per-read arrays)."""
+        wk = np.ascontiguousarray(workers, np.int32) if workers is not None else None
+        h = C.c_void_p()
+        info = CSample()
+        rc = self.L.sqg_batch_sample(self.ctx, n, wk.ctypes.data_as(C.POINTER(C.c_int32)) if wk is not None else None,
+                                     C.byref(h), C.byref(info))
+        self._chk(rc, "sqg_batch_sample")
+        b = Batch(self, h, n)
+        arr = lambda p, shape, dt: (np.ctypeslib.as_array(p, shape=shape).copy() if n else np.zeros(0, dt))  # noqa: E731
+        b.sampled = dict(ref_idx=arr(info.ref_idx, (n,), np.int32), ref_len=arr(info.ref_len, (n,), np.int32),
+                         ref_pos=arr(info.ref_pos, (n,), np.int32), rlen=arr(info.rlen, (n,), np.int32),
+                         strand=bytes(info.strand[:n]) if n else b"",
+                         seq_off=np.ctypeslib.as_array(info.seq_off, shape=(n + 1,)).copy())
+        return b
 
     def timing(self):
         t = CTiming()

@@ -62,6 +62,12 @@ struct sqg_ctx {
     uint4* d_tfix = nullptr; size_t tfix_cap = 0;
     unsigned char* d_tfix_n = nullptr; size_t tfixn_cap = 0;
     ItemDesc* d_items = nullptr; size_t items_cap = 0;          // [n_stiles] work items of the lean kernel (k_items)
+    uint8_t* d_genome = nullptr;                                // resident reference (sqg_genome_load)
+    long long* d_contig_off = nullptr; long long* d_cum = nullptr;
+    float* d_trans_csum = nullptr; int* d_trans_idx = nullptr;
+    uint32_t* d_samp = nullptr;                                 // [nw][3] sampler stream states: ref_pos, rand_strand, rand_rlen
+    GenomeParams genome{};
+    bool genome_loaded = false;
     uint8_t* d_svb = nullptr; size_t svb_cap = 0;               // svb-zd encodings of the last compressed batch
     long long* d_svb_size = nullptr; size_t svb_size_cap = 0;   // per read
     long long* d_svb_off = nullptr; size_t svb_off_cap = 0;
@@ -88,6 +94,11 @@ struct sqg_batch {
     long long n_tiles = 0, n_stiles = 0;
     long long* h_sigoff = nullptr;   // pinned, device-mapped: k_scan writes it directly
     long long* h_sigoff_dev = nullptr;   // its device-side address
+    long long n_bases_total = 0;         // bytes in d_bases
+    std::vector<long long> h_base_off;   // per read: its segment 0 in d_bases
+    std::vector<int32_t> s_ref_idx, s_ref_len, s_ref_pos, s_rlen;   // sqg_batch_sample: what gen_read returned
+    std::vector<char> s_strand;
+    std::vector<long long> s_seq_off, s_read_at;                    // offsets of the reads in sqg_fetch_reads / in d_bases
     long long* h_svboff = nullptr;       // pinned, device-mapped: offsets of the svb-zd encodings (sqg_batch_compress)
     long long n_svb = -1;
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel-phase boundaries on the stream
@@ -163,6 +174,8 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     (void)hipFree(ctx->d_evrec); (void)hipFree(ctx->d_tile_so); (void)hipFree(ctx->d_slow);
     (void)hipFree(ctx->d_tfix); (void)hipFree(ctx->d_tfix_n); (void)hipFree(ctx->d_items);
     (void)hipFree(ctx->d_svb); (void)hipFree(ctx->d_svb_size); (void)hipFree(ctx->d_svb_off);
+    (void)hipFree(ctx->d_genome); (void)hipFree(ctx->d_contig_off); (void)hipFree(ctx->d_cum);
+    (void)hipFree(ctx->d_trans_csum); (void)hipFree(ctx->d_trans_idx); (void)hipFree(ctx->d_samp);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -336,9 +349,10 @@ extern "C" void sqg_batch_free(sqg_ctx_t* ctx, sqg_batch_t* b) {
     delete b;
 }
 
-extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t* seq_off,
-                               const int32_t* worker, sqg_batch_t** out) {
-    if (!c || !out || n < 0 || (n > 0 && (!seqs || !seq_off))) return SQG_EINVAL;
+// Staging shared by sqg_batch_stage (reads come from the host: seqs != null) and sqg_batch_sample (reads were
+// sampled on the device: seqs == null, d_rec holds one SampleRec per read and k_copy_reads fills the base buffer).
+static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t* seq_off,
+                        const int32_t* worker, const SampleRec* d_rec, sqg_batch_t** out) {
     *out = nullptr;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const sqg_profile_t& p = c->cfg.profile;
@@ -395,8 +409,8 @@ extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const 
     }
 
     // pass 2: base buffer (prefix/stall attached as src/genread.c:95-123 does)
-    std::vector<uint8_t> hb((size_t)nb + 16, (uint8_t)'A');
-    for (int i = 0; i < n; i++) {
+    std::vector<uint8_t> hb(seqs ? (size_t)nb + 16 : 0, (uint8_t)'A');
+    for (int i = 0; seqs && i < n; i++) {
         const ReadDesc& d = rd[(size_t)i];
         uint8_t* dst = hb.data() + d.base_off;
         const char* src = seqs + seq_off[i];
@@ -474,10 +488,19 @@ extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const 
 
     auto bail = [&](int code) { sqg_batch_free(c, b); return code; };
 #define CHKB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE); } } while (0)
-    CHKB(hipMalloc(&b->d_bases, hb.size()));
-    CHKB(hipMemcpyAsync(b->d_bases, hb.data(), hb.size(), hipMemcpyHostToDevice, c->stream));
+    CHKB(hipMalloc(&b->d_bases, (size_t)nb + 16));
+    if (seqs) CHKB(hipMemcpyAsync(b->d_bases, hb.data(), hb.size(), hipMemcpyHostToDevice, c->stream));
+    else CHKB(hipMemsetAsync(b->d_bases + nb, 'A', 16, c->stream));
     CHKB(hipMalloc(&b->d_reads, std::max<size_t>(1, rd.size()) * sizeof(ReadDesc)));
     if (n) CHKB(hipMemcpyAsync(b->d_reads, rd.data(), rd.size() * sizeof(ReadDesc), hipMemcpyHostToDevice, c->stream));
+    if (!seqs && n) {                                      // the reads come from the resident genome
+        hipLaunchKernelGGL(k_copy_reads, dim3((unsigned)n), dim3(256), 0, c->stream, c->genome, d_rec, b->d_reads, b->d_bases, n,
+                           rna ? 1 : 0, prefix ? 1 : 0);
+        CHKB(hipGetLastError());
+    }
+    b->n_bases_total = nb;
+    b->h_base_off.resize((size_t)n);
+    for (int i = 0; i < n; i++) b->h_base_off[(size_t)i] = rd[(size_t)i].base_off;
     CHKB(hipMalloc(&b->d_blk_read, blk_read.size() * sizeof(int)));
     CHKB(hipMemcpyAsync(b->d_blk_read, blk_read.data(), blk_read.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     CHKB(hipMalloc(&b->d_chain_off, chain_off.size() * sizeof(int)));
@@ -497,6 +520,135 @@ extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const 
 #undef CHKB
     c->next_stage++;
     *out = b;
+    return SQG_OK;
+}
+
+extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t* seq_off,
+                               const int32_t* worker, sqg_batch_t** out) {
+    if (!c || !out || n < 0 || (n > 0 && (!seqs || !seq_off))) return SQG_EINVAL;
+    static const char none[1] = {0};
+    static const int64_t zero_off[1] = {0};
+    return stage_common(c, n, n > 0 ? seqs : none, n > 0 ? seq_off : zero_off, worker, nullptr, out);
+}
+
+// ---- resident genome + device-side read sampler ("next" row of SURVEY.md section 8f) ----
+extern "C" int sqg_genome_load(sqg_ctx_t* c, const sqg_genome_t* g) {
+    if (!c || !g || g->n_contigs <= 0 || !g->seqs || !g->contig_off || g->rlen <= 0) return SQG_EINVAL;
+    if (g->n_trans < 0 || (g->n_trans > 0 && (!g->trans_csum || !g->trans_idx))) return SQG_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const int nc = g->n_contigs;
+    const long long total = g->contig_off[nc] - g->contig_off[0];
+    std::vector<long long> off((size_t)nc + 1), cum((size_t)nc);
+    for (int i = 0; i <= nc; i++) off[(size_t)i] = g->contig_off[i] - g->contig_off[0];
+    long long run = 0;
+    for (int i = 0; i < nc; i++) {
+        const long long len = off[(size_t)i + 1] - off[(size_t)i];
+        if (len < 0 || len > 2000000000LL) return SQG_EINVAL;
+        run += len; cum[(size_t)i] = run;
+    }
+    (void)hipFree(c->d_genome); (void)hipFree(c->d_contig_off); (void)hipFree(c->d_cum);
+    (void)hipFree(c->d_trans_csum); (void)hipFree(c->d_trans_idx); (void)hipFree(c->d_samp);
+    c->d_genome = nullptr; c->d_contig_off = nullptr; c->d_cum = nullptr; c->d_trans_csum = nullptr; c->d_trans_idx = nullptr; c->d_samp = nullptr;
+    HIPCHK(c, hipMalloc(&c->d_genome, (size_t)total + 16));
+    HIPCHK(c, hipMemcpy(c->d_genome, g->seqs + g->contig_off[0], (size_t)total, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(c->d_genome + total, 0, 16));
+    HIPCHK(c, hipMalloc(&c->d_contig_off, off.size() * sizeof(long long)));
+    HIPCHK(c, hipMemcpy(c->d_contig_off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_cum, cum.size() * sizeof(long long)));
+    HIPCHK(c, hipMemcpy(c->d_cum, cum.data(), cum.size() * sizeof(long long), hipMemcpyHostToDevice));
+    if (g->n_trans > 0) {
+        HIPCHK(c, hipMalloc(&c->d_trans_csum, (size_t)g->n_trans * sizeof(float)));
+        HIPCHK(c, hipMemcpy(c->d_trans_csum, g->trans_csum, (size_t)g->n_trans * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc(&c->d_trans_idx, (size_t)g->n_trans * sizeof(int)));
+        HIPCHK(c, hipMemcpy(c->d_trans_idx, g->trans_idx, (size_t)g->n_trans * sizeof(int), hipMemcpyHostToDevice));
+    }
+    // the workers' sampler streams: ref_pos = s, rand_strand = s+1, rand_rlen = s+3 (src/sim.c:238-247)
+    HIPCHK(c, hipMalloc(&c->d_samp, (size_t)c->nw * 3 * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_init_sampler, dim3((unsigned)((c->nw + 255) / 256)), dim3(256), 0, c->stream, c->d_samp,
+                       (long long)c->cfg.seed, c->wlo, c->nw, (int)(1u << (2 * c->k)));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    GenomeParams& G = c->genome;
+    G.seq = c->d_genome; G.contig_off = c->d_contig_off; G.cum = c->d_cum;
+    G.trans_csum = c->d_trans_csum; G.trans_idx = c->d_trans_idx;
+    G.sum = total; G.grng_b = (double)(g->rlen / 2); G.n_contigs = nc; G.n_trans = g->n_trans; G.rlen = g->rlen;
+    G.flags = (int)g->mode;
+    c->genome_loaded = true;
+    return SQG_OK;
+}
+
+extern "C" int sqg_batch_sample(sqg_ctx_t* c, int32_t n, const int32_t* worker, sqg_batch_t** out, sqg_sample_t* info) {
+    if (!c || !out || n < 0) return SQG_EINVAL;
+    if (!c->genome_loaded) { c->err = "sqg_genome_load has not been called"; return SQG_EINVAL; }
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    // worker chains in batch order (a worker's reads are sampled in index order, like its signal streams)
+    std::vector<int> wk((size_t)n), count((size_t)c->nw, 0);
+    for (int i = 0; i < n; i++) {
+        const int w = worker ? worker[i] : sqg_worker_of(i, n, c->T);
+        if (w < c->wlo || w >= c->whi) { c->err = "read assigned to a worker this context does not own"; return SQG_EINVAL; }
+        wk[(size_t)i] = w - c->wlo; count[(size_t)wk[(size_t)i]]++;
+    }
+    std::vector<int> chain_of((size_t)c->nw, -1), chain_off(1, 0), chain_worker;
+    for (int w = 0; w < c->nw; w++) if (count[(size_t)w]) { chain_of[(size_t)w] = (int)chain_off.size() - 1; chain_off.push_back(chain_off.back() + count[(size_t)w]); chain_worker.push_back(w); }
+    const int n_chains = (int)chain_off.size() - 1;
+    std::vector<int> fill(chain_off.begin(), chain_off.end() - 1), chain_reads((size_t)n);
+    for (int i = 0; i < n; i++) chain_reads[(size_t)fill[(size_t)chain_of[(size_t)wk[(size_t)i]]]++] = i;
+
+    SampleRec* d_rec = nullptr;
+    int *d_co = nullptr, *d_cr = nullptr, *d_cw = nullptr;
+    std::vector<SampleRec> rec((size_t)n);
+    int rc = SQG_OK;
+    auto cleanup = [&]() { (void)hipFree(d_rec); (void)hipFree(d_co); (void)hipFree(d_cr); (void)hipFree(d_cw); };
+#define CHKS(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE; } } while (0)
+    CHKS(hipMalloc(&d_rec, std::max<size_t>(1, (size_t)n) * sizeof(SampleRec)));
+    if (n > 0) {
+        CHKS(hipMalloc(&d_co, chain_off.size() * sizeof(int)));
+        CHKS(hipMalloc(&d_cr, chain_reads.size() * sizeof(int)));
+        CHKS(hipMalloc(&d_cw, chain_worker.size() * sizeof(int)));
+        CHKS(hipMemcpyAsync(d_co, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        CHKS(hipMemcpyAsync(d_cr, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        CHKS(hipMemcpyAsync(d_cw, chain_worker.data(), chain_worker.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_sample, dim3((unsigned)((n_chains + 63) / 64)), dim3(64), 0, c->stream, c->genome, c->d_samp, d_co, d_cr, d_cw,
+                           n_chains, d_rec, c->d_err);
+        CHKS(hipGetLastError());
+        CHKS(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(SampleRec), hipMemcpyDeviceToHost, c->stream));
+        CHKS(hipStreamSynchronize(c->stream));
+        unsigned int e = 0;
+        CHKS(hipMemcpy(&e, c->d_err, sizeof e, hipMemcpyDeviceToHost));
+        if (e & 16u) { CHKS(hipMemset(c->d_err, 0, sizeof e)); c->err = "read sampler: no acceptable read after 100000 attempts"; cleanup(); return SQG_EINVAL; }
+    }
+#undef CHKS
+    // lengths are known now: stage as sqg_batch_stage would, the base buffer being filled on the device
+    std::vector<int64_t> seq_off((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++) seq_off[(size_t)i + 1] = seq_off[(size_t)i] + rec[(size_t)i].rlen;
+    rc = stage_common(c, n, nullptr, seq_off.data(), worker, d_rec, out);
+    cleanup();
+    if (rc) return rc;
+    sqg_batch* b = *out;
+    const bool rna = c->cfg.flags & SQG_RNA, prefix = c->cfg.flags & SQG_PREFIX;
+    const long long read_at = (prefix && !rna) ? (long long)(strlen(kStallDna) + strlen(kAdaptorDna)) : 0;
+    b->s_ref_idx.resize((size_t)n); b->s_ref_len.resize((size_t)n); b->s_ref_pos.resize((size_t)n); b->s_rlen.resize((size_t)n);
+    b->s_strand.resize((size_t)n + 1); b->s_seq_off.assign(seq_off.begin(), seq_off.end()); b->s_read_at.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+        const SampleRec& q = rec[(size_t)i];
+        b->s_ref_idx[(size_t)i] = q.ref_idx; b->s_ref_len[(size_t)i] = q.ref_len; b->s_ref_pos[(size_t)i] = q.ref_pos;
+        b->s_rlen[(size_t)i] = q.rlen; b->s_strand[(size_t)i] = (char)q.strand; b->s_read_at[(size_t)i] = read_at;
+    }
+    if (info) {
+        info->ref_idx = b->s_ref_idx.data(); info->ref_len = b->s_ref_len.data(); info->ref_pos = b->s_ref_pos.data();
+        info->rlen = b->s_rlen.data(); info->strand = b->s_strand.data(); info->seq_off = (const int64_t*)b->s_seq_off.data();
+    }
+    return SQG_OK;
+}
+
+extern "C" int sqg_fetch_reads(sqg_ctx_t* c, sqg_batch_t* b, char* dst) {
+    if (!c || !b || !dst || b->s_seq_off.empty()) return SQG_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    std::vector<uint8_t> all((size_t)b->n_bases_total + 1);
+    if (b->n_bases_total) HIPCHK(c, hipMemcpy(all.data(), b->d_bases, (size_t)b->n_bases_total, hipMemcpyDeviceToHost));
+    for (int i = 0; i < b->n; i++)
+        memcpy(dst + b->s_seq_off[(size_t)i], all.data() + b->h_base_off[(size_t)i] + b->s_read_at[(size_t)i], (size_t)b->s_rlen[(size_t)i]);
     return SQG_OK;
 }
 

@@ -1,0 +1,90 @@
+"""Device-side read sampler on the resident genome ("next" row): gen_read, src/genread.c:125-370.
+
+The oracle's sampler is pinned by the reference's goldens (read ids = contig/position/strand of every read,
+tests/test_oracle_goldens.py); here the device sampler must reproduce it read for read -- coordinates, the
+sequence after N substitution and reverse complement, and through them the signals."""
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from squigulator_amd import api, model, profiles
+
+INPUTS = os.path.join(os.path.dirname(__file__), "golden", "inputs")
+NCOV = os.path.join(INPUTS, "nCoV-2019.reference.fasta")
+SEQUIN = os.path.join(INPUTS, "rnasequin_sequences_2.4.fa")
+SEQUIN_TC = os.path.join(INPUTS, "sequin_count.tsv")
+
+
+def _contigs(ref):
+    return [bytes(ref.seqs[i][:ref.lengths[i]]) for i in range(ref.num_ref)]
+
+
+def _run(profile, k, fasta, T, batches, rlen, oflags=0, sflags=0, mode=api.SAMPLE_DNA, trans_count=None, seed=42):
+    prof, fl = profiles.get_profile(profile)
+    mean, stdv = model.synthetic_model(k)
+    orac = orc.Oracle(prof, fl | oflags | sflags, k, mean, stdv, seed, num_workers=T, rlen=rlen)
+    ref = orac.load_ref(fasta, trans_count)
+    trans = None
+    if trans_count:
+        trans = (np.ctypeslib.as_array(ref.trans_csum, shape=(ref.trans_n,)).copy(),
+                 np.ctypeslib.as_array(ref.trans_idx, shape=(ref.trans_n,)).copy())
+    gen = api.SignalGenerator(prof, fl | sflags, k, mean, stdv, seed, num_workers=T, mode=api.MODE_CERTIFIED)
+    gen.load_genome(_contigs(ref), rlen, mode, trans)
+    total = 0
+    for nb in batches:
+        want = orac.run_batch(nb)
+        b = gen.sample(nb).run().wait()
+        s = b.sampled
+        seqs = b.reads()
+        sig, dw = b.signal(), b.dwell()
+        for i, w in enumerate(want):
+            assert (s["ref_idx"][i], s["ref_pos"][i], s["rlen"][i], chr(s["strand"][i])) == \
+                   (w.ref_idx, w.ref_pos_st, w.rlen, w.strand), f"read {i}"
+            assert s["ref_len"][i] == w.ref_len
+            assert seqs[i] == w.seq, f"read {i}: sequence differs"
+            np.testing.assert_array_equal(sig[b.sig_off[i]:b.sig_off[i + 1]], w.sig, err_msg=f"read {i}")
+            np.testing.assert_array_equal(dw[b.ev_off[i]:b.ev_off[i + 1]], w.ss)
+        total += nb
+        b.free()
+    gen.close(); orac.close()
+    return total
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,batches", [(1, [12, 5]), (16, [16, 16, 7]), (4, [10])], ids=["t1", "tk16", "t4_k10"])
+def test_dna_sampler_matches_oracle(T, batches):
+    _run("dna-r9-prom", 6, NCOV, T, batches, rlen=1500)
+
+
+@pytest.mark.gpu
+def test_dna_sampler_with_N_runs_and_lowercase(tmp_path):
+    """N substitution from the fresh state-100 stream, >10 % N rejection, clipping at contig ends, lower case."""
+    rng = np.random.default_rng(11)
+    contigs = []
+    for n in (3000, 9000, 1200, 300):
+        s = rng.choice(list(b"ACGTacgt"), n).astype(np.uint8)
+        for _ in range(n // 400):
+            p = int(rng.integers(0, n - 60))
+            s[p:p + int(rng.integers(1, 60))] = ord("N")
+        contigs.append(bytes(s))
+    contigs[1] = contigs[1][:4000] + b"N" * 900 + contigs[1][4900:]
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(f">c{i}\n{c.decode()}\n" for i, c in enumerate(contigs)))
+    _run("dna-r9-prom", 6, str(fa), 8, [8, 8, 8], rlen=900, seed=7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,oflags,mode,tc", [
+    ("uniform", 0, api.SAMPLE_RNA, None),
+    ("trans_count", 0, api.SAMPLE_RNA, SEQUIN_TC),
+    ("trans_trunc", 0x100, api.SAMPLE_RNA | api.SAMPLE_TRUNC, SEQUIN_TC),
+], ids=lambda x: x if isinstance(x, str) else None)
+def test_rna_sampler_matches_oracle(name, oflags, mode, tc):
+    _run("rna004-prom", 9, SEQUIN, 6, [6, 6], rlen=10000, oflags=oflags, sflags=profiles.SQ_PREFIX, mode=mode, trans_count=tc)
+
+
+@pytest.mark.gpu
+def test_cdna_sampler_matches_oracle():
+    _run("dna-r9-prom", 6, SEQUIN, 5, [5, 5], rlen=10000, oflags=0x200, mode=api.SAMPLE_CDNA, trans_count=SEQUIN_TC)
