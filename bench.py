@@ -5,7 +5,10 @@ Workload (BASELINE.json configs[1]): nCoV-2019 reference, -x dna-r9-prom (R9 6-m
 reads of gamma-distributed length (-r 10000) cut from the 29 903-nt genome, --seed 42.  One "step" is
 one batch (one process_db()) of --batch-reads reads in the T=K regime: read i of a batch runs on
 virtual worker i.  Steps x batch-reads reads in total; the default 12 x 8192 ~= the config's n=100000.
-Inputs (sequences, per-read descriptors) are resident in HBM before the timed region starts.
+The reads are the ones the reference itself would draw: gen_read (src/genread.c) with `--seed 42 -t T -K T`
+on the genome kept in HBM, sampled by the library's device-side sampler at staging time (--host-sampler:
+numpy draws of the same distribution, uploaded).  Inputs (sequences, per-read descriptors) are resident in
+HBM before the timed region starts.
 
 N>1: one process per GPU (torch.distributed, backend nccl = RCCL).  The job's T = N*K virtual workers
 are sharded contiguously over ranks; each rank stages and runs only its own workers' reads (no
@@ -186,6 +189,8 @@ def main():
     ap.add_argument("--profile", default="dna-r9-prom")
     ap.add_argument("--mode", default="certified", choices=["exact", "certified"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-sampler", action="store_true",
+                    help="sample the reads with numpy on the host (same distribution) instead of the device-side gen_read")
     ap.add_argument("--no-store-probe", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for one rank per GPU; gloo only to exercise the N>1 control flow on a "
@@ -236,9 +241,16 @@ def main():
 
     nsteps = args.warmup + args.steps
     batches = []
-    for _ in range(nsteps):
-        blob, off = pack(sample_reads(genome, K, args.rlen, rng))
-        batches.append(gen.stage_packed(blob, off, workers))      # H2D happens here, outside the timed region
+    if args.host_sampler:
+        for _ in range(nsteps):
+            blob, off = pack(sample_reads(genome, K, args.rlen, rng))
+            batches.append(gen.stage_packed(blob, off, workers))  # H2D happens here, outside the timed region
+    else:
+        # the reads ARE the reference's: gen_read (src/genread.c) with `--seed 42 -r <rlen> -t T -K T` on the
+        # resident genome, sampled on the device at staging time (outside the timed region)
+        gen.load_genome([genome], args.rlen, api.SAMPLE_DNA)
+        for _ in range(nsteps):
+            batches.append(gen.sample(K, workers))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -297,6 +309,8 @@ def main():
                             f"-t {T} -K {T} (T=K virtual workers, {K} per GPU), {args.steps} batches "
                             f"(BASELINE.json configs[1], n~100000)",
                 "reads_per_step_per_gpu": K, "kmer_size": k, "mode": args.mode,
+                "reads": "numpy draws of gen_read's distribution (host)" if args.host_sampler
+                         else "gen_read on the device-resident genome (library sampler), as the reference with these options",
                 "pore_model": "synthetic stand-in table (built-in ONT tables absent from the reference mount)",
             },
             "reads_per_s": tot_reads / dt_max,
