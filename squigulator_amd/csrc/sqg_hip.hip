@@ -298,15 +298,17 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     // per-(worker,k-mer) stream states
     if (c->use_kmer_streams) {
         const long long total = (long long)c->nw * nk;
-        {   // A/B knob: SQG_ROWS_MTYPE=uncached|finegrained allocates the state rows with that memory type
-            const char* mt = getenv("SQG_ROWS_MTYPE");
-            if (mt && !strcmp(mt, "uncached")) CHK(hipExtMallocWithFlags((void**)&c->d_rows, (size_t)total * sizeof(uint32_t), hipDeviceMallocUncached));
-            else if (mt && !strcmp(mt, "finegrained")) CHK(hipExtMallocWithFlags((void**)&c->d_rows, (size_t)total * sizeof(uint32_t), hipDeviceMallocFinegrained));
-            else CHK(hipMalloc(&c->d_rows, (size_t)total * sizeof(uint32_t)));
+        CHK(hipMalloc(&c->d_rows, (size_t)total * sizeof(uint32_t)));
+        if (c->k <= 6) {
+            // rows hold the stream STATES; a chain moves its whole row through LDS (src/sim.c:248-256)
+            const int blocks = (int)((total + 255) / 256);
+            hipLaunchKernelGGL(k_init_rows, dim3(blocks), dim3(256), 0, c->stream, c->d_rows, (int)nk, (long long)cfg->seed, c->wlo, total);
+            CHK(hipGetLastError());
+        } else {
+            // 1 MiB per worker, ~4 % of it used by a read: rows hold the number of SAMPLES each stream has produced, so
+            // that one returning atomic add per k-mer bin replaces a load and a store; the state is seed * a^(2*count)
+            CHK(hipMemsetAsync(c->d_rows, 0, (size_t)total * sizeof(uint32_t), c->stream));
         }
-        const int blocks = (int)((total + 255) / 256);
-        hipLaunchKernelGGL(k_init_rows, dim3(blocks), dim3(256), 0, c->stream, c->d_rows, (int)nk, (long long)cfg->seed, c->wlo, total);
-        CHK(hipGetLastError());
     }
     // scalar streams (src/sim.c:241-247): time = s+2, offset = s+4, median = s+5
     c->time_c.resize((size_t)c->nw); c->off_x.resize((size_t)c->nw); c->med_x.resize((size_t)c->nw);
@@ -698,6 +700,7 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     P.dwell = c->use_dwell_stream ? c->d_dwell : nullptr; P.dwell_out = c->d_dwell; P.seglen_out = c->d_seglen;
     P.dmean = p.dwell_mean; P.dstd = p.dwell_std;
     P.seglen = c->d_seglen; P.sig_off = c->d_sigoff; P.model = c->d_model; P.pw = c->d_pow; P.rows = c->d_rows;
+    P.seed_base = canon((long long)c->cfg.seed + (long long)c->wlo * ((long long)(1u << (2 * c->k)) + 10)); P.seed_step = canon((long long)(1u << (2 * c->k)) + 10);
     P.err = c->d_err; P.dig = p.digitisation; P.range = p.range; P.kd = p.digitisation / p.range;
     P.chain_order = b->d_chain_order; P.delta_x = c->delta_x; P.thr_all = c->thr_all;
     P.k = c->k; P.num_kmer = c->num_kmer; P.const_sps = (int)p.dwell_mean;

@@ -165,7 +165,9 @@ struct SigParams {
     const long long* sig_off;    // [n_reads+1]
     const float2* model;         // {level_mean, (float)(level_stdv*amp_noise)}
     const uint32_t* pw;
-    uint32_t* rows;              // [n_local_workers][num_kmer]
+    uint32_t* rows;              // [n_local_workers][num_kmer]: k <= 6 the stream states; k > 6 the samples each stream has produced
+    uint32_t seed_base, seed_step;   // (seed + worker_lo*(4^k+10)) mod M and (4^k+10) mod M: the initial state of local worker w,
+                                     // k-mer j is (seed_base + w*seed_step + j) mod M (src/sim.c:238-256)
     int16_t* sig;
     unsigned int* err;
     FixEntry* fix;               // certified mode: undecided samples
@@ -405,7 +407,8 @@ struct EvLds {
     uint32_t head[DIRECT ? 1 : 2 * SEG];     // hash bin -> most recently inserted event of the segment (EV_NIL: none)
     uint32_t row[DIRECT ? 4096 : 1];         // DIRECT: the worker's stream states, resident for the whole chain; while a segment
                                              // is being handed out, ROW_BUSY | (most recently inserted event of the bin)
-    uint32_t st[DIRECT ? SEG : 1];           // DIRECT: the state the bin's first event of the segment swapped out of row[]
+    uint32_t st[SEG];                        // DIRECT: the state the bin's first exchanger swapped out of row[]; else: the
+                                             // bin's state at the start of the segment, published by its first event
     uint32_t nxt[SEG];          // per event: (dwell << 16) | next event in the same bin
     uint32_t jump[(MULT_N > SEG ? MULT_N : SEG)];    // a^(2j)
     uint8_t codes[SEG + EV_HALO + 4];  // 2-bit base codes of the segment
@@ -435,6 +438,9 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
     uint32_t* row = P.rows ? P.rows + (size_t)P.reads[P.chain_reads[c_lo]].worker * P.num_kmer : nullptr;
     const int k = P.k;
     const uint32_t kmask = (k >= 16) ? 0xffffffffu : ((1u << (2 * k)) - 1u);
+    // k > 6: initial state of this worker's k-mer j is (seed_w + j) mod M (src/sim.c:249)
+    const uint32_t seed_w = (uint32_t)(((unsigned long long)P.seed_base +
+                                        (unsigned long long)(P.rows ? P.reads[P.chain_reads[c_lo]].worker : 0) * P.seed_step) % LCG_M);
     if (DIRECT && P.use_streams) for (int i = tid; i < P.num_kmer; i += NT) L.row[i] = row[i];
     const uint32_t a2nt = DW ? lcg_jump2(P.pw, (uint32_t)SEG) : 0u;      // time-stream jump over one segment
     const float dw_sf = (float)P.dstd, dw_mf = (float)P.dmean;
@@ -594,11 +600,11 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
                 // and whether I am the last one (who stores the advanced state)
                 // the bin's FIRST event (prior == 0) stores the advanced state, so that every event has exactly one
                 // modular multiplication: a^(2*prior) for its own state, or a^(2*total) for the bin's next state
-                uint32_t prior[EPT], total[EPT], c_row[EPT];
+                uint32_t prior[EPT], total[EPT], c_row[EPT], fid[EPT];   // fid: the bin's first event (in event order)
                 bool first[EPT];
 #pragma unroll
                 for (int q = 0; q < EPT; q++) {
-                    prior[q] = 0; total[q] = (uint32_t)sps[q]; c_row[q] = 0; first[q] = true;
+                    prior[q] = 0; total[q] = (uint32_t)sps[q]; c_row[q] = 0; first[q] = true; fid[q] = 0;
                     if (EV_IN(e0 + q)) {
                         const uint32_t id = (uint32_t)(tid * EPT + q);
                         // walk the bin's other members (bins hold 1-3 events; alone: no iteration)
@@ -606,18 +612,26 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
                         if (DIRECT) {
                             c_row[q] = swapped[q];                                           // the state itself if I was first to exchange
                             t = L.row[rank[q]] & 0xffffu;                                    // most recently inserted event
-                        } else {
-                            c_row[q] = __builtin_nontemporal_load(&row[rank[q]]);            // global: L2-served (bypasses the CU's L1)
-                            t = L.head[h[q]];
-                        }
+                        } else t = L.head[h[q]];
                         if (t == id) t = my_prev[q];
+                        fid[q] = id;
                         while (t != EV_NIL) {
                             const uint32_t v = L.nxt[t];
                             const uint32_t s2 = v >> 16, nx = v & 0xffffu;
                             total[q] += s2;
-                            if (t < id) { prior[q] += s2; first[q] = false; }
+                            if (t < id) { prior[q] += s2; first[q] = false; fid[q] = min(fid[q], t); }
                             if (DIRECT && nx == EV_NIL) c_row[q] = L.st[t];                   // the first to exchange holds the state
                             t = (nx == id) ? my_prev[q] : nx;
+                        }
+                        if (!DIRECT && first[q]) {
+                            // one returning atomic per bin: the samples this stream had produced before the segment; its
+                            // state is the seed advanced by two draws per sample
+                            const uint32_t n_old = atomicAdd(&row[rank[q]], total[q]);
+                            const unsigned long long sv = (unsigned long long)seed_w + rank[q];
+                            uint32_t cb = (uint32_t)(sv >= LCG_M ? sv - LCG_M : sv);
+                            if (n_old) cb = lcg_mul(cb, n_old < MULT_N ? L.jump[n_old] : lcg_jump2(P.pw, n_old));
+                            c_row[q] = cb;
+                            L.st[id] = cb;
                         }
                     }
                 }
@@ -625,12 +639,13 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
 #pragma unroll
                 for (int q = 0; q < EPT; q++) {
                     if (EV_IN(e0 + q)) {
-                        const uint32_t n = first[q] ? total[q] : prior[q];                      // > 0: every event has >= 1 sample
-                        const uint32_t m = lcg_mul(c_row[q], n < MULT_N ? L.jump[n] : lcg_jump2(P.pw, n));
-                        if (first[q]) {
-                            c_ev[q] = c_row[q];
-                            if (DIRECT) L.row[rank[q]] = m; else row[rank[q]] = m;               // global: plain store, merged in L2
-                        } else c_ev[q] = m;
+                        if (DIRECT) {
+                            const uint32_t n = first[q] ? total[q] : prior[q];                  // > 0: every event has >= 1 sample
+                            const uint32_t m = lcg_mul(c_row[q], n < MULT_N ? L.jump[n] : lcg_jump2(P.pw, n));
+                            if (first[q]) { c_ev[q] = c_row[q]; L.row[rank[q]] = m; }
+                            else c_ev[q] = m;
+                        } else if (first[q]) c_ev[q] = c_row[q];
+                        else c_ev[q] = lcg_mul(L.st[fid[q]], prior[q] < MULT_N ? L.jump[prior[q]] : lcg_jump2(P.pw, prior[q]));
                     }
                 }
             }
