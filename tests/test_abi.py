@@ -70,3 +70,26 @@ def test_product_does_not_reference_the_oracle():
                     if re.search(r"sqg_oracle|libsqg_oracle|import orc\b|from orc\b|oracle/", txt.replace("never touches oracle/", "")):
                         bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_header_is_plain_c_and_the_c_example_compiles(tmp_path):
+    """include/sqg.h is consumed by a C host (the reference is C): the example host loop must compile as C99 with
+    -pedantic and link against the library without any HIP/C++/torch header."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    build.build()
+    src = os.path.join(ROOT, "examples", "process_db_gpu.c")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           "-fsyntax-only", src])
+    libdir = os.path.dirname(build.LIB)
+    exe = str(tmp_path / "process_db_gpu")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-L", libdir, "-lsqg_hip",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    # without a GPU the program must fail loudly at sqg_create (no CPU fallback); with one it must run
+    r = subprocess.run([exe, "4"], capture_output=True, text=True)
+    if r.returncode == 0:
+        assert r.stdout.count("read ") == 4, r.stdout
+    else:
+        assert "sqg_create" in r.stderr, r.stderr
