@@ -69,6 +69,49 @@ def sample_reads(genome: bytes, n: int, rlen: int, rng: np.random.Generator):
     return out[:n]
 
 
+HG38_CHR_MB = [248, 242, 198, 190, 182, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57]
+
+
+def load_contigs(path):
+    out, cur = [], []
+    with open(path) as f:
+        for line in f:
+            if line.startswith(">"):
+                if cur:
+                    out.append("".join(cur).encode())
+                cur = []
+            else:
+                cur.append(line.strip())
+    if cur:
+        out.append("".join(cur).encode())
+    return out
+
+
+def synthetic_genome(total_mb: float, seed: int = 1):
+    """hg38 is not available offline: 24 contigs with hg38's chromosome proportions, i.i.d. uniform ACGT
+    from a fixed seed, a few N runs (telomere/centromere-like) to exercise the sampler's rejection rule."""
+    rng = np.random.default_rng(seed)
+    lut = np.frombuffer(b"ACGT", np.uint8)
+    scale = total_mb * 1e6 / (sum(HG38_CHR_MB) * 1e6)
+    contigs = []
+    for mb in HG38_CHR_MB:
+        n = max(int(mb * 1e6 * scale), 5000)
+        a = lut[rng.integers(0, 4, n, dtype=np.uint8)]
+        a[:min(1000, n // 50)] = ord("N")
+        mid = n // 3
+        a[mid:mid + min(3000, n // 20)] = ord("N")
+        contigs.append(a.tobytes())
+    return contigs
+
+
+WORKLOADS = {
+    # name: (profile, extra flags, sampler mode, description)
+    "ncov-r9": ("dna-r9-prom", 0, "dna", "nCoV-2019.reference.fasta -x dna-r9-prom (BASELINE.json configs[1])"),
+    "synth-r10": ("dna-r10-prom", 0, "dna", "synthetic hg38-proportioned genome -x dna-r10-prom (configs[2]/[3]; hg38 itself is not available offline)"),
+    "sequin-rna004": ("rna004-prom", profiles.SQ_PREFIX, "rna", "rnasequin_sequences_2.4.fa -x rna004-prom --prefix=yes, whole transcripts (configs[4])"),
+}
+
+
 def pack(reads):
     off = np.zeros(len(reads) + 1, np.int64)
     off[1:] = np.cumsum([len(r) for r in reads])
@@ -186,7 +229,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch-reads", type=int, default=8192, help="reads per step per GPU (= workers per GPU)")
     ap.add_argument("--rlen", type=int, default=10000)
-    ap.add_argument("--profile", default="dna-r9-prom")
+    ap.add_argument("--workload", default="ncov-r9", choices=sorted(WORKLOADS),
+                    help="ncov-r9 is the headline (BASELINE.json configs[1]); the others are the remaining configs, reported for information")
+    ap.add_argument("--genome-mb", type=float, default=64.0, help="size of the synthetic genome of --workload synth-r10")
+    ap.add_argument("--profile", default=None, help="override the workload's -x preset")
     ap.add_argument("--mode", default="certified", choices=["exact", "certified"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-sampler", action="store_true",
@@ -218,7 +264,11 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    wl_profile, wl_flags, wl_mode, wl_desc = WORKLOADS[args.workload]
+    if args.profile is None:
+        args.profile = wl_profile
     prof, flags = profiles.get_profile(args.profile)
+    flags |= wl_flags
     k = profiles.default_kmer_size(flags)
     n_k = 1 << (2 * k)
     # pore model: rank 0 owns it; RCCL broadcast to the other GPUs (the only collective on this path)
@@ -235,7 +285,13 @@ def main():
     gen = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=T, device=local_rank,
                               mode=api.MODE_EXACT if args.mode == "exact" else api.MODE_CERTIFIED,
                               worker_lo=w_lo, worker_hi=w_hi)
-    genome = load_genome(GENOME)
+    if args.workload == "synth-r10":
+        contigs = synthetic_genome(args.genome_mb)
+    elif args.workload == "sequin-rna004":
+        contigs = load_contigs(os.path.join(ROOT, "tests", "golden", "inputs", "rnasequin_sequences_2.4.fa"))
+    else:
+        contigs = [load_genome(GENOME)]
+    genome = contigs[0]
     rng = np.random.default_rng(42 + rank)
     workers = np.arange(w_lo, w_hi, dtype=np.int32)
 
@@ -248,7 +304,7 @@ def main():
     else:
         # the reads ARE the reference's: gen_read (src/genread.c) with `--seed 42 -r <rlen> -t T -K T` on the
         # resident genome, sampled on the device at staging time (outside the timed region)
-        gen.load_genome([genome], args.rlen, api.SAMPLE_DNA)
+        gen.load_genome(contigs, args.rlen, api.SAMPLE_RNA if wl_mode == "rna" else api.SAMPLE_DNA)
         for _ in range(nsteps):
             batches.append(gen.sample(K, workers))
 
@@ -305,9 +361,8 @@ def main():
             "dtype": "f64" if args.mode == "exact" else "f32+f64",
             "data": "synthetic",
             "config": {
-                "workload": f"nCoV-2019.reference.fasta -x {args.profile} --seed 42 -r {args.rlen}, "
-                            f"-t {T} -K {T} (T=K virtual workers, {K} per GPU), {args.steps} batches "
-                            f"(BASELINE.json configs[1], n~100000)",
+                "workload": f"{wl_desc}; -x {args.profile} --seed 42 -r {args.rlen}, "
+                            f"-t {T} -K {T} (T=K virtual workers, {K} per GPU), {args.steps} batches",
                 "reads_per_step_per_gpu": K, "kmer_size": k, "mode": args.mode,
                 "reads": "numpy draws of gen_read's distribution (host)" if args.host_sampler
                          else "gen_read on the device-resident genome (library sampler), as the reference with these options",
@@ -325,7 +380,9 @@ def main():
         }
         if not args.no_store_probe:
             out["roofline"]["measured_store_peak_GBps"] = gen.probe_store_bandwidth(1 << 30, 10) / 1e9
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.workload != "ncov-r9":
+            out["cpu_baseline"] = None                       # the CPU legs are set up for the headline workload only
+        elif not args.no_cpu_baseline:
             # the reference's own gensig.c/genread.c (oracle/_ref, kind "reference") when the harness travelled with the
             # repo, else the oracle restatement (kind "port"); the other one is reported next to it
             port = cpu_baseline(prof, flags, k, mean, stdv, genome, args.rlen)
