@@ -767,7 +767,7 @@ struct LeanWaveLds {
 };
 template <int EPL>
 struct LeanLds {
-    uint2 mult[MULT_N];                 // {a^(2j+1), a^(2j+2)}
+    uint32_t mult[MULT_N];              // a^(2j+1): the first draw of an event's sample j is state * mult[j]
     LeanWaveLds<EPL> w[4];
 };
 
@@ -788,7 +788,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
     __shared__ LeanLds<LEAN_EPL> L;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < MULT_N; i += 256) L.mult[i] = make_uint2(P.pw[i], P.pw[POW_N + i]);
+    for (int i = tid; i < MULT_N; i += 256) L.mult[i] = P.pw[i];
     __syncthreads();
     LeanWaveLds<LEAN_EPL>& W = L.w[wid];
     const float thr = P.thr_all;
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
             }                                                                                                     \
             idx8 += 512u;                                                                                         \
             voff = RNA ? voff - 128u : voff + 128u;                                                               \
-            MN = *reinterpret_cast<const uint2*>(mult_b + ((idx8 - (RN.y >> 16)) & 0xff8u)); }
+            MN = *reinterpret_cast<const uint32_t*>(mult_b + (((idx8 - (RN.y >> 16)) & 0xff8u) >> 1)); }
 
         /* ablation builds (tools/ab_variants.sh; results are wrong): -DSQG_ABL_NOARITH, -DSQG_ABL_NOSTORE, -DSQG_ABL_NOLOOP */
 #if defined(SQG_ABL_NOSTORE)
@@ -914,15 +914,15 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         #define LEAN_STORE_COND
 #endif
 #if defined(SQG_ABL_NOARITH)
-        #define LEAN_ARITH(RA, MU) const uint32_t c1 = (RA.x ^ MU.x) & 0x3fffffffu; const float x = __uint_as_float((RA.x + MU.y) & 0x3fffffffu);
+        #define LEAN_ARITH(RA, MU) const uint32_t c1 = (RA.x ^ MU) & 0x3fffffffu; const float x = __uint_as_float((RA.x + MU) & 0x3fffffffu);
 #else
-        #define LEAN_ARITH(RA, MU) const uint32_t c1 = lcg_mul(RA.x, MU.x); const float x = box_muller_fast(c1);
+        #define LEAN_ARITH(RA, MU) const uint32_t c1 = lcg_mul(RA.x, MU); const float x = box_muller_fast(c1);
 #endif
-        uint4 ra, rb; uint2 ma, mb; int eva, evb;
+        uint4 ra, rb; uint32_t ma, mb; int eva, evb;
         base_ev = 0;
         LEAN_MAP(0, eva)
         ra = W.rec[eva];
-        ma = *reinterpret_cast<const uint2*>(mult_b + ((idx8 - (ra.y >> 16)) & 0xff8u));
+        ma = *reinterpret_cast<const uint32_t*>(mult_b + (((idx8 - (ra.y >> 16)) & 0xff8u) >> 1));
         int c = 0;
         for (; c + 2 <= nfull; c += 2) {
             LEAN_STEP(false, c, ra, ma, eva, rb, mb, evb)
