@@ -3,7 +3,8 @@
     python -m squigulator_amd.build          # -> squigulator_amd/csrc/libsqg_hip.so
 
 hipcc cross-compiles gfx950 code objects without a GPU, so this also runs in the CPU-only
-build container.  -ffp-contract=off: the FP64 path must round x*s+m twice like the reference
+build container.  -fno-slp-vectorize: the SLP pass pairs the two events a k_events thread handles into v_pk_* ops that need
+s_nop padding on gfx950 and measure 6 % slower.  -ffp-contract=off: the FP64 path must round x*s+m twice like the reference
 (which is built with gcc -std=c99, no FMA contraction; see DESIGN.md "Exact arithmetic").
 """
 from __future__ import annotations
@@ -39,7 +40,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-Wall", "-Wno-unused-result", "-o", LIB] + SOURCES
+           "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-result", "-o", LIB] + SOURCES
     if verbose:
         print("[squigulator_amd.build]", " ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
