@@ -314,8 +314,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    iso_lean_ms = []                  # warm-up batches run one at a time: the sample kernel alone on the machine
     for b in batches[:args.warmup]:
         b.run().wait()
+        iso_lean_ms.append(gen.timing()["lean_ms"])
     sync_all()
     t0 = time.perf_counter()
     sig_ms, dwell_ms, ev_ms, lean_ms = [], [], [], []
@@ -376,6 +378,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S,
                          "traffic": pmc_traffic(args.profile, K, args.rlen, args.mode),
+                         # with SQG_OVERLAP=1 the next batch's k_events runs next to this kernel and stretches it; the
+                         # warm-up batches run one at a time and give the kernel's duration alone on the machine
+                         "kernel_ms": k_ms,
+                         "kernel_ms_warmup": (iso_lean_ms[-1] if iso_lean_ms and iso_lean_ms[-1] > 0 else None),
+                         "streams": 2 if os.environ.get("SQG_OVERLAP") else 1,
                          "kernel": "k_samples_lean" if args.mode == "certified" else "k_samples<exact>", "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_store_probe:

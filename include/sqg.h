@@ -96,8 +96,10 @@ typedef struct sqg_ctx sqg_ctx_t;
 typedef struct sqg_batch sqg_batch_t;
 
 /* per-batch results; host arrays are owned by the batch and stay valid until
- * sqg_batch_free(); device pointers stay valid until the NEXT sqg_batch_run on
- * the same context (outputs live in context-owned HBM slabs that are reused) */
+ * sqg_batch_free(); device pointers (and sqg_fetch_*) stay valid until TWO more
+ * batches have been run on the same context: outputs live in two context-owned
+ * sets of HBM slabs used alternately (sqg_batch_run is asynchronous and batches
+ * can be queued back to back; sqg_batch_wait waits for that batch only) */
 typedef struct {
     int32_t n_reads;
     int64_t n_events;           /* k-mer events incl. prefix/stall events                    */
