@@ -176,3 +176,35 @@ def test_paf_sam_goldens_from_device_dwell():
             if kind in exp:
                 with gzip.open(os.path.join(exp_dir, exp[kind] + ".gz"), "rt") as f:
                     assert text == f.read(), f"{cid}: {kind}"
+
+
+@pytest.mark.gpu
+def test_batches_queued_back_to_back_keep_their_results():
+    """Double-buffered slots: batch i can be fetched after batch i+1 has been run (not after i+2), batches run without
+    intermediate waits equal the oracle, and waiting out of order is fine."""
+    import orc
+    from squigulator_amd import model, profiles
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    mean, stdv = model.synthetic_model(6)
+    rng = np.random.default_rng(3)
+    T = 6
+    batches = [[bytes(rng.choice(list(b"ACGT"), int(n)).astype(np.uint8)) for n in rng.integers(30, 900, T)] for _ in range(4)]
+    orac = orc.Oracle(prof, fl, 6, mean, stdv, 99, num_workers=T)
+    want = [orac.run_batch_seqs(bt) for bt in batches]
+    gen = api.SignalGenerator(prof, fl, 6, mean, stdv, 99, num_workers=T, mode=api.MODE_CERTIFIED)
+    hs = [gen.stage(bt) for bt in batches]
+    hs[0].run(); hs[1].run()                       # two in flight
+    hs[1].wait(); hs[0].wait()                     # out of order
+    s0, s1 = hs[0].signal(), hs[1].signal()        # batch 0 is still there after batch 1 ran
+    hs[2].run(); hs[3].run()
+    with pytest.raises(api.SqgError) as e:         # ... but not after batch 2 reused its slot
+        hs[0].signal()
+    assert e.value.code == -4
+    hs[3].wait(); hs[2].wait()
+    sigs = [s0, s1, hs[2].signal(), hs[3].signal()]
+    for bi in range(4):
+        for i, w in enumerate(want[bi]):
+            np.testing.assert_array_equal(sigs[bi][hs[bi].sig_off[i]:hs[bi].sig_off[i + 1]], w.sig, err_msg=f"batch {bi} read {i}")
+    for h in hs:
+        h.free()
+    gen.close(); orac.close()
