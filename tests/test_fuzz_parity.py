@@ -1,0 +1,56 @@
+"""Randomised parity: the HIP path (both arithmetic modes) against the oracle on random profiles, option flags, k-mer
+sizes, worker counts, seeds and ragged batches -- several batches per context, so that the carried stream states,
+the lean/generic split, every dwell regime and the segment tails of k_events are all exercised.  Bit-exact."""
+import numpy as np
+import pytest
+
+import orc
+from squigulator_amd import api, model, profiles
+
+FLAG_SETS = [0, profiles.SQ_PREFIX, profiles.SQ_RNA, profiles.SQ_RNA | profiles.SQ_PREFIX, profiles.SQ_IDEAL_TIME,
+             profiles.SQ_IDEAL_AMP, profiles.SQ_IDEAL, profiles.SQ_RNA | profiles.SQ_PREFIX | profiles.SQ_IDEAL_TIME]
+
+
+def _case(seed):
+    rng = np.random.default_rng(1000 + seed)
+    base, _ = profiles.get_profile(["dna-r9-prom", "dna-r9-min", "rna-r9-prom", "dna-r10-prom", "rna004-prom"][seed % 5])
+    dwell_mean = float(rng.choice([2.0, 5.0, 9.0, 13.0, 31.0, 43.0, 120.0, 600.0]))
+    dwell_std = float(rng.choice([0.0, 0.5, 4.0, dwell_mean * 0.8])) if seed % 7 else 0.0
+    prof = base.replace(dwell_mean=dwell_mean, dwell_std=dwell_std,
+                        offset_mean=base.offset_mean + float(rng.normal(0, 30)),
+                        offset_std=float(rng.choice([0.0, 5.0, 20.0])),
+                        range=base.range * float(rng.uniform(0.5, 2.0)))
+    flags = FLAG_SETS[int(rng.integers(0, len(FLAG_SETS)))]
+    k = int(rng.choice([5, 6, 6, 9]))
+    T = int(rng.integers(1, 9))
+    amp = float(rng.choice([1.0, 1.0, 0.3, 2.5]))
+    nb = int(rng.integers(1, 4))
+    batches = []
+    for _ in range(nb):
+        n = int(rng.integers(1, 2 * T + 2))
+        lens = rng.choice([1, 3, k - 1, k, k + 1, 63, 64, 65, 200, 511, 512, 513, 1025, 3000], n)
+        batches.append([bytes(rng.choice(list(b"ACGTacgtNRY"), int(m), p=[.22, .22, .22, .22, .02, .02, .02, .02, .02, .01, .01]).astype(np.uint8))
+                        for m in lens])
+    return prof, flags, k, T, amp, int(rng.integers(1, 1 << 30)), batches
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configuration_matches_oracle(seed):
+    prof, flags, k, T, amp, s, batches = _case(seed)
+    mean, stdv = model.synthetic_model(k, salt=seed)
+    orac = orc.Oracle(prof, flags, k, mean, stdv, s, num_workers=T, amp_noise=amp)
+    want = [orac.run_batch_seqs(bt) for bt in batches]
+    orac.close()
+    for mode in (api.MODE_CERTIFIED, api.MODE_EXACT):
+        gen = api.SignalGenerator(prof, flags, k, mean, stdv, s, num_workers=T, amp_noise=amp, mode=mode)
+        for bi, bt in enumerate(batches):
+            b = gen.submit(bt)
+            sig, dw = b.signal(), b.dwell()
+            for i, w in enumerate(want[bi]):
+                np.testing.assert_array_equal(sig[b.sig_off[i]:b.sig_off[i + 1]], w.sig,
+                                              err_msg=f"seed {seed} mode {mode} batch {bi} read {i} (k={k} T={T} flags={flags:#x} dwell={prof.dwell_mean}/{prof.dwell_std})")
+                np.testing.assert_array_equal(dw[b.ev_off[i]:b.ev_off[i + 1]], w.ss)
+                assert b.offset[i] == w.offset and b.median_before[i] == w.median_before
+            b.free()
+        gen.close()
