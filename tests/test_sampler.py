@@ -88,3 +88,24 @@ def test_rna_sampler_matches_oracle(name, oflags, mode, tc):
 @pytest.mark.gpu
 def test_cdna_sampler_matches_oracle():
     _run("dna-r9-prom", 6, SEQUIN, 5, [5, 5], rlen=10000, oflags=0x200, mode=api.SAMPLE_CDNA, trans_count=SEQUIN_TC)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_random_genomes(seed, tmp_path):
+    """Random contig sets (tiny contigs that force clipping and <200-nt rejections, N runs, lower case), read lengths,
+    worker counts and batch sizes."""
+    rng = np.random.default_rng(500 + seed)
+    contigs = []
+    for _ in range(int(rng.integers(1, 12))):
+        n = int(rng.choice([210, 260, 400, 1500, 6000, 20000]))
+        a = rng.choice(list(b"ACGTacgtRYN"), n, p=[.23, .23, .23, .23, .01, .01, .01, .01, .01, .01, .02]).astype(np.uint8)
+        if rng.random() < 0.5:
+            q = int(rng.integers(0, max(n - 50, 1)))
+            a[q:q + int(rng.integers(5, 120))] = ord("N")
+        contigs.append(bytes(a))
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(f">c{i}\n{c.decode()}\n" for i, c in enumerate(contigs)))
+    T = int(rng.integers(1, 9))
+    batches = [int(rng.integers(1, 2 * T + 1)) for _ in range(3)]
+    _run("dna-r9-prom", 6, str(fa), T, batches, rlen=int(rng.choice([300, 1000, 5000])), seed=int(rng.integers(1, 1 << 20)))
