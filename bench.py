@@ -134,8 +134,9 @@ def pmc_traffic(profile, batch_reads, rlen, mode):
     return None
 
 
-def cpu_baseline(prof, flags, k, mean, stdv, genome, rlen, target_cpu_seconds=20.0):
-    """Oracle (oracle/libsqg_oracle.so) on the host cores, T=K regime, bounded sample."""
+def cpu_baseline(prof, flags, k, mean, stdv, genome, rlen, target_cpu_seconds=20.0, check_mode=None):
+    """Oracle (oracle/libsqg_oracle.so) on the host cores, T=K regime, bounded sample.  With check_mode the same
+    reads also go through the HIP path and every int16 is compared (the oracle as the checker): `parity`."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ctypes
     import orc
@@ -169,9 +170,22 @@ def cpu_baseline(prof, flags, k, mean, stdv, genome, rlen, target_cpu_seconds=20
     dt = time.perf_counter() - t0
     o.close()
     ns = sum(len(r.sig) for r in res)
-    return {"value": ns / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{n} reads / {ns} samples of the same workload, generation only (no BLOW5 encode), "
-                      f"-t {n} -K {n} on {cores} host threads, {dt:.2f} s wall"}
+    out = {"value": ns / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": f"{n} reads / {ns} samples of the same workload, generation only (no BLOW5 encode), "
+                     f"-t {n} -K {n} on {cores} host threads, {dt:.2f} s wall"}
+    if check_mode is not None:
+        # the very same reads, seed and workers through the C ABI: bit-for-bit comparison of the whole sample
+        gen = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=n, mode=check_mode)
+        b = gen.submit(reads)
+        sig = b.signal()
+        bad = 0
+        for i, r in enumerate(res):
+            got = sig[b.sig_off[i]:b.sig_off[i + 1]]
+            if len(got) != len(r.sig) or not np.array_equal(got, r.sig):
+                bad += 1
+        out["parity"] = {"reads": n, "samples": int(ns), "reads_differing": bad, "equal": bad == 0 and int(b.n_samples) == int(ns)}
+        b.free(); gen.close()
+    return out
 
 
 def cpu_reference(prof, flags, k, mean, stdv, nproc, reads_per_proc=24, rlen=10000):
@@ -392,7 +406,9 @@ def main():
         elif not args.no_cpu_baseline:
             # the reference's own gensig.c/genread.c (oracle/_ref, kind "reference") when the harness travelled with the
             # repo, else the oracle restatement (kind "port"); the other one is reported next to it
-            port = cpu_baseline(prof, flags, k, mean, stdv, genome, args.rlen)
+            port = cpu_baseline(prof, flags, k, mean, stdv, genome, args.rlen,
+                                check_mode=api.MODE_EXACT if args.mode == "exact" else api.MODE_CERTIFIED)
+            out["parity_check"] = port.pop("parity", None)
             ref = cpu_reference(prof, flags, k, mean, stdv, nproc=min(os.cpu_count() or 1, 128), reads_per_proc=150)
             out["cpu_baseline"] = ref or port
             if ref:
