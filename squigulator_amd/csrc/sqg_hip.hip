@@ -16,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sqg.h"
@@ -376,9 +377,13 @@ extern "C" void sqg_batch_free(sqg_ctx_t* ctx, sqg_batch_t* b) {
 
 // Staging shared by sqg_batch_stage (reads come from the host: seqs != null) and sqg_batch_sample (reads were
 // sampled on the device: seqs == null, d_rec holds one SampleRec per read and k_copy_reads fills the base buffer).
+#include <chrono>
 static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t* seq_off,
                         const int32_t* worker, const SampleRec* d_rec, sqg_batch_t** out) {
     *out = nullptr;
+    static const bool st_on = getenv("SQG_STAGE_TIMING") != nullptr;
+    auto st_t0 = std::chrono::steady_clock::now();
+    auto st_mark = [&](const char* what) { if (st_on) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[stage] %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - st_t0).count()); st_t0 = t; } };
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const sqg_profile_t& p = c->cfg.profile;
     const bool rna = c->cfg.flags & SQG_RNA, prefix = c->cfg.flags & SQG_PREFIX;
@@ -433,6 +438,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         for (int t = rd[(size_t)i].tile_off; t < t1; t++) tile_read[(size_t)t] = i;
     }
 
+    st_mark("descriptors+tiles");
     // pass 2: base buffer (prefix/stall attached as src/genread.c:95-123 does)
     std::vector<uint8_t> hb(seqs ? (size_t)nb + 16 : 0, (uint8_t)'A');
     for (int i = 0; seqs && i < n; i++) {
@@ -459,6 +465,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         if (d.len1) memcpy(dst + d.len0, kStallRna, (size_t)d.len1);
     }
 
+    st_mark("base buffer");
     // pass 3: per-worker chains in batch order; host-side scalar streams advance in that order
     std::vector<int> count((size_t)c->nw, 0);
     for (int i = 0; i < n; i++) count[(size_t)wk[(size_t)i]]++;
@@ -477,21 +484,38 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     std::stable_sort(chain_order.begin(), chain_order.end(), [&](int x, int y) { return chain_ev[(size_t)x] > chain_ev[(size_t)y]; });
 
     const uint32_t a2 = lcg_mul(LCG_A, LCG_A);
-    for (int i = 0; i < n; i++) {                         // index order == per-worker order within a worker
-        ReadDesc& d = rd[(size_t)i];
-        const size_t w = (size_t)d.worker;
-        if (c->cfg.flags & SQG_IDEAL) {                   // src/gensig.c:311-313
-            d.offset = p.offset_mean; b->median[(size_t)i] = p.median_before_mean;
-        } else {                                          // src/gensig.c:315-316
-            d.offset = host_nrng(p.offset_mean, p.offset_std, &c->off_x[w]);
-            b->median[(size_t)i] = host_nrng(p.median_before_mean, p.median_before_std, &c->med_x[w]);
+    const bool no_lean = getenv("SQG_TEST_NO_LEAN") != nullptr;
+    // the per-read scalar draws (host libm, so that `offset` / `median_before` are the doubles the CPU reference prints):
+    // chains are independent, a few host threads share them
+    auto chain_range = [&](int q_lo, int q_hi) {
+        for (int q = q_lo; q < q_hi; q++)
+            for (int ci = chain_off[(size_t)q]; ci < chain_off[(size_t)q + 1]; ci++) {   // batch order within the worker
+                const int i = chain_reads[(size_t)ci];
+                ReadDesc& d = rd[(size_t)i];
+                const size_t w = (size_t)d.worker;
+                if (c->cfg.flags & SQG_IDEAL) {                   // src/gensig.c:311-313
+                    d.offset = p.offset_mean; b->median[(size_t)i] = p.median_before_mean;
+                } else {                                          // src/gensig.c:315-316
+                    d.offset = host_nrng(p.offset_mean, p.offset_std, &c->off_x[w]);
+                    b->median[(size_t)i] = host_nrng(p.median_before_mean, p.median_before_std, &c->med_x[w]);
+                }
+                b->offset[(size_t)i] = d.offset;
+                d.fast = (c->cfg.mode == SQG_MODE_CERTIFIED && c->use_kmer_streams && c->dwell_hi <= (double)MULT_N && !no_lean &&
+                          c->amp_floor - d.offset > 4.0 && c->amp_ceil - d.offset < 65000.0) ? 1 : 0;
+                d.time_c0 = c->time_c[w];
+                if (c->use_dwell_stream)                          // two draws per event (src/gensig.c:255)
+                    c->time_c[w] = lcg_mul(c->time_c[w], lcg_pow(a2, (unsigned long long)(d.ne0 + d.ne1)));
+            }
+    };
+    {
+        const int nth = (b->n_chains >= 1024) ? (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        if (nth <= 1) chain_range(0, b->n_chains);
+        else {
+            std::vector<std::thread> th;
+            const int per = (b->n_chains + nth - 1) / nth;
+            for (int t = 0; t < nth; t++) th.emplace_back(chain_range, std::min(t * per, b->n_chains), std::min((t + 1) * per, b->n_chains));
+            for (auto& t : th) t.join();
         }
-        b->offset[(size_t)i] = d.offset;
-        d.fast = (c->cfg.mode == SQG_MODE_CERTIFIED && c->use_kmer_streams && c->dwell_hi <= (double)MULT_N && !getenv("SQG_TEST_NO_LEAN") &&
-                  c->amp_floor - d.offset > 4.0 && c->amp_ceil - d.offset < 65000.0) ? 1 : 0;
-        d.time_c0 = c->time_c[w];
-        if (c->use_dwell_stream)                          // two draws per event (src/gensig.c:255)
-            c->time_c[w] = lcg_mul(c->time_c[w], lcg_pow(a2, (unsigned long long)(d.ne0 + d.ne1)));
     }
     if (!c->use_dwell_stream) {                           // constant dwell: lengths are known now
         const unsigned long long sps = (unsigned long long)(int)p.dwell_mean;
@@ -511,6 +535,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         }
     }
 
+    st_mark("chains+streams+blocks");
     auto bail = [&](int code) { sqg_batch_free(c, b); return code; };
 #define CHKB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE); } } while (0)
     CHKB(hipMalloc(&b->d_bases, (size_t)nb + 16));
@@ -541,7 +566,9 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     CHKB(hipHostMalloc(&b->h_sigoff, ((size_t)n + 1) * sizeof(long long), hipHostMallocMapped));
     CHKB(hipHostGetDevicePointer((void**)&b->h_sigoff_dev, b->h_sigoff, 0));
     for (auto& e : b->ev) CHKB(hipEventCreate(&e));
+    st_mark("mallocs+enqueue");
     CHKB(hipStreamSynchronize(c->stream));     // staging buffers above are stack-owned
+    st_mark("sync");
 #undef CHKB
     c->next_stage++;
     *out = b;
@@ -634,7 +661,7 @@ extern "C" int sqg_batch_sample(sqg_ctx_t* c, int32_t n, const int32_t* worker, 
         CHKS(hipMemcpyAsync(d_co, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         CHKS(hipMemcpyAsync(d_cr, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
         CHKS(hipMemcpyAsync(d_cw, chain_worker.data(), chain_worker.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_sample, dim3((unsigned)((n_chains + 63) / 64)), dim3(64), 0, c->stream, c->genome, c->d_samp, d_co, d_cr, d_cw,
+        hipLaunchKernelGGL(k_sample, dim3((unsigned)n_chains), dim3(64), 0, c->stream, c->genome, c->d_samp, d_co, d_cr, d_cw,
                            n_chains, d_rec, c->d_err);
         CHKS(hipGetLastError());
         CHKS(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(SampleRec), hipMemcpyDeviceToHost, c->stream));

@@ -1198,25 +1198,28 @@ __global__ void k_init_sampler(uint32_t* __restrict__ st, long long seed, int wo
 // rng() of src/rand.h:79-85 on a canonical state
 __device__ static inline double samp_rng(uint32_t& c) { c = lcg_mul(c, LCG_A); return lcg_uniform(c); }
 
-// exact count of bytes equal to 'N' in p[0..n)
-__device__ static inline int count_N(const uint8_t* __restrict__ p, int n) {
-    int cnt = 0, i = 0;
-    for (; i + 8 <= n; i += 8) {
+// exact count of bytes equal to 'N' in p[0..n), by the 64 lanes of a wavefront together (8 bytes per lane per step)
+__device__ static inline int count_N(const uint8_t* __restrict__ p, int n, int lane) {
+    int cnt = 0;
+    const int n8 = n & ~7;
+    for (int i = lane * 8; i < n8; i += 512) {
         unsigned long long v;
         __builtin_memcpy(&v, p + i, 8);
         const unsigned long long x = v ^ 0x4e4e4e4e4e4e4e4eull;        // zero byte <=> 'N'
         const unsigned long long t = ~(((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x | 0x7f7f7f7f7f7f7f7full);
         cnt += __popcll(t);
     }
-    for (; i < n; i++) cnt += p[i] == 'N';
+    if (lane < n - n8) cnt += p[n8 + lane] == 'N';
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     return cnt;
 }
 
-// one thread per worker chain: that worker's reads of the batch, in order
+// one wavefront per worker chain (that worker's reads of the batch, in order): every lane makes the same draws, the
+// lanes share the scan of the candidate for 'N's
 __global__ __launch_bounds__(64) void k_sample(const GenomeParams G, uint32_t* __restrict__ st, const int* __restrict__ chain_off,
                                                const int* __restrict__ chain_reads, const int* __restrict__ chain_worker,
                                                int n_chains, SampleRec* __restrict__ out, unsigned int* __restrict__ err) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = blockIdx.x, lane = threadIdx.x;
     if (ch >= n_chains) return;
     const int w = chain_worker[ch];
     uint32_t c_pos = st[3 * w], c_strand = st[3 * w + 1], c_len = st[3 * w + 2];
@@ -1262,15 +1265,15 @@ __global__ __launch_bounds__(64) void k_sample(const GenomeParams G, uint32_t* _
             const int n = min(len, clen - pos);                       // src/genread.c:149-177: clipped at the contig's end
             if (n < 200) continue;                                    // src/genread.c:126
             const long long src = G.contig_off[idx] + pos;
-            const int nN = count_N(G.seq + src, n);
+            const int nN = count_N(G.seq + src, n, lane);
             if ((double)nN > 0.1 * (double)n) continue;               // src/genread.c:139-142
             rec.src = src; rec.ref_idx = idx; rec.ref_pos = pos; rec.rlen = n; rec.strand = strand; rec.n_N = nN;
             rec.ref_len = (G.flags & (SQG_SAMPLE_RNA | SQG_SAMPLE_CDNA)) ? len : clen;
             break;
         }
-        out[chain_reads[ci]] = rec;
+        if (lane == 0) out[chain_reads[ci]] = rec;
     }
-    st[3 * w] = c_pos; st[3 * w + 1] = c_strand; st[3 * w + 2] = c_len;
+    if (lane == 0) { st[3 * w] = c_pos; st[3 * w + 1] = c_strand; st[3 * w + 2] = c_len; }
 }
 
 __device__ static const char kd_stall_dna[] = "TTTTTTTTTTTTTTTTTTAATCAA";                       // src/genread.c:110
