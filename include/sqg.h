@@ -204,6 +204,12 @@ int  sqg_batch_sample(sqg_ctx_t *ctx, int32_t n_reads, const int32_t *worker, sq
 /* the sampled reads as gen_read returned them (after N substitution and revcomp), for the FASTA/SAM writers */
 int  sqg_fetch_reads(sqg_ctx_t *ctx, sqg_batch_t *b, char *dst /* seq_off[n_reads] bytes */);
 
+/* Page-locked host memory for the sqg_fetch_* destinations: the D2H copy of a batch's signal (2 B/sample, or ~1.3
+ * with sqg_batch_compress) is what bounds a host that consumes the output (Measurement); into pinned
+ * memory it runs at the link rate instead of through a staging buffer.  Plain malloc'd destinations keep working. */
+void *sqg_host_alloc(size_t bytes);
+void  sqg_host_free(void *p);
+
 /* HBM streaming-store probe used by bench.py to state the measured write
  * ceiling next to the 8 TB/s spec figure: writes `bytes` of int16 `iters`
  * times and returns the average milliseconds per pass. */

@@ -76,7 +76,8 @@ SAMPLE_DNA, SAMPLE_RNA, SAMPLE_CDNA, SAMPLE_TRUNC = 0, 1, 2, 4
 EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_device_count",
            "sqg_batch_stage", "sqg_batch_run", "sqg_batch_wait", "sqg_fetch_signal", "sqg_fetch_dwell",
            "sqg_batch_free", "sqg_get_timing", "sqg_submit", "sqg_worker_of", "sqg_probe_store_bandwidth",
-           "sqg_batch_compress", "sqg_fetch_svb", "sqg_genome_load", "sqg_batch_sample", "sqg_fetch_reads")
+           "sqg_batch_compress", "sqg_fetch_svb", "sqg_genome_load", "sqg_batch_sample", "sqg_fetch_reads",
+           "sqg_host_alloc", "sqg_host_free")
 
 _lib = None
 
@@ -131,6 +132,10 @@ def load_library(path: str | None = None):
     L.sqg_batch_sample.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(vp), C.POINTER(CSample)]
     L.sqg_fetch_reads.restype = C.c_int
     L.sqg_fetch_reads.argtypes = [vp, vp, vp]
+    L.sqg_host_alloc.restype = vp
+    L.sqg_host_alloc.argtypes = [C.c_size_t]
+    L.sqg_host_free.restype = None
+    L.sqg_host_free.argtypes = [vp]
     if path == _build.LIB:
         _lib = L
     return L
@@ -159,10 +164,12 @@ class Batch:
         self.median_before = np.ctypeslib.as_array(r.median_before, shape=(n,)).copy() if n else np.zeros(0)
         return self
 
-    def signal(self) -> np.ndarray:
-        out = np.empty(self.n_samples, np.int16)
+    def signal(self, out: np.ndarray | None = None) -> np.ndarray:
+        """int16 samples of the batch; `out` may be (a view of) a pinned buffer from SignalGenerator.pinned()."""
+        if out is None:
+            out = np.empty(self.n_samples, np.int16)
         self.gen._chk(self.gen.L.sqg_fetch_signal(self.gen.ctx, self.handle, out.ctypes.data), "sqg_fetch_signal")
-        return out
+        return out[:self.n_samples]
 
     def dwell(self) -> np.ndarray:
         out = np.empty(self.n_events, np.int32)
@@ -177,7 +184,7 @@ class Batch:
         raw = buf.tobytes()
         return [raw[off[i]:off[i + 1]] for i in range(self.n_reads)]
 
-    def compress(self, fetch=True):
+    def compress(self, fetch=True, out: np.ndarray | None = None):
         """svb-zd encodings of the batch's signals (slow5lib's signal compression), made on the device.
         Returns (bytes as uint8 array, offsets[n_reads+1]); fetch=False leaves the bytes on the device."""
         r = CSvb()
@@ -185,7 +192,7 @@ class Batch:
         off = np.ctypeslib.as_array(r.svb_off, shape=(self.n_reads + 1,)).copy()
         if not fetch:
             return None, off
-        out = np.empty(r.n_bytes, np.uint8)
+        out = np.empty(r.n_bytes, np.uint8) if out is None else out[:r.n_bytes]
         self.gen._chk(self.gen.L.sqg_fetch_svb(self.gen.ctx, self.handle, out.ctypes.data), "sqg_fetch_svb")
         return out, off
 
@@ -292,6 +299,16 @@ class SignalGenerator:
                          seq_off=np.ctypeslib.as_array(info.seq_off, shape=(n + 1,)).copy())
         return b
 
+    def pinned(self, nbytes: int, dtype=np.uint8) -> np.ndarray:
+        """A page-locked host array (sqg_host_alloc) for fast sqg_fetch_* destinations; freed with the generator."""
+        p = self.L.sqg_host_alloc(nbytes)
+        if not p:
+            raise MemoryError("sqg_host_alloc")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        buf = (C.c_uint8 * nbytes).from_address(p)
+        return np.frombuffer(buf, dtype=dtype)
+
     def timing(self):
         t = CTiming()
         self._chk(self.L.sqg_get_timing(self.ctx, C.byref(t)), "sqg_get_timing")
@@ -305,6 +322,9 @@ class SignalGenerator:
 
     def close(self):
         if self.ctx:
+            for p in getattr(self, "_pinned", []):
+                self.L.sqg_host_free(p)
+            self._pinned = []
             self.L.sqg_destroy(self.ctx)
             self.ctx = None
 

@@ -1010,6 +1010,14 @@ extern "C" int sqg_fetch_svb(sqg_ctx_t* c, sqg_batch_t* b, uint8_t* dst) {
     return SQG_OK;
 }
 
+extern "C" void* sqg_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void sqg_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 extern "C" int sqg_probe_store_bandwidth(sqg_ctx_t* c, size_t bytes, int iters, float* ms_per_pass) {
     if (!c || !ms_per_pass || iters < 1 || bytes < 4096) return SQG_EINVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
