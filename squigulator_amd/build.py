@@ -18,7 +18,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsqg_hip.so")
 SOURCES = [os.path.join(CSRC, "sqg_hip.hip")]
-HEADERS = [os.path.join(os.path.dirname(HERE), "include", "sqg.h"), os.path.join(CSRC, "sqg_kernels.h")]
+HEADERS = [os.path.join(os.path.dirname(HERE), "include", "sqg.h")] + \
+          [os.path.join(CSRC, h) for h in ("sqg_kernels.h", "k_common.h", "k_events.h", "k_samples.h", "k_sampler.h", "k_svb.h")]
 ARCH = "gfx950"
 
 

@@ -1,0 +1,178 @@
+// k_common.h -- constants, the Lehmer generator in canonical form, Box-Muller (FP64 and certified fp32), descriptors
+// Part of the device code of the per-read signal path; included through sqg_kernels.h (see there for the overview).
+#pragma once
+
+#define LCG_M 2147483647u
+#define LCG_A 16807u
+
+#define POW_N 1024          // entries per jump table
+// d_pow layout (uint32 each):
+//   [0*POW_N + j] = a^(2j+1)   first draw of sample/event j after a base state
+//   [1*POW_N + j] = a^(2j+2)   second draw
+//   [2*POW_N + j] = a^(2j)     jump over j draws-pairs
+//   [3*POW_N + j] = a^(2*1024*j)
+//   [4*POW_N + j] = a^(2*1024*1024*j)
+#define POW_TABLES 5
+
+#define NEAR_ONE_BITS 17    // c1 > M - 2^17 (u within 6e-5 of 1): always taken to the FP64 path
+
+// ---- MINSTD in canonical form: c' = a*c mod (2^31-1), c in [1, M-1] -------------------------
+__host__ __device__ static inline uint32_t lcg_mul(uint32_t a, uint32_t b) {
+    const unsigned long long p = (unsigned long long)a * b;
+    uint32_t r = (uint32_t)(p & LCG_M) + (uint32_t)(p >> 31);
+    r = (r & LCG_M) + (r >> 31);
+    return r;
+}
+// same product, result only reduced to [0, 2^32) (congruent mod M): enough for the cosine argument
+__device__ static inline uint32_t lcg_mul_lazy(uint32_t a, uint32_t b) {
+    const unsigned long long p = (unsigned long long)a * b;
+    return (uint32_t)(p & LCG_M) + (uint32_t)(p >> 31);
+}
+
+// a^(2n) for n < 2^30 from three table levels
+__device__ static inline uint32_t lcg_jump2(const uint32_t* __restrict__ pw, uint32_t n) {
+    uint32_t r = pw[2 * POW_N + (n & (POW_N - 1))];
+    const uint32_t hi = (n >> 10) & (POW_N - 1), hi2 = n >> 20;
+    if (hi) r = lcg_mul(r, pw[3 * POW_N + hi]);
+    if (hi2) r = lcg_mul(r, pw[4 * POW_N + hi2]);
+    return r;
+}
+
+// (double)x/2147483647 with the reference's corrected state (src/rand.h:82-84)
+__device__ static inline double lcg_uniform(uint32_t c) {
+    return (double)(c ? c : LCG_M) / 2147483647.0;
+}
+
+// nrng body, src/rand.h:87-94, for two consecutive draws c1, c2 (FP64, no contraction)
+__device__ static inline double box_muller_exact(uint32_t c1, uint32_t c2) {
+    const double u = lcg_uniform(c1);
+    const double t = (2.0 * 3.14159265) * lcg_uniform(c2);
+    return sqrt(-2.0 * log(u)) * cos(t);
+}
+
+// fp32 evaluation of the same deviate from the canonical first draw c1 (the second one is a function of it).
+// v_log_f32 is log2, v_cos_f32 takes turns.  The 6.2831853-vs-2*pi ratio (1 - 1.1e-9) is below fp32
+// resolution; the sweep (k_certify) prices it with everything else.
+__device__ static inline float box_muller_fast(uint32_t c1) {
+    const float uf = (float)c1 * 4.656612873077393e-10f;                  // c1 * 2^-31 (exact scaling)
+    const float lg = __builtin_amdgcn_logf(uf);
+    const float y = __builtin_fmaf(lg, -1.3862943611198906f, -9.313225750491594e-10f);   // -2 ln(c1/M)
+    const float r = __builtin_amdgcn_sqrtf(y);
+    // second uniform c2/M = frac(a*c1/M): four full-rate FP64/convert instructions instead of a modular
+    // multiplication plus an int->float conversion (the product is exact to 2^-39, far below fp32 resolution)
+    const double t2 = (double)c1 * (16807.0 / 2147483647.0);                // a / M
+    const float cs = __builtin_amdgcn_cosf((float)__builtin_amdgcn_fract(t2));
+    return r * cs;
+}
+
+// dwell draw in FP64 (src/gensig.c:255), kept out of line: it is taken for ~4e-5 of the events and must not
+// set the register budget of the kernels that call it
+__device__ __attribute__((noinline)) static int dwell_exact(uint32_t c1, double dstd, double dmean) {
+    const double z = box_muller_exact(c1, lcg_mul(c1, LCG_A));
+    return (int)round((z * dstd) + dmean);
+}
+
+// (int16_t)double as gcc/x86-64 lowers it (cvttsd2si r32, low half): src/gensig.c:270
+__device__ static inline int16_t to_i16(double v) {
+    int32_t t;
+    if (v > -2147483649.0 && v < 2147483648.0) t = (int32_t)v; else t = (int32_t)0x80000000u;
+    return (int16_t)(uint16_t)((uint32_t)t & 0xffffu);
+}
+
+// one sample, FP64 path: float s = nrng(...); raw = s*dig/range - offset  (src/gensig.c:264-270)
+__device__ static inline int16_t sample_exact(uint32_t c1, float m, float sd, double dig, double range, double offset) {
+    const double z = box_muller_exact(c1, lcg_mul(c1, LCG_A));
+    const float s = (float)((z * (double)sd) + (double)m);
+    return to_i16((double)s * dig / range - offset);
+}
+
+// base -> 2-bit code, src/seq.h:14-27
+__host__ __device__ static inline uint32_t base_code(uint8_t b) {
+    switch (b) {
+    case 'C': case 'c': case 'Y': case 'B': return 1;
+    case 'G': case 'g': case 'S': case 'K': return 2;
+    case 'T': case 't': case 'U': return 3;
+    default: return 0;   // A a R W M D H V and anything unknown
+    }
+}
+
+// ---- descriptors ---------------------------------------------------------------------------
+struct ReadDesc {
+    long long base_off;   // first byte of segment 0 in the batch's base buffer
+    long long ev_off;     // first event of this read in the batch's event arrays
+    double offset;        // slow5 offset of this read (drawn on the host)
+    int len0, len1;       // bytes in segment 0 (read incl. attached prefix) and 1 (RNA stall)
+    int ne0, ne1;         // events per segment
+    int worker;           // context-local worker index
+    uint32_t time_c0;     // worker's time-stream state at the start of this read
+    int tile_off;         // first 64-event tile of this read in the batch's tile arrays
+    int fast;             // certified mode: every ADC value of this read is provably in (2, 65000) -> lean kernel
+    int stile_off;        // first 256-event super tile of this read
+    int pad;
+};
+
+struct FixEntry {         // one sample handed to the FP64 path
+    long long at;         // absolute index into the signal slab
+    long long ev;         // batch-wide event index (k-mer recomputed from the bases)
+    uint32_t c1;          // first draw of the sample
+    int read;
+    int shifted;          // inside the RNA adaptor level-shift window
+    int pad;
+};
+
+// work item of k_samples_lean (256 consecutive events of one read), filled by k_items
+struct ItemDesc {
+    long long ev_first;          // index (in evrec / dwell) of the item's first event
+    long long sig_base;          // index (in sig) of the read's first sample
+    double offset;               // the read's slow5 offset
+    int n_ev;                    // events in the item (1..256); 0: not taken (queued for the generic kernel, or empty)
+    int n_samples;               // samples in the item
+    uint32_t at0;                // position within the read of the item's first sample (RNA: counted from the read's end)
+    int ev_read0;                // index within the read of the item's first event
+    int read;                    // read index (fix-up overflow path)
+    int pad;
+};
+
+struct SigParams {
+    const ReadDesc* reads;
+    const int* chain_off;        // [n_chains+1]
+    const int* chain_reads;      // read indices grouped per worker chain, batch order inside a chain
+    const int* chain_order;      // launch order (longest chain first)
+    const uint8_t* bases;
+    const uint16_t* dwell;       // per event (null when dwell is constant)
+    uint16_t* dwell_out;         // k_events with inline dwell draws: the same array, written
+    unsigned long long* seglen_out;    // ... and the per-read segment totals
+    double dmean, dstd;          // dwell_mean, dwell_std
+    const unsigned long long* seglen;  // [2*n_reads] samples in segment 0 / 1
+    const long long* sig_off;    // [n_reads+1]
+    const float2* model;         // {level_mean, (float)(level_stdv*amp_noise)}
+    const uint32_t* pw;
+    uint32_t* rows;              // [n_local_workers][num_kmer]: k <= 6 the stream states; k > 6 the samples each stream has produced
+    uint32_t seed_base, seed_step;   // (seed + worker_lo*(4^k+10)) mod M and (4^k+10) mod M: the initial state of local worker w,
+                                     // k-mer j is (seed_base + w*seed_step + j) mod M (src/sim.c:238-256)
+    int16_t* sig;
+    unsigned int* err;
+    FixEntry* fix;               // certified mode: undecided samples
+    unsigned int* fix_count;
+    unsigned int fix_cap;
+    uint2* evrec;                // per event {stream state at its first draw, k-mer rank}
+    uint32_t* tile_so;           // per 64-event tile: its first sample within the read
+    const int* tile_read;        // per tile: read index
+    const int* stile_read;       // per 256-event super tile (lean kernel work item): read index
+    ItemDesc* items;             // per super tile: what k_samples_lean needs, in one 48-B record
+    int lean_epl;                // events per lane of the lean kernel (4, 2 or 1): a super tile is 64*lean_epl events
+    int* slow_tiles;             // tiles the lean sample kernel left to the generic one
+    unsigned int* slow_count;
+    uint4* tfix;                 // lean kernel: FIX_SLOTS undecided samples per tile {index in read, c1, event in read, 0}
+    unsigned char* tfix_n;       // lean kernel: entries used per tile
+    double dig, range, kd;       // kd = dig/range
+    float delta_x;               // swept bound on |x_fast - x_exact| (incl. margin)
+    float thr_all;               // 1/2 - (largest eps over all k-mers): acceptance threshold of the lean kernel
+    int k, num_kmer;
+    int const_sps;               // (int)dwell_mean, used when dwell == null
+    int use_streams;             // 0 in --ideal / --ideal-amp (src/gensig.c:265-269)
+    int rna;                     // reverse the signal (src/gensig.c:348-354)
+    int shift_len;               // RNA+prefix: 79*(int)dwell_mean samples get -shift (src/genread.c:79-86)
+    int shift;                   // (int16)(30*dig/range)
+};
+

@@ -1,0 +1,195 @@
+// k_sampler.h -- gen_read on the device-resident genome: k_init_sampler, k_sample, k_copy_reads
+// Part of the device code of the per-read signal path; included through sqg_kernels.h (see there for the overview).
+#pragma once
+
+// ---- read sampler on the device-resident genome ("next" row) ----------
+// gen_read, src/genread.c:125-370: per worker the streams ref_pos (seed s), rand_strand (s+1) and rand_rlen
+// (s+3; Erlang-2 with scale rlen/2, the INTEGER quotient) of src/sim.c:238-247, consumed in read order.
+// GenomeParams.flags holds the SQG_SAMPLE_* bits of include/sqg.h
+
+struct GenomeParams {
+    const uint8_t* seq;          // contigs back to back (no terminators)
+    const long long* contig_off; // [n_contigs+1]
+    const long long* cum;        // [n_contigs] inclusive prefix sums of the contig lengths (src/genread.c:181-191)
+    const float* trans_csum;     // --trans-count: cumulative abundances (float, src/ref.c:206-273), or null
+    const int* trans_idx;        // ... and the contig of each entry
+    long long sum;               // ref->sum
+    double grng_b;               // (double)(rlen / 2)
+    int n_contigs, n_trans, rlen, flags;
+};
+
+struct SampleRec {               // what gen_read returns, per read
+    long long src;               // offset of the read's first base in GenomeParams.seq (forward strand)
+    int ref_idx, ref_pos, rlen;  // contig, 0-based start, bases copied
+    int strand;                  // '+' or '-'
+    int n_N;                     // 'N's substituted (src/genread.c:132-138)
+    int ref_len;                 // *ref_len of gen_read: the contig's length (DNA) / the transcript part used (RNA)
+};
+
+__global__ void k_init_sampler(uint32_t* __restrict__ st, long long seed, int worker_lo, int nw, int num_kmer) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    const long long s = seed + (long long)(w + worker_lo) * ((long long)num_kmer + 10);
+    const long long add[3] = {0, 1, 3};                              // ref_pos, rand_strand, rand_rlen
+    for (int j = 0; j < 3; j++) {
+        long long v = (s + add[j]) % (long long)LCG_M;
+        if (v < 0) v += LCG_M;
+        st[3 * w + j] = (uint32_t)v;
+    }
+}
+
+// rng() of src/rand.h:79-85 on a canonical state
+__device__ static inline double samp_rng(uint32_t& c) { c = lcg_mul(c, LCG_A); return lcg_uniform(c); }
+
+// exact count of bytes equal to 'N' in p[0..n), by the 64 lanes of a wavefront together (8 bytes per lane per step)
+__device__ static inline int count_N(const uint8_t* __restrict__ p, int n, int lane) {
+    int cnt = 0;
+    const int n8 = n & ~7;
+    for (int i = lane * 8; i < n8; i += 512) {
+        unsigned long long v;
+        __builtin_memcpy(&v, p + i, 8);
+        const unsigned long long x = v ^ 0x4e4e4e4e4e4e4e4eull;        // zero byte <=> 'N'
+        const unsigned long long t = ~(((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x | 0x7f7f7f7f7f7f7f7full);
+        cnt += __popcll(t);
+    }
+    if (lane < n - n8) cnt += p[n8 + lane] == 'N';
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    return cnt;
+}
+
+// one wavefront per worker chain (that worker's reads of the batch, in order): every lane makes the same draws, the
+// lanes share the scan of the candidate for 'N's
+__global__ __launch_bounds__(64) void k_sample(const GenomeParams G, uint32_t* __restrict__ st, const int* __restrict__ chain_off,
+                                               const int* __restrict__ chain_reads, const int* __restrict__ chain_worker,
+                                               int n_chains, SampleRec* __restrict__ out, unsigned int* __restrict__ err) {
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    if (ch >= n_chains) return;
+    const int w = chain_worker[ch];
+    uint32_t c_pos = st[3 * w], c_strand = st[3 * w + 1], c_len = st[3 * w + 2];
+    for (int ci = chain_off[ch]; ci < chain_off[ch + 1]; ci++) {
+        SampleRec rec;
+        for (int attempt = 0;; attempt++) {
+            if (attempt > 100000) { atomicOr(err, 16u); rec.src = 0; rec.ref_idx = 0; rec.ref_pos = 0; rec.rlen = 0; rec.strand = '+'; rec.n_N = 0; rec.ref_len = 0; break; }
+            int idx, pos, len, strand = '+';
+            if (G.flags & (SQG_SAMPLE_RNA | SQG_SAMPLE_CDNA)) {
+                // src/genread.c:283-300: uniform over transcripts, or by the abundance CDF (uniform narrowed to float)
+                if (G.n_trans == 0) idx = (int)round(samp_rng(c_pos) * (G.n_contigs - 1));
+                else {
+                    const float r = (float)samp_rng(c_pos);
+                    idx = 0;
+                    for (int i = 0; i < G.n_trans; i++) if (r <= G.trans_csum[i]) { idx = G.trans_idx[i]; break; }
+                }
+                const int clen = (int)(G.contig_off[idx + 1] - G.contig_off[idx]);
+                len = clen; pos = 0;
+                if (G.flags & SQG_SAMPLE_TRUNC) {                     // src/genread.c:303-309
+                    double acc = 0.0;
+                    acc += -log(1 - samp_rng(c_len));
+                    acc += -log(1 - samp_rng(c_len));
+                    const double frac = (acc * G.grng_b) / (double)G.rlen;
+                    int tl = (int)(frac * clen);
+                    tl = tl > clen ? clen : tl;
+                    pos = clen - tl; len = tl;
+                }
+                if (G.flags & SQG_SAMPLE_CDNA) strand = ((long long)round(samp_rng(c_strand))) ? '+' : '-';
+            } else {
+                // src/genread.c:243-281
+                double acc = 0.0;                                     // grng, src/rand.h:96-102 (Erlang-2)
+                acc += -log(1 - samp_rng(c_len));
+                acc += -log(1 - samp_rng(c_len));
+                len = (int)(acc * G.grng_b);
+                const long long at = (long long)round(samp_rng(c_pos) * (double)G.sum);   // src/genread.c:181
+                idx = 0;
+                while (idx < G.n_contigs - 1 && G.cum[idx] < at) idx++;
+                pos = (int)(at - G.cum[idx]) + (int)(G.contig_off[idx + 1] - G.contig_off[idx]);
+                strand = ((long long)round(samp_rng(c_strand))) ? '+' : '-';            // src/genread.c:196-200
+            }
+            if (len < 0) len = 0;
+            const int clen = (int)(G.contig_off[idx + 1] - G.contig_off[idx]);
+            const int n = min(len, clen - pos);                       // src/genread.c:149-177: clipped at the contig's end
+            if (n < 200) continue;                                    // src/genread.c:126
+            const long long src = G.contig_off[idx] + pos;
+            const int nN = count_N(G.seq + src, n, lane);
+            if ((double)nN > 0.1 * (double)n) continue;               // src/genread.c:139-142
+            rec.src = src; rec.ref_idx = idx; rec.ref_pos = pos; rec.rlen = n; rec.strand = strand; rec.n_N = nN;
+            rec.ref_len = (G.flags & (SQG_SAMPLE_RNA | SQG_SAMPLE_CDNA)) ? len : clen;
+            break;
+        }
+        if (lane == 0) out[chain_reads[ci]] = rec;
+    }
+    if (lane == 0) { st[3 * w] = c_pos; st[3 * w + 1] = c_strand; st[3 * w + 2] = c_len; }
+}
+
+__device__ static const char kd_stall_dna[] = "TTTTTTTTTTTTTTTTTTAATCAA";                       // src/genread.c:110
+__device__ static const char kd_adaptor_dna[] = "GGCGTCTGCTTGGGTGTTTAACCTTTTTTTTTTAATGTACTTCGTTCAGTTACGTATTGCT";  // src/genread.c:38
+__device__ static const char kd_adaptor_rna[] = "TGATGATGAGGGATAGACGATGGTTGTTTCTGTTGGTGCTGATATTGCTTTTTTTTTTTTTATGATGCAAGATACGCAC";  // src/genread.c:39
+__device__ static const char kd_stall_rna[] = "AAAAAGAAAAAACCCCCCCCCCCCCCCCCC";                  // src/genread.c:87
+
+// one workgroup per read: the sampled slice of the genome -> the batch's base buffer, exactly as gen_read returns
+// it ('N' -> a base from a FRESH state-100 stream per read, src/genread.c:132-138; '-' -> revcomp, src/seq.h:78-112)
+// with the prefix / stall attached as src/genread.c:95-123 does.  read_at: where the read starts in segment 0.
+__global__ __launch_bounds__(256) void k_copy_reads(const GenomeParams G, const SampleRec* __restrict__ recs, const ReadDesc* __restrict__ reads,
+                                                    uint8_t* __restrict__ bases, int n_reads, int rna, int prefix) {
+    __shared__ int wcnt[4];
+    __shared__ int carry;
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const SampleRec rec = recs[r];
+    const ReadDesc rd = reads[r];
+    uint8_t* dst = bases + rd.base_off;
+    const int n = rec.rlen;
+    int read_at = 0;
+    if (prefix) {
+        if (rna) {                                                    // read + polyA(158) + adaptor
+            for (int i = tid; i < 158; i += 256) dst[n + i] = 'A';
+            for (int i = tid; i < (int)sizeof(kd_adaptor_rna) - 1; i += 256) dst[n + 158 + i] = (uint8_t)kd_adaptor_rna[i];
+        } else {                                                      // stall + adaptor + read
+            const int st = (int)sizeof(kd_stall_dna) - 1, ad = (int)sizeof(kd_adaptor_dna) - 1;
+            for (int i = tid; i < st; i += 256) dst[i] = (uint8_t)kd_stall_dna[i];
+            for (int i = tid; i < ad; i += 256) dst[st + i] = (uint8_t)kd_adaptor_dna[i];
+            read_at = st + ad;
+        }
+    }
+    for (int i = tid; i < rd.len1; i += 256) dst[rd.len0 + i] = (uint8_t)kd_stall_rna[i];
+    const uint8_t* src = G.seq + rec.src;
+    const bool rev = rec.strand == '-';
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        uint8_t c = i < n ? src[i] : (uint8_t)'A';
+        if (rec.n_N) {                                                // ordinal of every 'N' in forward order
+            const bool isN = i < n && c == 'N';
+            const unsigned long long m = __ballot(isN);
+            if (lane == 0) wcnt[wid] = __popcll(m);
+            __syncthreads();
+            int before = carry;
+            for (int w2 = 0; w2 < wid; w2++) before += wcnt[w2];
+            const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            if (isN) {
+                const int j = before + __popcll(m & ((1ull << lane) - 1)); // 0-based; draw j+1 of the state-100 stream
+                uint32_t cst = 100u;
+                for (int q = 0; q <= j; q++) cst = lcg_mul(cst, LCG_A);    // <= 10 % of the read: a short walk
+                const int v = (int)round(lcg_uniform(cst) * 3);
+                c = v == 0 ? 'A' : v == 1 ? 'C' : v == 2 ? 'G' : 'T';
+            }
+            __syncthreads();
+            if (tid == 0) carry += tot;
+            __syncthreads();
+        }
+        if (i < n) {
+            if (rev) {
+                uint8_t o;
+                switch (c) {
+                case 'A': case 'a': o = 'T'; break;
+                case 'C': case 'c': o = 'G'; break;
+                case 'G': case 'g': o = 'C'; break;
+                case 'T': case 't': o = 'A'; break;
+                default: o = 'T'; break;
+                }
+                dst[read_at + n - 1 - i] = o;
+            } else dst[read_at + i] = c;
+        }
+    }
+}
+

@@ -1,0 +1,511 @@
+// k_samples.h -- k_items, k_samples_lean (the hot kernel), the generic k_samples, the FP64 fix-up kernels, k_certify, k_store_probe
+// Part of the device code of the per-read signal path; included through sqg_kernels.h (see there for the overview).
+#pragma once
+
+struct SmpWaveLds {
+    uint4 rec_a[64];            // {c_ev, first sample in tile, F | level_mean, sdk | sd}
+    uint2 rec_b[64];            // {I | constant sample, thr}
+    uint8_t mk[MK_W];           // event-start markers of the current sample window
+};
+struct SmpLds {
+    uint2 mult[MULT_N];         // {a^(2j+1), a^(2j+2)}
+    SmpWaveLds w[4];
+};
+
+__device__ static inline void push_fix(const SigParams& P, bool bad, int lane, unsigned long long lane_le,
+                                       long long at, uint32_t c1, long long ev, int r, int shifted) {
+    const unsigned long long am = __ballot(bad);
+    if (am) {                                                  // hand the undecided samples to k_fixup
+        unsigned int slot0 = 0;
+        const int leader = __ffsll((long long)am) - 1;
+        if (lane == leader) slot0 = atomicAdd(P.fix_count, (unsigned int)__popcll(am));
+        slot0 = __shfl(slot0, leader);
+        if (bad) {
+            const unsigned int slot = slot0 + (unsigned int)__popcll(am & lane_le) - 1u;
+            if (slot < P.fix_cap) {
+                FixEntry fe; fe.at = at; fe.c1 = c1; fe.ev = ev; fe.read = r; fe.shifted = shifted; fe.pad = 0;
+                P.fix[slot] = fe;
+            } else atomicOr(P.err, 8u);
+        }
+    }
+}
+
+// one undecided sample from a divergent region (rare overflow path of the lean kernel)
+__device__ static inline void push_fix_one(const SigParams& P, long long at, uint32_t c1, long long ev, int r, int shifted) {
+    const unsigned int slot = atomicAdd(P.fix_count, 1u);
+    if (slot < P.fix_cap) {
+        FixEntry fe; fe.at = at; fe.c1 = c1; fe.ev = ev; fe.read = r; fe.shifted = shifted; fe.pad = 0;
+        P.fix[slot] = fe;
+    } else atomicOr(P.err, 8u);
+}
+
+#define LEAN_EPL_MAX 4                     // events per lane of the lean kernel: 4, 2 or 1 (SigParams.lean_epl, chosen per profile so
+                                           // that a work item -- 64*epl consecutive events of a read -- stays below LEAN_MAX_SAMPLES)
+#define FIX_SLOTS 8                        // parked undecided samples per super tile (expected ~0.5); overflow -> global list
+#define LEAN_MAX_SAMPLES 4096              // samples per work item the 64x64-bit start map covers
+
+// k_items: one thread per 256-event super tile.  Collapses the dependent look-ups of the lean kernel's set-up
+// (tile -> read -> tile_so / sig_off / seglen) into one record per item and decides which items the lean
+// kernel takes; the others are queued (as 64-event tiles) for k_samples<MODE, GENERIC>.
+__global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_stiles, const int n_reads, long long* __restrict__ host_off) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g <= n_reads) host_off[g] = P.sig_off[g];                      // read offsets to the host through the pinned mapping
+    if (g >= n_stiles) return;
+    const int r = P.stile_read[g];
+    const ReadDesc rd = P.reads[r];
+    const int LEAN_EPL = P.lean_epl, LEAN_EV = 64 * LEAN_EPL;
+    const int lt = g - rd.stile_off;                                   // super tile within the read
+    const int ne = rd.ne0 + rd.ne1;
+    const int n_ev = min(LEAN_EV, ne - lt * LEAN_EV);
+    const long long sig_base = P.sig_off[r];
+    const uint32_t read_len = (uint32_t)(P.sig_off[r + 1] - sig_base);
+    const uint32_t base_pos = P.tile_so[rd.tile_off + lt * LEAN_EPL];
+    const uint32_t next_pos = (lt + 1) * LEAN_EV < ne ? P.tile_so[rd.tile_off + (lt + 1) * LEAN_EPL] : read_len;
+    const int n_samples = (int)(next_pos - base_pos);
+    bool take = rd.fast != 0 && n_samples <= LEAN_MAX_SAMPLES;
+    if (P.shift_len > 0) {                                             // RNA adaptor level-shift window (src/genread.c:79-86)
+        const long long n1 = (long long)P.seglen[2 * r];
+        if ((long long)base_pos + n_samples > n1 - P.shift_len && (long long)base_pos < n1) take = false;
+    }
+    if (!take) {                                                       // leave these (up to 4) 64-event tiles to the generic kernel
+        const int nt = (n_ev + 63) >> 6;
+        const unsigned int q = atomicAdd(P.slow_count, (unsigned int)nt);
+        for (int i = 0; i < nt; i++) P.slow_tiles[q + i] = rd.tile_off + lt * LEAN_EPL + i;
+    }
+    ItemDesc d;
+    d.ev_first = rd.ev_off + (long long)lt * LEAN_EV;
+    d.sig_base = sig_base;
+    d.offset = rd.offset;
+    d.n_ev = (take && n_samples > 0) ? n_ev : 0;
+    d.n_samples = n_samples;
+    d.at0 = P.rna ? read_len - 1u - base_pos : base_pos;
+    d.ev_read0 = lt * LEAN_EV;
+    d.read = r;
+    d.pad = 0;
+    P.items[g] = d;
+    P.tfix_n[g] = 0;
+}
+
+template <int EPL>
+struct LeanWaveLds {
+    uint4 rec[64 * EPL];                // {c_ev, ((8*first sample) & 0xfff) << 16 | I (16 bits), F - 1/2, sdk}
+    unsigned long long bm[64];          // bit s-1 set: an event (other than the item's first) starts at sample s
+    int nfix;                           // undecided samples of the item so far
+    int pad[3];
+};
+template <int EPL>
+struct LeanLds {
+    uint32_t mult[MULT_N];              // a^(2j+1): the first draw of an event's sample j is state * mult[j]
+    LeanWaveLds<EPL> w[4];
+};
+
+// k_samples_lean: the hot kernel.  Certified fp32 path only, for reads whose ADC values are provably in
+// (2, 65000) (ReadDesc.fast), events of <= MULT_N samples, outside the RNA level-shift window; everything
+// else is queued (as 64-event tiles) for k_samples<MODE, GENERIC>.
+// One wavefront per 256 consecutive events of a read (4 per lane: the dependent global round trips of the
+// set-up are paid once per ~2300 samples; the item's descriptors are wave-uniform and live in SGPRs).
+// Per step 64 consecutive samples:
+//   64-bit slice of the event-start map (v_readlane) -> mbcnt -> event -> {state, first|I, F-1/2, sdk}
+//   (one ds_read_b128) -> jump constants (ds_read_b64) -> 2 modular multiplications -> v_log/v_sqrt/v_cos ->
+//   v' = fma(x, sdk, F-1/2) -> t = v' + 1.5*2^23 (round to nearest: floor of the ADC value unless it is within
+//   eps of an integer) -> acceptance test on v' - (t - 1.5*2^23) -> int16 store of the low half of bits(t) + I.
+// The loads of step i+1 are issued before the arithmetic of step i (software pipelining, two steps unrolled
+// so that the pipeline registers do not have to be copied).
+template <bool RNA, int LEAN_EPL>
+__global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const int n_stiles) {
+    __shared__ LeanLds<LEAN_EPL> L;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < MULT_N; i += 256) L.mult[i] = P.pw[i];
+    __syncthreads();
+    LeanWaveLds<LEAN_EPL>& W = L.w[wid];
+    const float thr = P.thr_all;
+    const char* mult_b = reinterpret_cast<const char*>(L.mult);
+
+    for (int g = blockIdx.x * 4 + wid; g < n_stiles; g += gridDim.x * 4) {
+        // the item's descriptor is wave-uniform: scalar load (the constant address space forces s_load; k_items wrote it
+        // before this kernel started)
+        ItemDesc it;
+        {
+            const __attribute__((address_space(4))) uint32_t* src =
+                reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(P.items + g));
+            uint32_t w[sizeof(ItemDesc) / 4];
+#pragma unroll
+            for (int q = 0; q < (int)(sizeof(ItemDesc) / 4); q++) w[q] = src[q];
+            __builtin_memcpy(&it, w, sizeof it);
+        }
+        const int ne = it.n_ev;                                         // events of this item
+        if (ne == 0) continue;                                         // not taken, or empty
+        const int wave_total = it.n_samples;
+        const int e0 = lane * LEAN_EPL;                                // my first event (within the item)
+        const long long gev = it.ev_first + e0;
+        // ---- set-up: LEAN_EPL consecutive events per lane ----
+        uint2 er[LEAN_EPL];
+        int sps[LEAN_EPL];
+        if (e0 + LEAN_EPL <= ne) {
+            uint32_t ew[2 * LEAN_EPL];
+            __builtin_memcpy(ew, P.evrec + gev, 8 * LEAN_EPL);                        // 8-B aligned wide loads
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) er[q] = make_uint2(ew[2 * q], ew[2 * q + 1]);
+            if (P.dwell) {
+                uint16_t dw[LEAN_EPL];
+                __builtin_memcpy(dw, P.dwell + gev, 2 * LEAN_EPL);                    // 2-B aligned wide load
+#pragma unroll
+                for (int q = 0; q < LEAN_EPL; q++) sps[q] = (int)dw[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < LEAN_EPL; q++) sps[q] = P.const_sps;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) {
+                const bool v = e0 + q < ne;
+                er[q] = v ? P.evrec[gev + q] : make_uint2(0u, 0u);
+                sps[q] = v ? (P.dwell ? (int)P.dwell[gev + q] : P.const_sps) : 0;
+            }
+        }
+        float2 md[LEAN_EPL];
+#pragma unroll
+        for (int q = 0; q < LEAN_EPL; q++) md[q] = (e0 + q < ne) ? P.model[er[q].y] : make_float2(0.f, 0.f);
+        int lane_total = 0;
+#pragma unroll
+        for (int q = 0; q < LEAN_EPL; q++) lane_total += sps[q];
+        const int incl = wave_incl_scan_dpp(lane_total);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // previous item's LDS reads are done
+        W.bm[lane] = 0ull;
+        if (lane == 0) W.nfix = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        {
+            int run = incl - lane_total;
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) {
+                const int so = run; run += sps[q];
+                // v = s_f*dig/range - offset  ~  x*(sd*kd) + (m*kd - offset) = x*sdk + (I + F), I = floor(.) in (2, 65000)
+                const double mk = (double)md[q].x * P.kd - it.offset;
+                const double fl0 = floor(mk);
+                const float Fh = (float)(mk - fl0 - 0.5);
+                const float sdk = (float)((double)md[q].y * P.kd);
+                W.rec[lane * LEAN_EPL + q] = make_uint4(er[q].x, ((((uint32_t)so << 3) & 0xfffu) << 16) | ((uint32_t)(int)fl0 & 0xffffu),
+                                                        __float_as_uint(Fh), __float_as_uint(sdk));
+                if ((e0 + q < ne) && (lane | q) != 0)                  // so >= 1: every earlier event has >= 1 sample
+                    atomicOr(reinterpret_cast<unsigned int*>(W.bm) + ((so - 1) >> 5), 1u << ((so - 1) & 31));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const unsigned long long my_bm = W.bm[lane];
+        const uint32_t bm_lo = (uint32_t)my_bm, bm_hi = (uint32_t)(my_bm >> 32);
+        char* const out_b = reinterpret_cast<char*>(P.sig + it.sig_base);               // wave-uniform: global_store saddr + 32-bit lane offset
+        // byte offset of my sample of step 0 within the read: generation index i is stored at at0 + i (RNA: at0 - i)
+        uint32_t voff = RNA ? 2u * (it.at0 - (uint32_t)lane) : 2u * (it.at0 + (uint32_t)lane);
+        uint32_t idx8 = (uint32_t)lane << 3;                           // 8 * (my sample index within the item)
+        const int ev_read0 = it.ev_read0;                               // event index (within the read) of rec[0]
+#if defined(SQG_ABL_NOLOOP)
+        const int nfull = 0, rem = wave_total & 1;
+#else
+        const int nfull = wave_total >> 6, rem = wave_total & 63;
+#endif
+        int base_ev;
+
+        // event of my sample in step c: events begun in earlier steps + start bits below my lane
+        #define LEAN_MAP(c_, ev_) {                                                                              \
+            const uint32_t lo_ = __builtin_amdgcn_readlane(bm_lo, (c_)), hi_ = __builtin_amdgcn_readlane(bm_hi, (c_)); \
+            ev_ = (int)__builtin_amdgcn_mbcnt_hi(hi_, __builtin_amdgcn_mbcnt_lo(lo_, (uint32_t)base_ev));          \
+            base_ev += __builtin_popcount(lo_) + __builtin_popcount(hi_); }
+        // one step: issue the loads of step c_+1 into (RN, MN, EN), then the arithmetic of step c_ from (RA, MU, EV)
+        #define LEAN_STEP(TAIL, c_, RA, MU, EV, RN, MN, EN) {                                                    \
+            LEAN_MAP(min((c_) + 1, 63), EN)                                                                       \
+            RN = W.rec[EN];                                                                                       \
+            LEAN_ARITH(RA, MU)                                                                                    \
+            const float vh = __builtin_fmaf(x, __uint_as_float(RA.w), __uint_as_float(RA.z));                     \
+            const float t = vh + LEAN_MAGIC;                                                                      \
+            const float d = vh - (t - LEAN_MAGIC);                                                                \
+            const bool act = !(TAIL) || (int)(idx8 >> 3) < wave_total;                                            \
+            const bool ok = fabsf(d) < thr && c1 <= LCG_M - (1u << NEAR_ONE_BITS);                                \
+            if (act && ok LEAN_STORE_COND) *reinterpret_cast<uint16_t*>(out_b + voff) = (uint16_t)((__float_as_uint(t) + RA.y) & 0xffffu); \
+            else if (act) {                                        /* ~1 % of steps: park the undecided samples (no round trip) */ \
+                const unsigned long long am = __builtin_amdgcn_ballot_w64(true);                                  \
+                const int n0 = W.nfix;                                                                            \
+                const int slot = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)); \
+                if (slot < FIX_SLOTS) P.tfix[(size_t)g * FIX_SLOTS + slot] = make_uint4(voff >> 1, c1, (uint32_t)(ev_read0 + EV), 0u); \
+                else push_fix_one(P, it.sig_base + (voff >> 1), c1, it.ev_first + EV, it.read, 0);   /* overflow (never in practice): global list */ \
+                if (slot + 1 == n0 + __popcll(am)) W.nfix = slot + 1;          /* the last of them publishes the new count */ \
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                            \
+            }                                                                                                     \
+            idx8 += 512u;                                                                                         \
+            voff = RNA ? voff - 128u : voff + 128u;                                                               \
+            MN = *reinterpret_cast<const uint32_t*>(mult_b + (((idx8 - (RN.y >> 16)) & 0xff8u) >> 1)); }
+
+        /* ablation builds (tools/ab_variants.sh; results are wrong): -DSQG_ABL_NOARITH, -DSQG_ABL_NOSTORE, -DSQG_ABL_NOLOOP */
+#if defined(SQG_ABL_NOSTORE)
+        #define LEAN_STORE_COND && (__float_as_uint(t) == 0x12345u)
+#else
+        #define LEAN_STORE_COND
+#endif
+#if defined(SQG_ABL_NOARITH)
+        #define LEAN_ARITH(RA, MU) const uint32_t c1 = (RA.x ^ MU) & 0x3fffffffu; const float x = __uint_as_float((RA.x + MU) & 0x3fffffffu);
+#else
+        #define LEAN_ARITH(RA, MU) const uint32_t c1 = lcg_mul(RA.x, MU); const float x = box_muller_fast(c1);
+#endif
+        uint4 ra, rb; uint32_t ma, mb; int eva, evb;
+        base_ev = 0;
+        LEAN_MAP(0, eva)
+        ra = W.rec[eva];
+        ma = *reinterpret_cast<const uint32_t*>(mult_b + (((idx8 - (ra.y >> 16)) & 0xff8u) >> 1));
+        int c = 0;
+        for (; c + 2 <= nfull; c += 2) {
+            LEAN_STEP(false, c, ra, ma, eva, rb, mb, evb)
+            LEAN_STEP(false, c + 1, rb, mb, evb, ra, ma, eva)
+        }
+        if (c < nfull) {
+            LEAN_STEP(false, c, ra, ma, eva, rb, mb, evb)
+            ra = rb; ma = mb; eva = evb; c++;
+        }
+        if (rem) LEAN_STEP(true, c, ra, ma, eva, rb, mb, evb)
+        #undef LEAN_STEP
+        #undef LEAN_MAP
+        #undef LEAN_ARITH
+        #undef LEAN_STORE_COND
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int nfix = W.nfix;
+        if (nfix && lane == 0) P.tfix_n[g] = (unsigned char)min(nfix, FIX_SLOTS);
+    }
+}
+
+// MODE 0: FP64 everywhere.  MODE 1: certified fp32 path.
+// GENERIC false: the lean kernel; tiles it cannot take (long events, level-shift window, possibly
+//                negative ADC values, no-noise modes) are queued for the GENERIC instantiation.
+template <int MODE, bool GENERIC>
+__global__ __launch_bounds__(256) void k_samples(const SigParams P, const int n_tiles) {
+    __shared__ SmpLds L;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < MULT_N; i += 256) L.mult[i] = make_uint2(P.pw[i], P.pw[POW_N + i]);
+    __syncthreads();
+    SmpWaveLds& W = L.w[wid];
+    const unsigned long long lane_le = (lane == 63) ? ~0ull : ((2ull << lane) - 1);   // lanes <= me
+    const int n_work = GENERIC && P.slow_tiles ? (int)min(*P.slow_count, (unsigned int)n_tiles) : n_tiles;
+
+    for (int wi = blockIdx.x * 4 + wid; wi < n_work; wi += gridDim.x * 4) {
+        const int g = GENERIC && P.slow_tiles ? P.slow_tiles[wi] : wi;
+        const int r = P.tile_read[g];
+        const ReadDesc rd = P.reads[r];
+        const int ne = rd.ne0 + rd.ne1;
+        const int e = (g - rd.tile_off) * 64 + lane;
+        const bool valid = e < ne;
+        const long long ev_first = rd.ev_off + (long long)(g - rd.tile_off) * 64;
+        uint2 er = make_uint2(0u, 0u);
+        int sps = 0;
+        if (valid) {
+            er = P.evrec[rd.ev_off + e];
+            sps = P.dwell ? (int)P.dwell[rd.ev_off + e] : P.const_sps;
+        }
+        const float2 md = valid ? P.model[er.y] : make_float2(0.f, 0.f);
+        const int incl = wave_incl_scan(sps, lane);
+        const int wave_total = __shfl(incl, 63);
+        const int so = incl - sps;                                     // first sample of my event within the tile
+        const long long sig_base = P.sig_off[r];
+        const uint32_t read_len = (uint32_t)(P.sig_off[r + 1] - sig_base);
+        const long long n1 = (long long)P.seglen[2 * r];               // samples of segment 0
+        const long long shift_lo = n1 - P.shift_len;                    // src/genread.c:79
+        const uint32_t base_pos = P.tile_so[g];
+        const bool shift_tile = P.shift_len > 0 && (long long)base_pos + wave_total > shift_lo && (long long)base_pos < n1;
+        const double offset = rd.offset;
+        int16_t* out = P.sig + sig_base;
+
+        float thr = 1.0f;
+        bool fast_ok = false;
+        uint4 ra; uint2 rb;
+        if (!P.use_streams) {
+            // no amplitude noise (--ideal / --ideal-amp): s = level_mean, one digitisation per event (src/gensig.c:266,270)
+            const int16_t qc = to_i16((double)md.x * P.dig / P.range - offset);
+            ra = make_uint4(0u, (uint32_t)so, 0u, 0u);
+            rb = make_uint2((uint32_t)(uint16_t)qc, 0u);
+        } else if (MODE == 1) {
+            // v = s_f*dig/range - offset  ~  x*(sd*kd) + (m*kd - offset) = x*sdk + (I + F)
+            const double mkd = (double)md.x * P.kd;
+            const double mk = mkd - offset;
+            const double fl = floor(mk);
+            const float F = (float)(mk - fl);
+            const float sdk = (float)((double)md.y * P.kd);
+            const float asdk = fabsf(sdk);
+            // error budget (DESIGN.md "Certified fast path"): swept |x'-x| * sdk; float narrowing of s
+            // (2^-24 (|m| kd + 6.56 sdk)); roundings of sdk (x6.56), of F (2^-25) and of the fma
+            // (2^-24 (6.56 sdk + 1)); FP64 roundings and the fp32 evaluation of eps itself in the slack
+            const float eps = P.delta_x * asdk + 5.9604645e-8f * ((float)fabs(mkd) + 21.0f * asdk + 3.0f) + 2.0e-7f;
+            thr = 0.5f - eps;
+            if (!(fabs(fl) < 1.0e9)) thr = -1.0f;                     // absurd profile: everything goes to FP64
+            fast_ok = !valid || (sps <= MULT_N && fl - 7.0 * (double)asdk > 2.0 && fl < 1.0e9);
+            ra = make_uint4(er.x, (uint32_t)so, __float_as_uint(F), __float_as_uint(sdk));
+            rb = make_uint2((uint32_t)(int)fl, __float_as_uint(thr));
+        } else {
+            ra = make_uint4(er.x, (uint32_t)so, __float_as_uint(md.x), __float_as_uint(md.y));
+            rb = make_uint2(0u, 0u);
+        }
+        const bool take_fast = MODE == 1 && P.use_streams && !shift_tile && __all(fast_ok);
+        if (!GENERIC) {
+            if (!take_fast) {                                          // leave this tile to the generic kernel
+                if (lane == 0) { const unsigned int q = atomicAdd(P.slow_count, 1u); P.slow_tiles[q] = g; }
+                continue;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // previous tile's LDS reads are done
+        W.rec_a[lane] = ra;
+        W.rec_b[lane] = rb;
+        if (wave_total <= 0) continue;
+
+        if (!GENERIC) {
+            // ---------------- the hot loop ----------------
+            float t = valid ? thr : 1.0f;
+            for (int o = 32; o > 0; o >>= 1) t = fminf(t, __shfl_xor(t, o));
+            const bool rna = P.rna != 0;
+            const uint32_t a_top = read_len - 1 - base_pos;
+            for (int w0 = 0; w0 < wave_total; w0 += MK_W) {
+                ((uint4*)W.mk)[lane] = make_uint4(0, 0, 0, 0);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (valid && so >= w0 && so < w0 + MK_W) W.mk[so - w0] = 1;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                int base_ev = __popcll(__ballot(valid && so < w0)) - 1;
+                const int w_end = min(w0 + MK_W, wave_total);
+                for (int c0 = w0; c0 < w_end; c0 += 64) {
+                    const int idx = c0 + lane;
+                    const unsigned long long sm = __ballot(W.mk[idx - w0] != 0);
+                    const int ev = base_ev + __popcll(sm & lane_le);
+                    base_ev += __popcll(sm);
+                    const uint4 qa = W.rec_a[ev];
+                    const int I = (int)W.rec_b[ev].x;
+                    const uint32_t j = ((uint32_t)idx - qa.y) & (MULT_N - 1);
+                    const uint2 mu = L.mult[j];
+                    const uint32_t c1 = lcg_mul(qa.x, mu.x);
+                    const float x = box_muller_fast(c1);
+                    const float v = __builtin_fmaf(x, __uint_as_float(qa.w), __uint_as_float(qa.z));
+                    const float fl = floorf(v);
+                    const float fr = v - fl;
+                    const bool act = idx < w_end;
+                    const bool ok = fabsf(fr - 0.5f) < t && c1 <= LCG_M - (1u << NEAR_ONE_BITS);
+                    const int n = I + (int)fl;
+                    const uint32_t at = rna ? (a_top - (uint32_t)idx) : (base_pos + (uint32_t)idx);
+                    if (act && ok) out[at] = (int16_t)(uint16_t)((uint32_t)n & 0xffffu);
+                    push_fix(P, act && !ok, lane, lane_le, sig_base + at, c1, ev_first + ev, r, 0);
+                }
+            }
+        } else {
+            // ---------------- every option, both modes ----------------
+            for (int w0 = 0; w0 < wave_total; w0 += MK_W) {
+                ((uint4*)W.mk)[lane] = make_uint4(0, 0, 0, 0);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                if (valid && so >= w0 && so < w0 + MK_W) W.mk[so - w0] = 1;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                int base_ev = __popcll(__ballot(valid && so < w0)) - 1;
+                const int w_end = min(w0 + MK_W, wave_total);
+                for (int c0 = w0; c0 < w_end; c0 += 64) {
+                    const int idx = c0 + lane;
+                    const unsigned long long sm = __ballot(W.mk[idx - w0] != 0);
+                    const int ev = base_ev + __popcll(sm & lane_le);
+                    base_ev += __popcll(sm);
+                    const bool act = idx < w_end;
+                    const uint4 qa = W.rec_a[act ? ev : 0];
+                    const uint2 qb = W.rec_b[act ? ev : 0];
+                    const uint32_t j = (uint32_t)idx - qa.y;
+                    const uint32_t pos = base_pos + (uint32_t)idx;
+                    const uint32_t at = P.rna ? (read_len - 1 - pos) : pos;
+                    const bool in_shift = shift_tile && (long long)pos >= shift_lo && (long long)pos < n1;
+                    int16_t q = 0;
+                    bool ok = true;
+                    uint32_t c1 = 1;
+                    if (!P.use_streams) {
+                        q = (int16_t)(uint16_t)qb.x;
+                    } else if (act) {
+                        if (j < MULT_N) c1 = lcg_mul(qa.x, L.mult[j].x);
+                        else c1 = lcg_mul(lcg_mul(qa.x, lcg_jump2(P.pw, j)), LCG_A);
+                        if (MODE == 1) {
+                            const float x = box_muller_fast(c1);
+                            const float v = __builtin_fmaf(x, __uint_as_float(qa.w), __uint_as_float(qa.z));
+                            const float fl = floorf(v);
+                            const float fr = v - fl;
+                            ok = fabsf(fr - 0.5f) < __uint_as_float(qb.y) && c1 <= LCG_M - (1u << NEAR_ONE_BITS);
+                            int n = (int)qb.x + (int)fl;
+                            n -= n >> 31;                                  // truncation toward zero (value is not an integer)
+                            q = (int16_t)(uint16_t)((uint32_t)n & 0xffffu);
+                        } else {
+                            const double z = box_muller_exact(c1, lcg_mul(c1, LCG_A));
+                            const float sv = (float)((z * (double)__uint_as_float(qa.w)) + (double)__uint_as_float(qa.z));   // src/gensig.c:268
+                            q = to_i16((double)sv * P.dig / P.range - offset);                                             // src/gensig.c:270
+                        }
+                    }
+                    if (in_shift) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);
+                    if (act && ok) out[at] = q;
+                    if (MODE == 1) push_fix(P, act && !ok, lane, lane_le, sig_base + at, c1, ev_first + ev, r, in_shift ? 1 : 0);
+                }
+            }
+        }
+    }
+}
+
+// ---- k_fixup: FP64 path for the samples k_signal<CERTIFIED> left undecided -------------------
+// per-tile slots of the lean kernel: one thread per super tile walks its (0-8, typically 0-1) parked samples.
+// No atomics: a returning atomic per wavefront on one counter costs ~10 ns each and serialises.
+__global__ __launch_bounds__(256) void k_fixup_tiles(const SigParams P, const int n_stiles) {
+    __shared__ uint16_t work[4][64 * FIX_SLOTS];         // per wavefront: (lane of the item << 4) | slot
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int n = g < n_stiles ? (int)P.tfix_n[g] : 0;
+    // spread the wavefront's parked samples (0-8 per item, ~0.5 on average) evenly over its lanes
+    const int incl = wave_incl_scan_dpp(n);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total == 0) return;
+    for (int q = 0; q < n; q++) work[wid][incl - n + q] = (uint16_t)((lane << 4) | q);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    for (int w = lane; w < total; w += 64) {
+        const int code = work[wid][w];
+        const int gi = g - lane + (code >> 4), slot = code & 15;
+        const int r = P.stile_read[gi];
+        const ReadDesc rd = P.reads[r];
+        const uint4 fe = P.tfix[(size_t)gi * FIX_SLOTS + slot];
+        const int e = (int)fe.z;
+        const uint8_t* bp = P.bases + rd.base_off + (e < rd.ne0 ? (long long)e : (long long)rd.len0 + (e - rd.ne0));
+        uint32_t rank = 0;
+        for (int q = 0; q < P.k; q++) rank = (rank << 2) | base_code(bp[q]);
+        const float2 md = P.model[rank];
+        P.sig[P.sig_off[r] + fe.x] = sample_exact(fe.y, md.x, md.y, P.dig, P.range, rd.offset);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fixup(const SigParams P) {
+    const unsigned int n = min(*P.fix_count, P.fix_cap);
+    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const FixEntry fe = P.fix[i];
+        const ReadDesc rd = P.reads[fe.read];
+        const int e = (int)(fe.ev - rd.ev_off);
+        const uint8_t* bp = P.bases + rd.base_off + (e < rd.ne0 ? (long long)e : (long long)rd.len0 + (e - rd.ne0));
+        uint32_t rank = 0;
+        for (int q = 0; q < P.k; q++) rank = (rank << 2) | base_code(bp[q]);
+        const float2 md = P.model[rank];
+        int16_t q = sample_exact(fe.c1, md.x, md.y, P.dig, P.range, rd.offset);
+        if (fe.shifted) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);
+        P.sig[fe.at] = q;
+    }
+}
+
+// ---- k_certify: max |x_fast - x_exact| over every state the fp32 path may accept ------------
+// The deviate is a function of c1 alone (c2 = a*c1 mod M), so the sweep is exhaustive.
+__global__ __launch_bounds__(256) void k_certify(unsigned int* __restrict__ max_bits) {
+    float m = 0.f;
+    const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+    for (unsigned long long c = 1 + (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+         c <= LCG_M - (1u << NEAR_ONE_BITS); c += stride) {
+        const uint32_t c1 = (uint32_t)c, c2 = lcg_mul(c1, LCG_A);
+        const double xe = box_muller_exact(c1, c2);
+        const float e0 = fabsf((float)((double)box_muller_fast(c1) - xe));
+        m = fmaxf(m, e0);
+        if (!(e0 == e0)) m = __builtin_inff();
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(max_bits, __float_as_uint(m));
+}
+
+// ---- k_store_probe: pure streaming store, the measured HBM write ceiling --------------------
+__global__ __launch_bounds__(256) void k_store_probe(uint4* __restrict__ dst, size_t n16, uint32_t v) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride)
+        dst[i] = make_uint4(v, v + 1, v + 2, (uint32_t)i);
+}
+
