@@ -160,18 +160,18 @@ __global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restr
 // The per-read loop nest of src/gensig.c:249-282 is split at its only sequential dependency:
 //
 // k_events   one workgroup of NT threads per worker chain (a worker's reads of this batch, in
-//            batch order); a read is walked in segments of NT consecutive events, one event per
-//            thread: k-mer rank, dwell, block scan -> first sample of each 64-event tile, and the
-//            hand-out of the per-(worker,k-mer) Lehmer streams IN EVENT ORDER: events are binned
-//            by k-mer in an LDS hash table, bin members listed through a block scan, and each
-//            event sums the dwell of the same-k-mer events before it (bins hold 1-3 events).
-//            Stream states live in HBM/L2 (rows[worker][rank]): one load per event and one store
-//            per bin, advanced by an O(1) jump a^(2*samples).  Output: 8 B per event
-//            {state at the event's first draw, rank}.
-// k_samples  one wavefront per 64-event tile, no inter-wave dependency and no block barrier:
-//            64 consecutive samples per step (contiguous int16 stores).  sample -> event through
-//            start-marker bytes in LDS + ballot/mbcnt; the two draws of a sample are two modular
-//            multiplications of the event's state with per-slot constants a^(2j+1), a^(2j+2).
+//            batch order); a read is walked in segments of NT*EPT consecutive events, EPT consecutive
+//            events per thread: dwell draw, k-mer rank, block scan -> first sample of each 64-event
+//            tile, and the hand-out of the per-(worker,k-mer) Lehmer streams IN EVENT ORDER.
+//            k <= 6: the worker's 4^k stream states stay in LDS for the whole chain and the events of
+//            a segment that share a k-mer chain through the state table itself (atomicExch).
+//            k > 6: an LDS open-addressing hash; HBM holds the number of samples each stream has
+//            produced, one returning atomicAdd per k-mer bin, state = seed * a^(2*count).
+//            Either way an event sums the dwell of the same-k-mer events before it (bins hold 1-3
+//            events) and needs one modular multiplication.  Output: 8 B per event {state at the
+//            event's first draw, rank}.
+// k_samples  (k_samples.h) one wavefront per work item, no inter-wave dependency and no block
+//            barrier: 64 consecutive samples per step (contiguous int16 stores).
 #ifndef SQG_EVENT_THREADS
 #define SQG_EVENT_THREADS 256
 #endif
