@@ -109,3 +109,39 @@ def test_random_genomes(seed, tmp_path):
     T = int(rng.integers(1, 9))
     batches = [int(rng.integers(1, 2 * T + 1)) for _ in range(3)]
     _run("dna-r9-prom", 6, str(fa), T, batches, rlen=int(rng.choice([300, 1000, 5000])), seed=int(rng.integers(1, 1 << 20)))
+
+
+@pytest.mark.gpu
+def test_sampler_shards_equal_one_context():
+    """Multi-GPU sharding of the sampler: a context that owns workers [lo, hi) draws exactly the reads the
+    single-context run draws for those workers (streams are per worker; no exchange)."""
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    mean, stdv = model.synthetic_model(6)
+    orac = orc.Oracle(prof, fl, 6, mean, stdv, 5, num_workers=1)
+    contigs = _contigs(orac.load_ref(NCOV))
+    orac.close()
+    T = 12
+    one = api.SignalGenerator(prof, fl, 6, mean, stdv, 5, num_workers=T, mode=api.MODE_CERTIFIED)
+    one.load_genome(contigs, 1200)
+    shards = []
+    for lo, hi in ((0, 5), (5, 12)):
+        g = api.SignalGenerator(prof, fl, 6, mean, stdv, 5, num_workers=T, mode=api.MODE_CERTIFIED, worker_lo=lo, worker_hi=hi)
+        g.load_genome(contigs, 1200)
+        shards.append((lo, hi, g))
+    for _ in range(3):                                         # several batches: the streams carry over
+        b = one.sample(T).run().wait()
+        sig = b.signal()
+        for lo, hi, g in shards:
+            bs = g.sample(hi - lo, workers=np.arange(lo, hi, dtype=np.int32)).run().wait()
+            ss = bs.signal()
+            for j in range(hi - lo):
+                i = lo + j
+                for key in ("ref_idx", "ref_pos", "rlen"):
+                    assert bs.sampled[key][j] == b.sampled[key][i]
+                assert bs.sampled["strand"][j] == b.sampled["strand"][i]
+                np.testing.assert_array_equal(ss[bs.sig_off[j]:bs.sig_off[j + 1]], sig[b.sig_off[i]:b.sig_off[i + 1]])
+            bs.free()
+        b.free()
+    one.close()
+    for _, _, g in shards:
+        g.close()
