@@ -168,6 +168,8 @@ class Batch:
         """int16 samples of the batch; `out` may be (a view of) a pinned buffer from SignalGenerator.pinned()."""
         if out is None:
             out = np.empty(self.n_samples, np.int16)
+        elif out.dtype != np.int16 or len(out) < self.n_samples:
+            raise ValueError("destination too small for the batch's samples")
         self.gen._chk(self.gen.L.sqg_fetch_signal(self.gen.ctx, self.handle, out.ctypes.data), "sqg_fetch_signal")
         return out[:self.n_samples]
 
