@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_dwell(const ReadDesc* __restrict__ read
 // ---- k_scan: sig_off = exclusive scan of per-read totals (single workgroup) -----------------
 // sig_off goes to HBM for the kernels and, through the pinned host mapping, straight to the host (no D2H copy
 // between kernels): host_off is visible once the stream has been synchronised.
-#define SCAN_PER 8
+#define SCAN_PER 32
 __global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restrict__ seglen, int n_reads,
                                                long long* __restrict__ sig_off, long long* __restrict__ host_off,
                                                unsigned int* __restrict__ err, unsigned int* __restrict__ counters) {

@@ -11,7 +11,7 @@ import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-key = sys.argv[3] if len(sys.argv) > 3 else "dna-r9-prom|batch_reads=8192|rlen=10000|mode=certified"
+key = sys.argv[3] if len(sys.argv) > 3 else "dna-r9-prom|batch_reads=32768|rlen=10000|mode=certified"
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f, name in (("pmc4", "FETCH_SIZE"), ("pmc5", "WRITE_SIZE")):
     path = os.path.join(src, f + "_counter_collection.csv")
