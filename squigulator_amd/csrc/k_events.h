@@ -179,10 +179,11 @@ __global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restr
 #define SQG_EVENT_EPT 2     // consecutive events per thread of k_events (segment = SQG_EVENT_THREADS * SQG_EVENT_EPT events)
 #endif
 #ifndef SQG_EVENT_WAVES
-#define SQG_EVENT_WAVES 6   // waves per SIMD the register allocation of k_events aims at (LDS allows 7 workgroups per CU)
+#define SQG_EVENT_WAVES 7   // waves per SIMD the register allocation of k_events aims at (LDS allows 7 workgroups per CU)
 #endif
 #define MK_W 1024          // marker window (samples) per wavefront
 #define MULT_N 512         // LDS jump constants cover events of up to 512 samples
+#define EV_JUMP_N 256      // k_events' own jump table: bins of >= 256 samples go through the three-level global tables
 #define BIN_EMPTY 0xffffffffu
 
 // inclusive wave scan with DPP row shifts/broadcasts (6 VALU, no LDS)
@@ -218,7 +219,7 @@ struct EvLds {
     uint32_t st[SEG];                        // DIRECT: the state the bin's first exchanger swapped out of row[]; else: the
                                              // bin's state at the start of the segment, published by its first event
     uint32_t nxt[SEG];          // per event: (dwell << 16) | next event in the same bin
-    uint32_t jump[(MULT_N > SEG ? MULT_N : SEG)];    // a^(2j)
+    uint32_t jump[EV_JUMP_N];   // a^(2j), j < EV_JUMP_N
     uint8_t codes[SEG + EV_HALO + 4];  // 2-bit base codes of the segment
     uint8_t lut[256];           // base -> 2-bit code (src/seq.h:14-27)
     int wsum[NT / 64];
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
     __shared__ long long n1_sh;
     constexpr int NW = NT / 64, SEG = NT * EPT, HT = 2 * SEG, TL = 64 / EPT;   // TL: lanes per 64-event tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int i = tid; i < (MULT_N > SEG ? MULT_N : SEG); i += NT) L.jump[i] = P.pw[2 * POW_N + i];
+    for (int i = tid; i < EV_JUMP_N; i += NT) L.jump[i] = P.pw[2 * POW_N + i];
     for (int i = tid; i < 256; i += NT) L.lut[i] = (uint8_t)base_code((uint8_t)i);
 
     const int chain = P.chain_order[blockIdx.x];
@@ -251,6 +252,7 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
                                         (unsigned long long)(P.rows ? P.reads[P.chain_reads[c_lo]].worker : 0) * P.seed_step) % LCG_M);
     if (DIRECT && P.use_streams) for (int i = tid; i < P.num_kmer; i += NT) L.row[i] = row[i];
     const uint32_t a2nt = DW ? lcg_jump2(P.pw, (uint32_t)SEG) : 0u;      // time-stream jump over one segment
+    const uint32_t a2jn = DW ? lcg_jump2(P.pw, (uint32_t)EV_JUMP_N) : 0u; // ... and over EV_JUMP_N events
     const float dw_sf = (float)P.dstd, dw_mf = (float)P.dmean;
     // delta_x*s (swept) + float roundings of s, m and the fma (each <= 2^-24 * mag) + slack
     const float dw_eps = P.delta_x * fabsf(dw_sf) + 4.0f * 5.9604645e-8f * (fabsf(dw_mf) + 7.0f * fabsf(dw_sf) + 1.0f) + 1e-6f;
@@ -293,6 +295,14 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
             for (int q = 0; q < EPT; q++) code_cur[q] = L.lut[b_cur[q]];                     // consumed after the dwell draw
             const uint8_t code_halo = L.lut[tid < EV_HALO ? b_halo : (uint8_t)'A'];
             int sps[EPT];
+            // c_seg * a^(512*h): the segment state advanced to event 256*h (scalar unit)
+            uint32_t c_seg_hi[(NT * EPT + EV_JUMP_N - 1) / EV_JUMP_N];
+            if (DW) {
+                c_seg_hi[0] = c_seg;
+#pragma unroll
+                for (int h2 = 1; h2 < (NT * EPT + EV_JUMP_N - 1) / EV_JUMP_N; h2++)
+                    c_seg_hi[h2] = __builtin_amdgcn_readfirstlane(lcg_mul(c_seg_hi[h2 - 1], a2jn));
+            }
 #pragma unroll
             for (int q = 0; q < EPT; q++) {
                 const int e = e0 + q;
@@ -302,7 +312,14 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
                     sps[q] = valid ? (P.dwell ? (int)d_cur[q] : P.const_sps) : 0;
                 } else if (valid) {
                     // event e uses draws 2e+1, 2e+2 of the worker's time stream after the read's first state
-                    const uint32_t c1 = lcg_mul(c_seg, L.jump[tid * EPT + q]);
+                    // draw of event id = tid*EPT+q: a^(2*id) = a^(2*(id % 256)) * a^(512*(id / 256)); the second factor is
+                    // folded into the (scalar) segment state
+                    constexpr int ID_HI = (NT * EPT + EV_JUMP_N - 1) / EV_JUMP_N;
+                    const int id_ = tid * EPT + q;
+                    uint32_t cs = c_seg_hi[0];
+#pragma unroll
+                    for (int h2 = 1; h2 < ID_HI; h2++) cs = (id_ / EV_JUMP_N == h2) ? c_seg_hi[h2] : cs;
+                    const uint32_t c1 = lcg_mul(cs, L.jump[id_ % EV_JUMP_N]);
                     bool decided = false;
                     int v = 0;
                     if (DW == 1) {
@@ -437,7 +454,7 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
                             const uint32_t n_old = atomicAdd(&row[rank[q]], total[q]);
                             const unsigned long long sv = (unsigned long long)seed_w + rank[q];
                             uint32_t cb = (uint32_t)(sv >= LCG_M ? sv - LCG_M : sv);
-                            if (n_old) cb = lcg_mul(cb, n_old < MULT_N ? L.jump[n_old] : lcg_jump2(P.pw, n_old));
+                            if (n_old) cb = lcg_mul(cb, n_old < EV_JUMP_N ? L.jump[n_old] : lcg_jump2(P.pw, n_old));
                             c_row[q] = cb;
                             L.st[id] = cb;
                         }
@@ -449,11 +466,11 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
                     if (EV_IN(e0 + q)) {
                         if (DIRECT) {
                             const uint32_t n = first[q] ? total[q] : prior[q];                  // > 0: every event has >= 1 sample
-                            const uint32_t m = lcg_mul(c_row[q], n < MULT_N ? L.jump[n] : lcg_jump2(P.pw, n));
+                            const uint32_t m = lcg_mul(c_row[q], n < EV_JUMP_N ? L.jump[n] : lcg_jump2(P.pw, n));
                             if (first[q]) { c_ev[q] = c_row[q]; L.row[rank[q]] = m; }
                             else c_ev[q] = m;
                         } else if (first[q]) c_ev[q] = c_row[q];
-                        else c_ev[q] = lcg_mul(L.st[fid[q]], prior[q] < MULT_N ? L.jump[prior[q]] : lcg_jump2(P.pw, prior[q]));
+                        else c_ev[q] = lcg_mul(L.st[fid[q]], prior[q] < EV_JUMP_N ? L.jump[prior[q]] : lcg_jump2(P.pw, prior[q]));
                     }
                 }
             }
