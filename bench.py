@@ -403,8 +403,8 @@ def main():
         }
         if not args.no_store_probe:
             out["roofline"]["measured_store_peak_GBps"] = gen.probe_store_bandwidth(1 << 30, 10) / 1e9
-        if not args.no_cpu_baseline and args.workload != "ncov-r9":
-            out["cpu_baseline"] = None                       # the CPU legs are set up for the headline workload only
+        if not args.no_cpu_baseline and (args.workload != "ncov-r9" or world > 1):
+            out["cpu_baseline"] = None                       # the CPU legs: headline workload, single-GPU run only
         elif not args.no_cpu_baseline:
             # the reference's own gensig.c/genread.c (oracle/_ref, kind "reference") when the harness travelled with the
             # repo, else the oracle restatement (kind "port"); the other one is reported next to it
