@@ -728,23 +728,33 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     sqg_ctx::Slot& S = c->slot[b->slot];
     // this slot's buffers were last used by the sample kernels of batch seq-2 (stream2)
     HIPCHK(c, hipStreamWaitEvent(c->stream, S.done, 0));
-    if ((size_t)n + 1 > S.reads_cap) {
-        HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
-        (void)hipFree(S.d_seglen); (void)hipFree(S.d_sigoff); S.d_seglen = nullptr; S.d_sigoff = nullptr;
-        const size_t cap = (size_t)n + 1 + (size_t)n / 2;
-        HIPCHK(c, hipMalloc(&S.d_seglen, 2 * cap * sizeof(unsigned long long)));
-        HIPCHK(c, hipMalloc(&S.d_sigoff, cap * sizeof(long long)));
-        S.reads_cap = cap;
-    }
-    if ((rc = ensure(c, (void**)&S.d_dwell, &S.dwell_cap, (size_t)b->n_events + 64, sizeof(uint16_t)))) return rc;
-    if ((rc = ensure(c, (void**)&S.d_evrec, &S.evrec_cap, (size_t)b->n_events + 64, sizeof(uint2)))) return rc;
-    if ((rc = ensure(c, (void**)&S.d_tile_so, &S.tile_cap, (size_t)b->n_tiles + 64, sizeof(uint32_t)))) return rc;
-    if ((rc = ensure(c, (void**)&S.d_slow, &S.slow_cap, (size_t)b->n_tiles + 64, sizeof(int)))) return rc;
-    if (certified && c->use_kmer_streams) {
-        if ((rc = ensure(c, (void**)&S.d_tfix, &S.tfix_cap, (size_t)b->n_stiles * FIX_SLOTS + 64, sizeof(uint4)))) return rc;
-        if ((rc = ensure(c, (void**)&S.d_tfix_n, &S.tfixn_cap, (size_t)b->n_stiles + 64, 1))) return rc;
-        if ((rc = ensure(c, (void**)&S.d_items, &S.items_cap, (size_t)b->n_stiles + 64, sizeof(ItemDesc)))) return rc;
-    }
+    // per-slot buffers grow on demand; a slot that has never been used is sized together with the first one, so that
+    // a host that warms up with a single batch does not pay the second slot's allocations later
+    auto grow = [&](sqg_ctx::Slot& Z) -> int {
+        int rc2;
+        if ((size_t)n + 1 > Z.reads_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
+            (void)hipFree(Z.d_seglen); (void)hipFree(Z.d_sigoff); Z.d_seglen = nullptr; Z.d_sigoff = nullptr;
+            const size_t cap = (size_t)n + 1 + (size_t)n / 2;
+            HIPCHK(c, hipMalloc(&Z.d_seglen, 2 * cap * sizeof(unsigned long long)));
+            HIPCHK(c, hipMalloc(&Z.d_sigoff, cap * sizeof(long long)));
+            Z.reads_cap = cap;
+        }
+        if ((rc2 = ensure(c, (void**)&Z.d_dwell, &Z.dwell_cap, (size_t)b->n_events + 64, sizeof(uint16_t)))) return rc2;
+        if ((rc2 = ensure(c, (void**)&Z.d_evrec, &Z.evrec_cap, (size_t)b->n_events + 64, sizeof(uint2)))) return rc2;
+        if ((rc2 = ensure(c, (void**)&Z.d_tile_so, &Z.tile_cap, (size_t)b->n_tiles + 64, sizeof(uint32_t)))) return rc2;
+        if ((rc2 = ensure(c, (void**)&Z.d_slow, &Z.slow_cap, (size_t)b->n_tiles + 64, sizeof(int)))) return rc2;
+        if (certified && c->use_kmer_streams) {
+            if ((rc2 = ensure(c, (void**)&Z.d_tfix, &Z.tfix_cap, (size_t)b->n_stiles * FIX_SLOTS + 64, sizeof(uint4)))) return rc2;
+            if ((rc2 = ensure(c, (void**)&Z.d_tfix_n, &Z.tfixn_cap, (size_t)b->n_stiles + 64, 1))) return rc2;
+            if ((rc2 = ensure(c, (void**)&Z.d_items, &Z.items_cap, (size_t)b->n_stiles + 64, sizeof(ItemDesc)))) return rc2;
+        }
+        return SQG_OK;
+    };
+    sqg_ctx::Slot& other = c->slot[b->slot ^ 1];
+    const bool other_fresh = other.reads_cap == 0 && n > 0;
+    if ((rc = grow(S))) return rc;
+    if (other_fresh && (rc = grow(other))) return rc;
 
     // Dwell draws are made inside k_events (SQG_SEPARATE_DWELL=1 keeps the stand-alone k_dwell for A/B runs).
     static const bool separate_dwell = getenv("SQG_SEPARATE_DWELL") != nullptr;
@@ -820,9 +830,12 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
             need_samples = (size_t)b->h_sigoff[n];
         }
     }
-    if ((rc = ensure(c, (void**)&S.d_sig, &S.sig_cap, need_samples + 64, sizeof(int16_t)))) return rc;
-    if (certified && c->use_kmer_streams) {
-        if ((rc = ensure(c, (void**)&S.d_fix, &S.fix_cap, (c->force_fix ? need_samples : need_samples / 256) + 65536, sizeof(FixEntry)))) return rc;
+    for (int z = 0; z < (other_fresh ? 2 : 1); z++) {
+        sqg_ctx::Slot& Z = z ? other : S;
+        if ((rc = ensure(c, (void**)&Z.d_sig, &Z.sig_cap, need_samples + 64, sizeof(int16_t)))) return rc;
+        if (certified && c->use_kmer_streams) {
+            if ((rc = ensure(c, (void**)&Z.d_fix, &Z.fix_cap, (c->force_fix ? need_samples : need_samples / 256) + 65536, sizeof(FixEntry)))) return rc;
+        }
     }
 
     if (n > 0 && b->n_chains > 0) {
