@@ -375,6 +375,41 @@ extern "C" void sqg_batch_free(sqg_ctx_t* ctx, sqg_batch_t* b) {
     delete b;
 }
 
+// Per-slot device buffers for a batch of this geometry.  with_output: also the signal slab and the fix-up list, sized
+// by the hard bound on the dwell (skipped when that bound is unreasonable; sqg_batch_run then reads the scan back).
+static int grow_slot(sqg_ctx* c, sqg_ctx::Slot& Z, const sqg_batch* b, bool with_output) {
+    int rc2;
+    const int n = b->n;
+    const bool certified = c->cfg.mode == SQG_MODE_CERTIFIED;
+    if ((size_t)n + 1 > Z.reads_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
+        (void)hipFree(Z.d_seglen); (void)hipFree(Z.d_sigoff); Z.d_seglen = nullptr; Z.d_sigoff = nullptr;
+        const size_t cap = (size_t)n + 1 + (size_t)n / 2;
+        HIPCHK(c, hipMalloc(&Z.d_seglen, 2 * cap * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc(&Z.d_sigoff, cap * sizeof(long long)));
+        Z.reads_cap = cap;
+    }
+    if ((rc2 = ensure(c, (void**)&Z.d_dwell, &Z.dwell_cap, (size_t)b->n_events + 64, sizeof(uint16_t)))) return rc2;
+    if ((rc2 = ensure(c, (void**)&Z.d_evrec, &Z.evrec_cap, (size_t)b->n_events + 64, sizeof(uint2)))) return rc2;
+    if ((rc2 = ensure(c, (void**)&Z.d_tile_so, &Z.tile_cap, (size_t)b->n_tiles + 64, sizeof(uint32_t)))) return rc2;
+    if ((rc2 = ensure(c, (void**)&Z.d_slow, &Z.slow_cap, (size_t)b->n_tiles + 64, sizeof(int)))) return rc2;
+    if (certified && c->use_kmer_streams) {
+        if ((rc2 = ensure(c, (void**)&Z.d_tfix, &Z.tfix_cap, (size_t)b->n_stiles * FIX_SLOTS + 64, sizeof(uint4)))) return rc2;
+        if ((rc2 = ensure(c, (void**)&Z.d_tfix_n, &Z.tfixn_cap, (size_t)b->n_stiles + 64, 1))) return rc2;
+        if ((rc2 = ensure(c, (void**)&Z.d_items, &Z.items_cap, (size_t)b->n_stiles + 64, sizeof(ItemDesc)))) return rc2;
+    }
+    if (with_output) {
+        const double bound = c->dwell_hi * (double)b->n_events;
+        if (bound <= 4.0e10) {
+            const size_t need = (size_t)bound;
+            if ((rc2 = ensure(c, (void**)&Z.d_sig, &Z.sig_cap, need + 64, sizeof(int16_t)))) return rc2;
+            if (certified && c->use_kmer_streams)
+                if ((rc2 = ensure(c, (void**)&Z.d_fix, &Z.fix_cap, (c->force_fix ? need : need / 256) + 65536, sizeof(FixEntry)))) return rc2;
+        }
+    }
+    return SQG_OK;
+}
+
 // Staging shared by sqg_batch_stage (reads come from the host: seqs != null) and sqg_batch_sample (reads were
 // sampled on the device: seqs == null, d_rec holds one SampleRec per read and k_copy_reads fills the base buffer).
 #include <chrono>
@@ -570,6 +605,9 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     CHKB(hipStreamSynchronize(c->stream));     // staging buffers above are stack-owned
     st_mark("sync");
 #undef CHKB
+    // slots that have never held a batch are sized now, so that not even the first run allocates
+    for (auto& Z : c->slot)
+        if (Z.reads_cap == 0 && n > 0) { const int rg = grow_slot(c, Z, b, /*with_output=*/true); if (rg) return bail(rg); }
     c->next_stage++;
     *out = b;
     return SQG_OK;
@@ -728,29 +766,7 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     sqg_ctx::Slot& S = c->slot[b->slot];
     // this slot's buffers were last used by the sample kernels of batch seq-2 (stream2)
     HIPCHK(c, hipStreamWaitEvent(c->stream, S.done, 0));
-    // per-slot buffers grow on demand; a slot that has never been used is sized together with the first one, so that
-    // a host that warms up with a single batch does not pay the second slot's allocations later
-    auto grow = [&](sqg_ctx::Slot& Z) -> int {
-        int rc2;
-        if ((size_t)n + 1 > Z.reads_cap) {
-            HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
-            (void)hipFree(Z.d_seglen); (void)hipFree(Z.d_sigoff); Z.d_seglen = nullptr; Z.d_sigoff = nullptr;
-            const size_t cap = (size_t)n + 1 + (size_t)n / 2;
-            HIPCHK(c, hipMalloc(&Z.d_seglen, 2 * cap * sizeof(unsigned long long)));
-            HIPCHK(c, hipMalloc(&Z.d_sigoff, cap * sizeof(long long)));
-            Z.reads_cap = cap;
-        }
-        if ((rc2 = ensure(c, (void**)&Z.d_dwell, &Z.dwell_cap, (size_t)b->n_events + 64, sizeof(uint16_t)))) return rc2;
-        if ((rc2 = ensure(c, (void**)&Z.d_evrec, &Z.evrec_cap, (size_t)b->n_events + 64, sizeof(uint2)))) return rc2;
-        if ((rc2 = ensure(c, (void**)&Z.d_tile_so, &Z.tile_cap, (size_t)b->n_tiles + 64, sizeof(uint32_t)))) return rc2;
-        if ((rc2 = ensure(c, (void**)&Z.d_slow, &Z.slow_cap, (size_t)b->n_tiles + 64, sizeof(int)))) return rc2;
-        if (certified && c->use_kmer_streams) {
-            if ((rc2 = ensure(c, (void**)&Z.d_tfix, &Z.tfix_cap, (size_t)b->n_stiles * FIX_SLOTS + 64, sizeof(uint4)))) return rc2;
-            if ((rc2 = ensure(c, (void**)&Z.d_tfix_n, &Z.tfixn_cap, (size_t)b->n_stiles + 64, 1))) return rc2;
-            if ((rc2 = ensure(c, (void**)&Z.d_items, &Z.items_cap, (size_t)b->n_stiles + 64, sizeof(ItemDesc)))) return rc2;
-        }
-        return SQG_OK;
-    };
+    auto grow = [&](sqg_ctx::Slot& Z) -> int { return grow_slot(c, Z, b, /*with_output=*/false); };
     sqg_ctx::Slot& other = c->slot[b->slot ^ 1];
     const bool other_fresh = other.reads_cap == 0 && n > 0;
     if ((rc = grow(S))) return rc;
