@@ -241,9 +241,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-reads", type=int, default=32768,
-                    help="reads per step per GPU (= virtual workers per GPU); throughput grows with it up to ~32768 "
-                         "(1.4e11 samples/s at 512, 4.8e11 at 8192, 5.4e11 at 32768 and 65536)")
+    ap.add_argument("--batch-reads", type=int, default=None,
+                    help="reads per step per GPU (= virtual workers per GPU).  Default 32768 (6-mer: 1.4e11 samples/s at 512, "
+                         "4.8e11 at 8192, 5.4e11 at 32768 and 65536); 16384 for the 9-mer workload, whose 1-MiB-per-worker "
+                         "state table makes larger batches slower (1.2e11 at 1024, 1.63e11 at 8192-16384, 1.54e11 at 32768)")
     ap.add_argument("--rlen", type=int, default=10000)
     ap.add_argument("--workload", default="ncov-r9", choices=sorted(WORKLOADS),
                     help="ncov-r9 is the headline (BASELINE.json configs[1]); the others are the remaining configs, reported for information")
@@ -281,6 +282,8 @@ def main():
             dist.init_process_group("gloo")
 
     wl_profile, wl_flags, wl_mode, wl_desc = WORKLOADS[args.workload]
+    if args.batch_reads is None:
+        args.batch_reads = 16384 if args.workload == "synth-r10" else 32768
     if args.profile is None:
         args.profile = wl_profile
     prof, flags = profiles.get_profile(args.profile)
