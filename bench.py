@@ -365,7 +365,7 @@ def main():
 
     if rank == 0:
         steps = max(args.steps, 1)
-        alg_bytes = (2 * samples + bases + 24 * reads) / steps           # per k_signal launch (this rank)
+        alg_bytes = (2 * samples + bases + 24 * reads) / steps           # per k_samples_lean launch (this rank)
         k_ms = float(np.mean(lean_ms)) if lean_ms else float("nan")     # the dominant kernel alone
         achieved = alg_bytes / (k_ms * 1e-3)
         out = {

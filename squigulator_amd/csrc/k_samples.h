@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void k_samples(const SigParams P, const int n_
     }
 }
 
-// ---- k_fixup: FP64 path for the samples k_signal<CERTIFIED> left undecided -------------------
+// ---- k_fixup: FP64 path for the samples the certified kernels left undecided ------------------
 // per-tile slots of the lean kernel: one thread per super tile walks its (0-8, typically 0-1) parked samples.
 // No atomics: a returning atomic per wavefront on one counter costs ~10 ns each and serialises.
 __global__ __launch_bounds__(256) void k_fixup_tiles(const SigParams P, const int n_stiles) {

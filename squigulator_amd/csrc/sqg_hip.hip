@@ -1,7 +1,7 @@
 // sqg_hip.hip -- MI355X (gfx950) implementation of include/sqg.h.
 //
 // Host side of the C ABI: context/batch management, staging, launches, timing.  The gfx950
-// kernels (k_dwell, k_scan, k_signal, k_fixup, k_certify) are in sqg_kernels.h.
+// kernels are in sqg_kernels.h (k_common.h, k_events.h, k_samples.h, k_sampler.h, k_svb.h).
 // No MFMA anywhere: this is an integer-LCG / transcendental / streaming-store path.
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (see squigulator_amd/build.py).
 //
