@@ -130,6 +130,8 @@ struct ItemDesc {
     uint32_t at0;                // position within the read of the item's first sample (RNA: counted from the read's end)
     int ev_read0;                // index within the read of the item's first event
     int read;                    // read index (fix-up overflow path)
+    int shift_lo, shift_hi;      // RNA adaptor level-shift window (src/genread.c:79-86) as sample indices within the item
+                                 // (generation order): samples lo <= i < hi get -shift; hi <= lo: none
     int pad;
 };
 

@@ -63,9 +63,13 @@ __global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_st
     const uint32_t next_pos = (lt + 1) * LEAN_EV < ne ? P.tile_so[rd.tile_off + (lt + 1) * LEAN_EPL] : read_len;
     const int n_samples = (int)(next_pos - base_pos);
     bool take = rd.fast != 0 && n_samples <= LEAN_MAX_SAMPLES;
+    int shift_lo = 0, shift_hi = 0;
     if (P.shift_len > 0) {                                             // RNA adaptor level-shift window (src/genread.c:79-86)
         const long long n1 = (long long)P.seglen[2 * r];
-        if ((long long)base_pos + n_samples > n1 - P.shift_len && (long long)base_pos < n1) take = false;
+        if ((long long)base_pos + n_samples > n1 - P.shift_len && (long long)base_pos < n1) {
+            shift_lo = (int)max(n1 - P.shift_len - (long long)base_pos, 0LL);
+            shift_hi = (int)min(n1 - (long long)base_pos, (long long)n_samples);
+        }
     }
     if (!take) {                                                       // leave these (up to 4) 64-event tiles to the generic kernel
         const int nt = (n_ev + 63) >> 6;
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_st
     d.at0 = P.rna ? read_len - 1u - base_pos : base_pos;
     d.ev_read0 = lt * LEAN_EV;
     d.read = r;
+    d.shift_lo = shift_lo; d.shift_hi = shift_hi;
     d.pad = 0;
     P.items[g] = d;
     P.tfix_n[g] = 0;
@@ -100,7 +105,7 @@ struct LeanLds {
 };
 
 // k_samples_lean: the hot kernel.  Certified fp32 path only, for reads whose ADC values are provably in
-// (2, 65000) (ReadDesc.fast), events of <= MULT_N samples, outside the RNA level-shift window; everything
+// (2, 65000) (ReadDesc.fast), events of <= MULT_N samples (the RNA level-shift window included); everything
 // else is queued (as 64-event tiles) for k_samples<MODE, GENERIC>.
 // One wavefront per 256 consecutive events of a read (4 per lane: the dependent global round trips of the
 // set-up are paid once per ~2300 samples; the item's descriptors are wave-uniform and live in SGPRs).
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
             ev_ = (int)__builtin_amdgcn_mbcnt_hi(hi_, __builtin_amdgcn_mbcnt_lo(lo_, (uint32_t)base_ev));          \
             base_ev += __builtin_popcount(lo_) + __builtin_popcount(hi_); }
         // one step: issue the loads of step c_+1 into (RN, MN, EN), then the arithmetic of step c_ from (RA, MU, EV)
-        #define LEAN_STEP(TAIL, c_, RA, MU, EV, RN, MN, EN) {                                                    \
+        #define LEAN_STEP(SH, TAIL, c_, RA, MU, EV, RN, MN, EN) {                                                    \
             LEAN_MAP(min((c_) + 1, 63), EN)                                                                       \
             RN = W.rec[EN];                                                                                       \
             LEAN_ARITH(RA, MU)                                                                                    \
@@ -221,13 +226,16 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
             const float d = vh - (t - LEAN_MAGIC);                                                                \
             const bool act = !(TAIL) || (int)(idx8 >> 3) < wave_total;                                            \
             const bool ok = fabsf(d) < thr && c1 <= LCG_M - (1u << NEAR_ONE_BITS);                                \
-            if (act && ok LEAN_STORE_COND) *reinterpret_cast<uint16_t*>(out_b + voff) = (uint16_t)((__float_as_uint(t) + RA.y) & 0xffffu); \
+            /* RNA adaptor window: the ADC value gets -(int16)(30*dig/range) with int16 wrap (src/genread.c:79-86) */ \
+            const bool shf = (SH) && (uint32_t)((int)(idx8 >> 3) - it.shift_lo) < (uint32_t)(it.shift_hi - it.shift_lo);       \
+            if (act && ok LEAN_STORE_COND) *reinterpret_cast<uint16_t*>(out_b + voff) =                            \
+                (uint16_t)((__float_as_uint(t) + RA.y - (shf ? (uint32_t)P.shift : 0u)) & 0xffffu);                \
             else if (act) {                                        /* ~1 % of steps: park the undecided samples (no round trip) */ \
                 const unsigned long long am = __builtin_amdgcn_ballot_w64(true);                                  \
                 const int n0 = W.nfix;                                                                            \
                 const int slot = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)); \
-                if (slot < FIX_SLOTS) P.tfix[(size_t)g * FIX_SLOTS + slot] = make_uint4(voff >> 1, c1, (uint32_t)(ev_read0 + EV), 0u); \
-                else push_fix_one(P, it.sig_base + (voff >> 1), c1, it.ev_first + EV, it.read, 0);   /* overflow (never in practice): global list */ \
+                if (slot < FIX_SLOTS) P.tfix[(size_t)g * FIX_SLOTS + slot] = make_uint4(voff >> 1, c1, (uint32_t)(ev_read0 + EV), shf ? 1u : 0u); \
+                else push_fix_one(P, it.sig_base + (voff >> 1), c1, it.ev_first + EV, it.read, shf ? 1 : 0);   /* overflow (never in practice): global list */ \
                 if (slot + 1 == n0 + __popcll(am)) W.nfix = slot + 1;          /* the last of them publishes the new count */ \
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                            \
             }                                                                                                     \
@@ -252,15 +260,19 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         ra = W.rec[eva];
         ma = *reinterpret_cast<const uint32_t*>(mult_b + (((idx8 - (ra.y >> 16)) & 0xff8u) >> 1));
         int c = 0;
-        for (; c + 2 <= nfull; c += 2) {
-            LEAN_STEP(false, c, ra, ma, eva, rb, mb, evb)
-            LEAN_STEP(false, c + 1, rb, mb, evb, ra, ma, eva)
-        }
-        if (c < nfull) {
-            LEAN_STEP(false, c, ra, ma, eva, rb, mb, evb)
-            ra = rb; ma = mb; eva = evb; c++;
-        }
-        if (rem) LEAN_STEP(true, c, ra, ma, eva, rb, mb, evb)
+        // the (few) items that overlap the RNA level-shift window run the variant that tests every sample against it
+        #define LEAN_LOOP(SH)                                                                                    \
+            for (; c + 2 <= nfull; c += 2) {                                                                      \
+                LEAN_STEP(SH, false, c, ra, ma, eva, rb, mb, evb)                                                 \
+                LEAN_STEP(SH, false, c + 1, rb, mb, evb, ra, ma, eva)                                             \
+            }                                                                                                     \
+            if (c < nfull) {                                                                                      \
+                LEAN_STEP(SH, false, c, ra, ma, eva, rb, mb, evb)                                                 \
+                ra = rb; ma = mb; eva = evb; c++;                                                                 \
+            }                                                                                                     \
+            if (rem) LEAN_STEP(SH, true, c, ra, ma, eva, rb, mb, evb)
+        if (RNA && it.shift_hi > it.shift_lo) { LEAN_LOOP(true) } else { LEAN_LOOP(false) }
+        #undef LEAN_LOOP
         #undef LEAN_STEP
         #undef LEAN_MAP
         #undef LEAN_ARITH
@@ -465,7 +477,9 @@ __global__ __launch_bounds__(256) void k_fixup_tiles(const SigParams P, const in
         uint32_t rank = 0;
         for (int q = 0; q < P.k; q++) rank = (rank << 2) | base_code(bp[q]);
         const float2 md = P.model[rank];
-        P.sig[P.sig_off[r] + fe.x] = sample_exact(fe.y, md.x, md.y, P.dig, P.range, rd.offset);
+        int16_t q = sample_exact(fe.y, md.x, md.y, P.dig, P.range, rd.offset);
+        if (fe.w) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);      // RNA adaptor level shift
+        P.sig[P.sig_off[r] + fe.x] = q;
     }
 }
 
