@@ -145,3 +145,29 @@ def test_sampler_shards_equal_one_context():
     one.close()
     for _, _, g in shards:
         g.close()
+
+
+@pytest.mark.gpu
+def test_sampler_and_compress_error_paths():
+    """Loud failures, no silent fallbacks: sampling without a genome, bad genome arguments, stale batches."""
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    mean, stdv = model.synthetic_model(6)
+    gen = api.SignalGenerator(prof, fl, 6, mean, stdv, 1, num_workers=2, mode=api.MODE_CERTIFIED)
+    with pytest.raises(api.SqgError) as e:
+        gen.sample(2)
+    assert e.value.code == -1 and "sqg_genome_load" in str(e.value)
+    with pytest.raises(api.SqgError):
+        gen.load_genome([b"ACGT" * 100], 0)                       # -r must be positive
+    gen.load_genome([b"ACGT" * 100], 500)                          # 400 nt: reads get clipped, still >= 200
+    bs = [gen.sample(2).run().wait() for _ in range(3)]
+    enc, off = bs[2].compress()
+    assert off[-1] == len(enc) > 0
+    with pytest.raises(api.SqgError) as e:                         # batch 0's slot was reused by batch 2
+        bs[0].compress()
+    assert e.value.code == -4
+    with pytest.raises(api.SqgError) as e:
+        gen.sample(2, workers=np.array([0, 5], np.int32))          # worker 5 does not exist
+    assert e.value.code == -1
+    for b in bs:
+        b.free()
+    gen.close()
