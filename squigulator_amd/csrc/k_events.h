@@ -13,6 +13,18 @@ __global__ void k_init_rows(uint32_t* rows, int num_kmer, long long seed, int wo
     rows[i] = (uint32_t)s;
 }
 
+// ---- k_fill_tiles: tile -> read and super tile -> read maps, one workgroup per read -----------
+__global__ __launch_bounds__(64) void k_fill_tiles(const ReadDesc* __restrict__ reads, int n_reads, int lean_ev,
+                                                   int* __restrict__ tile_read, int* __restrict__ stile_read) {
+    const int r = blockIdx.x;
+    if (r >= n_reads) return;
+    const ReadDesc rd = reads[r];
+    const int ne = rd.ne0 + rd.ne1;
+    const int nt = (ne + 63) >> 6, nst = (ne + lean_ev - 1) / lean_ev;
+    for (int t = threadIdx.x; t < nt; t += 64) tile_read[rd.tile_off + t] = r;
+    for (int t = threadIdx.x; t < nst; t += 64) stile_read[rd.stile_off + t] = r;
+}
+
 // ---- k_dwell: one thread per event of the batch --------------------------------------------
 // sps = round(nrng(rand_time)); sps = sps<1 ? -sps+1 : sps           (src/gensig.c:255-256)
 // Event e of a read uses draws 2e+1, 2e+2 after the worker's time-stream state at the start of

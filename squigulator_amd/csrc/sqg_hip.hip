@@ -91,6 +91,7 @@ struct sqg_batch {
     std::vector<long long> ev_off, sig_off;
     std::vector<double> offset, median;
     std::vector<unsigned long long> seglen_host;   // only when dwell is constant
+    uint8_t* d_block = nullptr;          // the batch's one device allocation; the pointers below point into it
     uint8_t* d_bases = nullptr;
     ReadDesc* d_reads = nullptr;
     int* d_blk_read = nullptr;
@@ -367,8 +368,7 @@ static const char kShortHack[] = "ACGTACGTACGTA";   // src/gensig.c:242-245: "AC
 extern "C" void sqg_batch_free(sqg_ctx_t* ctx, sqg_batch_t* b) {
     if (!b) return;
     if (ctx) { (void)hipSetDevice(ctx->cfg.device); if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); }
-    (void)hipFree(b->d_bases); (void)hipFree(b->d_reads); (void)hipFree(b->d_blk_read);
-    (void)hipFree(b->d_chain_off); (void)hipFree(b->d_chain_reads); (void)hipFree(b->d_chain_order); (void)hipFree(b->d_tile_read); (void)hipFree(b->d_stile_read);
+    (void)hipFree(b->d_block);
     if (b->h_sigoff) (void)hipHostFree(b->h_sigoff);
     if (b->h_svboff) (void)hipHostFree(b->h_svboff);
     for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
@@ -462,16 +462,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     long long nst = 0;                                        // super tiles of 64*lean_epl events (work items of k_samples_lean)
     for (int i = 0; i < n; i++) { rd[(size_t)i].stile_off = (int)nst; rd[(size_t)i].pad = 0; nst += (rd[(size_t)i].ne0 + rd[(size_t)i].ne1 + lean_ev - 1) / lean_ev; }
     b->n_stiles = nst;
-    std::vector<int> stile_read((size_t)std::max<long long>(nst, 1));
-    for (int i = 0; i < n; i++) {
-        const int t1 = (i + 1 < n) ? rd[(size_t)i + 1].stile_off : (int)nst;
-        for (int t = rd[(size_t)i].stile_off; t < t1; t++) stile_read[(size_t)t] = i;
-    }
-    std::vector<int> tile_read((size_t)std::max<long long>(ntile, 1));
-    for (int i = 0; i < n; i++) {
-        const int t1 = (i + 1 < n) ? rd[(size_t)i + 1].tile_off : (int)ntile;
-        for (int t = rd[(size_t)i].tile_off; t < t1; t++) tile_read[(size_t)t] = i;
-    }
+    // the tile -> read maps are filled on the device (k_fill_tiles) once the descriptors are there
 
     st_mark("descriptors+tiles");
     // pass 2: base buffer (prefix/stall attached as src/genread.c:95-123 does)
@@ -514,9 +505,18 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     // launch order: longest chain first, so the tail of the grid is made of short chains
     std::vector<long long> chain_ev((size_t)b->n_chains, 0);
     for (int i = 0; i < n; i++) chain_ev[(size_t)chain_of[(size_t)wk[(size_t)i]]] += rd[(size_t)i].ne0 + rd[(size_t)i].ne1;
+    // (a counting sort over 4096 length classes: exact order within a class does not matter for the tail)
     std::vector<int> chain_order((size_t)b->n_chains);
-    for (int q = 0; q < b->n_chains; q++) chain_order[(size_t)q] = q;
-    std::stable_sort(chain_order.begin(), chain_order.end(), [&](int x, int y) { return chain_ev[(size_t)x] > chain_ev[(size_t)y]; });
+    {
+        long long mx = 1;
+        for (long long v : chain_ev) mx = std::max(mx, v);
+        constexpr int NB = 4096;
+        std::vector<int> cnt(NB + 1, 0);
+        auto cls = [&](long long v) { return (int)((NB - 1) - (v * (NB - 1)) / mx); };    // longest -> class 0
+        for (long long v : chain_ev) cnt[(size_t)cls(v) + 1]++;
+        for (int q = 0; q < NB; q++) cnt[(size_t)q + 1] += cnt[(size_t)q];
+        for (int q = 0; q < b->n_chains; q++) chain_order[(size_t)cnt[(size_t)cls(chain_ev[(size_t)q])]++] = q;
+    }
 
     const uint32_t a2 = lcg_mul(LCG_A, LCG_A);
     const bool no_lean = getenv("SQG_TEST_NO_LEAN") != nullptr;
@@ -573,30 +573,38 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     st_mark("chains+streams+blocks");
     auto bail = [&](int code) { sqg_batch_free(c, b); return code; };
 #define CHKB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE); } } while (0)
-    CHKB(hipMalloc(&b->d_bases, (size_t)nb + 16));
+    {   // one device allocation per batch, carved into the batch's arrays (256-byte aligned)
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_bases = carve((size_t)nb + 16), o_reads = carve(std::max<size_t>(1, rd.size()) * sizeof(ReadDesc)),
+                     o_blk = carve(blk_read.size() * sizeof(int)), o_coff = carve(chain_off.size() * sizeof(int)),
+                     o_crd = carve(std::max<size_t>(1, chain_reads.size()) * sizeof(int)),
+                     o_st = carve((size_t)std::max<long long>(nst, 1) * sizeof(int)), o_t = carve((size_t)std::max<long long>(ntile, 1) * sizeof(int)),
+                     o_ord = carve(std::max<size_t>(1, chain_order.size()) * sizeof(int));
+        CHKB(hipMalloc(&b->d_block, off));
+        uint8_t* base = b->d_block;
+        b->d_bases = base + o_bases; b->d_reads = (ReadDesc*)(base + o_reads); b->d_blk_read = (int*)(base + o_blk);
+        b->d_chain_off = (int*)(base + o_coff); b->d_chain_reads = (int*)(base + o_crd); b->d_stile_read = (int*)(base + o_st);
+        b->d_tile_read = (int*)(base + o_t); b->d_chain_order = (int*)(base + o_ord);
+    }
     if (seqs) CHKB(hipMemcpyAsync(b->d_bases, hb.data(), hb.size(), hipMemcpyHostToDevice, c->stream));
     else CHKB(hipMemsetAsync(b->d_bases + nb, 'A', 16, c->stream));
-    CHKB(hipMalloc(&b->d_reads, std::max<size_t>(1, rd.size()) * sizeof(ReadDesc)));
     if (n) CHKB(hipMemcpyAsync(b->d_reads, rd.data(), rd.size() * sizeof(ReadDesc), hipMemcpyHostToDevice, c->stream));
     if (!seqs && n) {                                      // the reads come from the resident genome
         hipLaunchKernelGGL(k_copy_reads, dim3((unsigned)n), dim3(256), 0, c->stream, c->genome, d_rec, b->d_reads, b->d_bases, n,
                            rna ? 1 : 0, prefix ? 1 : 0);
         CHKB(hipGetLastError());
     }
+    if (n) {
+        hipLaunchKernelGGL(k_fill_tiles, dim3((unsigned)n), dim3(64), 0, c->stream, b->d_reads, n, lean_ev, b->d_tile_read, b->d_stile_read);
+        CHKB(hipGetLastError());
+    }
     b->n_bases_total = nb;
     b->h_base_off.resize((size_t)n);
     for (int i = 0; i < n; i++) b->h_base_off[(size_t)i] = rd[(size_t)i].base_off;
-    CHKB(hipMalloc(&b->d_blk_read, blk_read.size() * sizeof(int)));
     CHKB(hipMemcpyAsync(b->d_blk_read, blk_read.data(), blk_read.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    CHKB(hipMalloc(&b->d_chain_off, chain_off.size() * sizeof(int)));
     CHKB(hipMemcpyAsync(b->d_chain_off, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    CHKB(hipMalloc(&b->d_chain_reads, std::max<size_t>(1, chain_reads.size()) * sizeof(int)));
     if (n) CHKB(hipMemcpyAsync(b->d_chain_reads, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    CHKB(hipMalloc(&b->d_stile_read, stile_read.size() * sizeof(int)));
-    CHKB(hipMemcpyAsync(b->d_stile_read, stile_read.data(), stile_read.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    CHKB(hipMalloc(&b->d_tile_read, tile_read.size() * sizeof(int)));
-    CHKB(hipMemcpyAsync(b->d_tile_read, tile_read.data(), tile_read.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    CHKB(hipMalloc(&b->d_chain_order, std::max<size_t>(1, chain_order.size()) * sizeof(int)));
     if (b->n_chains) CHKB(hipMemcpyAsync(b->d_chain_order, chain_order.data(), chain_order.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     CHKB(hipHostMalloc(&b->h_sigoff, ((size_t)n + 1) * sizeof(long long), hipHostMallocMapped));
     CHKB(hipHostGetDevicePointer((void**)&b->h_sigoff_dev, b->h_sigoff, 0));
