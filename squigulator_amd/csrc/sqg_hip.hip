@@ -58,6 +58,11 @@ struct sqg_ctx {
         hipEvent_t done = nullptr;                 // recorded on stream2 after the slot's last sample kernel
     } slot[2];
     hipStream_t stream2 = nullptr;                 // the sample kernels (k_samples_lean, generic, fix-ups)
+    // device block, pinned offsets and events of freed batches, kept for the next sqg_batch_stage / sqg_batch_sample
+    struct Recycled { uint8_t* d_block; size_t block_bytes; long long* h_sigoff; long long* h_sigoff_dev; size_t h_n; hipEvent_t ev[8]; };
+    std::vector<Recycled> pool;
+    hipStream_t stage_stream = nullptr;            // uploads and the staging kernels (k_sample, k_copy_reads, k_fill_tiles): a host
+                                                   // can stage batch i+1 while batch i runs
     std::vector<uint32_t> time_c;          // canonical time-stream state per local worker
     std::vector<long long> off_x, med_x;   // raw Schrage states (as the reference keeps them)
     unsigned long long next_stage = 0, next_run = 0, compress_seq = 0;
@@ -92,6 +97,7 @@ struct sqg_batch {
     std::vector<double> offset, median;
     std::vector<unsigned long long> seglen_host;   // only when dwell is constant
     uint8_t* d_block = nullptr;          // the batch's one device allocation; the pointers below point into it
+    size_t block_bytes = 0, h_n = 0;     // its size; entries of h_sigoff
     uint8_t* d_bases = nullptr;
     ReadDesc* d_reads = nullptr;
     int* d_blk_read = nullptr;
@@ -191,6 +197,9 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     (void)hipFree(ctx->d_svb); (void)hipFree(ctx->d_svb_size); (void)hipFree(ctx->d_svb_off);
     (void)hipFree(ctx->d_genome); (void)hipFree(ctx->d_contig_off); (void)hipFree(ctx->d_cum);
     (void)hipFree(ctx->d_trans_csum); (void)hipFree(ctx->d_trans_idx); (void)hipFree(ctx->d_samp);
+    if (ctx->stage_stream) { (void)hipStreamSynchronize(ctx->stage_stream); (void)hipStreamDestroy(ctx->stage_stream); }
+    for (auto& r : ctx->pool) { (void)hipFree(r.d_block); (void)hipHostFree(r.h_sigoff); for (auto& e : r.ev) if (e) (void)hipEventDestroy(e); }
+    ctx->pool.clear();
     if (ctx->stream2 && ctx->stream2 != ctx->stream) (void)hipStreamDestroy(ctx->stream2);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -261,6 +270,7 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     CHK(hipMemcpy(c->d_pow, pw.data(), pw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     CHK(hipMalloc(&c->d_err, sizeof(unsigned int)));
     CHK(hipMemset(c->d_err, 0, sizeof(unsigned int)));
+    CHK(hipStreamCreateWithFlags(&c->stage_stream, hipStreamNonBlocking));
     // SQG_OVERLAP=1: the sample kernels get their own stream, so that the event kernels of the next batch run next to
     // them (measured +2 % throughput on the bench workload; it stretches every kernel's duration, which is why the
     // default keeps one stream and clean per-kernel timings).  Batches are double-buffered either way.
@@ -367,11 +377,21 @@ static const char kShortHack[] = "ACGTACGTACGTA";   // src/gensig.c:242-245: "AC
 
 extern "C" void sqg_batch_free(sqg_ctx_t* ctx, sqg_batch_t* b) {
     if (!b) return;
-    if (ctx) { (void)hipSetDevice(ctx->cfg.device); if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); }
-    (void)hipFree(b->d_block);
-    if (b->h_sigoff) (void)hipHostFree(b->h_sigoff);
+    if (ctx) {
+        (void)hipSetDevice(ctx->cfg.device);
+        if (b->ran && b->ev[4]) (void)hipEventSynchronize(b->ev[4]);      // this batch's kernels only, not the ones queued after it
+    }
     if (b->h_svboff) (void)hipHostFree(b->h_svboff);
-    for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx && b->d_block && b->h_sigoff && b->ev[0] && ctx->pool.size() < 4) {
+        sqg_ctx::Recycled r;
+        r.d_block = b->d_block; r.block_bytes = b->block_bytes; r.h_sigoff = b->h_sigoff; r.h_sigoff_dev = b->h_sigoff_dev; r.h_n = b->h_n;
+        for (int i = 0; i < 8; i++) r.ev[i] = b->ev[i];
+        ctx->pool.push_back(r);
+    } else {
+        (void)hipFree(b->d_block);
+        if (b->h_sigoff) (void)hipHostFree(b->h_sigoff);
+        for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+    }
     delete b;
 }
 
@@ -581,36 +601,57 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
                      o_crd = carve(std::max<size_t>(1, chain_reads.size()) * sizeof(int)),
                      o_st = carve((size_t)std::max<long long>(nst, 1) * sizeof(int)), o_t = carve((size_t)std::max<long long>(ntile, 1) * sizeof(int)),
                      o_ord = carve(std::max<size_t>(1, chain_order.size()) * sizeof(int));
-        CHKB(hipMalloc(&b->d_block, off));
+        // a freed batch's block, pinned offsets and events are reused when they are large enough
+        for (size_t pi = 0; pi < c->pool.size(); pi++) {
+            sqg_ctx::Recycled& r = c->pool[pi];
+            if (r.block_bytes >= off && r.h_n >= (size_t)n + 1) {
+                b->d_block = r.d_block; b->block_bytes = r.block_bytes; b->h_sigoff = r.h_sigoff; b->h_sigoff_dev = r.h_sigoff_dev; b->h_n = r.h_n;
+                for (int i = 0; i < 8; i++) b->ev[i] = r.ev[i];
+                c->pool.erase(c->pool.begin() + (long)pi);
+                break;
+            }
+        }
+        if (!b->d_block) {
+            if (c->pool.size() >= 4) {                      // nothing fits: make room
+                sqg_ctx::Recycled& r = c->pool.front();
+                (void)hipFree(r.d_block); (void)hipHostFree(r.h_sigoff); for (auto& e : r.ev) if (e) (void)hipEventDestroy(e);
+                c->pool.erase(c->pool.begin());
+            }
+            b->block_bytes = off + off / 8;                 // slack: the next batches are about this size
+            CHKB(hipMalloc(&b->d_block, b->block_bytes));
+        }
         uint8_t* base = b->d_block;
         b->d_bases = base + o_bases; b->d_reads = (ReadDesc*)(base + o_reads); b->d_blk_read = (int*)(base + o_blk);
         b->d_chain_off = (int*)(base + o_coff); b->d_chain_reads = (int*)(base + o_crd); b->d_stile_read = (int*)(base + o_st);
         b->d_tile_read = (int*)(base + o_t); b->d_chain_order = (int*)(base + o_ord);
     }
-    if (seqs) CHKB(hipMemcpyAsync(b->d_bases, hb.data(), hb.size(), hipMemcpyHostToDevice, c->stream));
-    else CHKB(hipMemsetAsync(b->d_bases + nb, 'A', 16, c->stream));
-    if (n) CHKB(hipMemcpyAsync(b->d_reads, rd.data(), rd.size() * sizeof(ReadDesc), hipMemcpyHostToDevice, c->stream));
+    if (seqs) CHKB(hipMemcpyAsync(b->d_bases, hb.data(), hb.size(), hipMemcpyHostToDevice, c->stage_stream));
+    else CHKB(hipMemsetAsync(b->d_bases + nb, 'A', 16, c->stage_stream));
+    if (n) CHKB(hipMemcpyAsync(b->d_reads, rd.data(), rd.size() * sizeof(ReadDesc), hipMemcpyHostToDevice, c->stage_stream));
     if (!seqs && n) {                                      // the reads come from the resident genome
-        hipLaunchKernelGGL(k_copy_reads, dim3((unsigned)n), dim3(256), 0, c->stream, c->genome, d_rec, b->d_reads, b->d_bases, n,
+        hipLaunchKernelGGL(k_copy_reads, dim3((unsigned)n), dim3(256), 0, c->stage_stream, c->genome, d_rec, b->d_reads, b->d_bases, n,
                            rna ? 1 : 0, prefix ? 1 : 0);
         CHKB(hipGetLastError());
     }
     if (n) {
-        hipLaunchKernelGGL(k_fill_tiles, dim3((unsigned)n), dim3(64), 0, c->stream, b->d_reads, n, lean_ev, b->d_tile_read, b->d_stile_read);
+        hipLaunchKernelGGL(k_fill_tiles, dim3((unsigned)n), dim3(64), 0, c->stage_stream, b->d_reads, n, lean_ev, b->d_tile_read, b->d_stile_read);
         CHKB(hipGetLastError());
     }
     b->n_bases_total = nb;
     b->h_base_off.resize((size_t)n);
     for (int i = 0; i < n; i++) b->h_base_off[(size_t)i] = rd[(size_t)i].base_off;
-    CHKB(hipMemcpyAsync(b->d_blk_read, blk_read.data(), blk_read.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    CHKB(hipMemcpyAsync(b->d_chain_off, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    if (n) CHKB(hipMemcpyAsync(b->d_chain_reads, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    if (b->n_chains) CHKB(hipMemcpyAsync(b->d_chain_order, chain_order.data(), chain_order.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    CHKB(hipHostMalloc(&b->h_sigoff, ((size_t)n + 1) * sizeof(long long), hipHostMallocMapped));
-    CHKB(hipHostGetDevicePointer((void**)&b->h_sigoff_dev, b->h_sigoff, 0));
-    for (auto& e : b->ev) CHKB(hipEventCreate(&e));
+    CHKB(hipMemcpyAsync(b->d_blk_read, blk_read.data(), blk_read.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+    CHKB(hipMemcpyAsync(b->d_chain_off, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+    if (n) CHKB(hipMemcpyAsync(b->d_chain_reads, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+    if (b->n_chains) CHKB(hipMemcpyAsync(b->d_chain_order, chain_order.data(), chain_order.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+    if (!b->h_sigoff) {
+        b->h_n = (size_t)n + 1 + (size_t)n / 8;
+        CHKB(hipHostMalloc(&b->h_sigoff, b->h_n * sizeof(long long), hipHostMallocMapped));
+        CHKB(hipHostGetDevicePointer((void**)&b->h_sigoff_dev, b->h_sigoff, 0));
+        for (auto& e : b->ev) CHKB(hipEventCreate(&e));
+    }
     st_mark("mallocs+enqueue");
-    CHKB(hipStreamSynchronize(c->stream));     // staging buffers above are stack-owned
+    CHKB(hipStreamSynchronize(c->stage_stream));     // staging buffers above are stack-owned (only the staging stream: a running batch is not waited for)
     st_mark("sync");
 #undef CHKB
     // slots that have never held a batch are sized now, so that not even the first run allocates
@@ -662,10 +703,10 @@ extern "C" int sqg_genome_load(sqg_ctx_t* c, const sqg_genome_t* g) {
     }
     // the workers' sampler streams: ref_pos = s, rand_strand = s+1, rand_rlen = s+3 (src/sim.c:238-247)
     HIPCHK(c, hipMalloc(&c->d_samp, (size_t)c->nw * 3 * sizeof(uint32_t)));
-    hipLaunchKernelGGL(k_init_sampler, dim3((unsigned)((c->nw + 255) / 256)), dim3(256), 0, c->stream, c->d_samp,
+    hipLaunchKernelGGL(k_init_sampler, dim3((unsigned)((c->nw + 255) / 256)), dim3(256), 0, c->stage_stream, c->d_samp,
                        (long long)c->cfg.seed, c->wlo, c->nw, (int)(1u << (2 * c->k)));
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stage_stream));
     GenomeParams& G = c->genome;
     G.seq = c->d_genome; G.contig_off = c->d_contig_off; G.cum = c->d_cum;
     G.trans_csum = c->d_trans_csum; G.trans_idx = c->d_trans_idx;
@@ -704,14 +745,14 @@ extern "C" int sqg_batch_sample(sqg_ctx_t* c, int32_t n, const int32_t* worker, 
         CHKS(hipMalloc(&d_co, chain_off.size() * sizeof(int)));
         CHKS(hipMalloc(&d_cr, chain_reads.size() * sizeof(int)));
         CHKS(hipMalloc(&d_cw, chain_worker.size() * sizeof(int)));
-        CHKS(hipMemcpyAsync(d_co, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        CHKS(hipMemcpyAsync(d_cr, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        CHKS(hipMemcpyAsync(d_cw, chain_worker.data(), chain_worker.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_sample, dim3((unsigned)n_chains), dim3(64), 0, c->stream, c->genome, c->d_samp, d_co, d_cr, d_cw,
+        CHKS(hipMemcpyAsync(d_co, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+        CHKS(hipMemcpyAsync(d_cr, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+        CHKS(hipMemcpyAsync(d_cw, chain_worker.data(), chain_worker.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+        hipLaunchKernelGGL(k_sample, dim3((unsigned)n_chains), dim3(64), 0, c->stage_stream, c->genome, c->d_samp, d_co, d_cr, d_cw,
                            n_chains, d_rec, c->d_err);
         CHKS(hipGetLastError());
-        CHKS(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(SampleRec), hipMemcpyDeviceToHost, c->stream));
-        CHKS(hipStreamSynchronize(c->stream));
+        CHKS(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(SampleRec), hipMemcpyDeviceToHost, c->stage_stream));
+        CHKS(hipStreamSynchronize(c->stage_stream));
         unsigned int e = 0;
         CHKS(hipMemcpy(&e, c->d_err, sizeof e, hipMemcpyDeviceToHost));
         if (e & 16u) { CHKS(hipMemset(c->d_err, 0, sizeof e)); c->err = "read sampler: no acceptable read after 100000 attempts"; cleanup(); return SQG_EINVAL; }
