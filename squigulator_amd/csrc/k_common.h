@@ -11,8 +11,11 @@
 //   [1*POW_N + j] = a^(2j+2)   second draw
 //   [2*POW_N + j] = a^(2j)     jump over j draws-pairs
 //   [3*POW_N + j] = a^(2*1024*j)
-//   [4*POW_N + j] = a^(2*1024*1024*j)
+//   [4*POW_N + j] = a^(2*1024*1024*j)   j < POW_TOP
 #define POW_TABLES 5
+#define POW_TOP 4096        // entries of the last table: any 32-bit count
+#define POW_WORDS (4 * POW_N + POW_TOP)
+#define LCG_ORD2 1073741823u   // (M-1)/2: a^(2n) depends on n mod this
 
 #define NEAR_ONE_BITS 17    // c1 > M - 2^17 (u within 6e-5 of 1): always taken to the FP64 path
 
@@ -29,7 +32,7 @@ __device__ static inline uint32_t lcg_mul_lazy(uint32_t a, uint32_t b) {
     return (uint32_t)(p & LCG_M) + (uint32_t)(p >> 31);
 }
 
-// a^(2n) for n < 2^30 from three table levels
+// a^(2n) for any 32-bit n from three table levels
 __device__ static inline uint32_t lcg_jump2(const uint32_t* __restrict__ pw, uint32_t n) {
     uint32_t r = pw[2 * POW_N + (n & (POW_N - 1))];
     const uint32_t hi = (n >> 10) & (POW_N - 1), hi2 = n >> 20;
@@ -150,6 +153,8 @@ struct SigParams {
     const float2* model;         // {level_mean, (float)(level_stdv*amp_noise)}
     const uint32_t* pw;
     uint32_t* rows;              // [n_local_workers][num_kmer]: k <= 6 the stream states; k > 6 the samples each stream has produced
+    uint32_t* link_rows;         // split chains (few workers, many reads): [n_chains][num_kmer], the same per LINK of a worker's chain,
+                                 // prepared by k_link_hist / k_link_prefix; k_events then takes its row from here
     uint32_t seed_base, seed_step;   // (seed + worker_lo*(4^k+10)) mod M and (4^k+10) mod M: the initial state of local worker w,
                                      // k-mer j is (seed_base + w*seed_step + j) mod M (src/sim.c:238-256)
     int16_t* sig;

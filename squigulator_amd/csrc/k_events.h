@@ -168,6 +168,57 @@ __global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restr
     if (tid == 1023) { sig_off[n_reads] = run; if (host_off) host_off[n_reads] = run; }   // the last thread's running total is the grand total
 }
 
+// ---- split chains --------------------------------------------------------------------------
+// With few workers and many reads (the reference's `-t 1`, or `-t 8 -K 1000`) a worker's chain of reads is cut into
+// LINKS of whole reads that k_events walks concurrently.  A link needs the worker's k-mer streams as they stand at its
+// first read: the state (k <= 6) or sample count (k > 6) of the worker's row, advanced by the samples the chain's
+// earlier links draw from each stream.
+//   k_events<HIST> per link: dwell draws, samples per k-mer -> link_rows[link][rank]   (the front half of k_events)
+//   k_link_prefix  per (worker chain, k-mer): exclusive scan over the chain's links, applied to the worker's row
+//                  -> link_rows[link][rank] = the row as the link finds it; the worker's row is advanced past the batch
+//   k_events       as usual, one workgroup per link, dwell from memory
+// grid (num_kmer/64, worker chains), 1024 threads: 64 k-mers x 16 groups of consecutive links.
+// wlink_off[q]..wlink_off[q+1]: the links of worker chain q, in chain order
+template <bool DIRECT>
+__global__ __launch_bounds__(1024) void k_link_prefix(const SigParams P, const int* __restrict__ wlink_off, const int* __restrict__ wlink_worker) {
+    __shared__ unsigned long long sums[16][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, q = blockIdx.y;
+    const int j = blockIdx.x * 64 + lane;
+    const bool live = j < P.num_kmer;
+    const int l0 = wlink_off[q], l1 = wlink_off[q + 1];
+    const int per = (l1 - l0 + 15) / 16, la = min(l0 + g * per, l1), lb = min(la + per, l1);
+    uint32_t* wrow = P.rows + (size_t)wlink_worker[q] * P.num_kmer;
+    uint32_t* lr = P.link_rows + j;
+    unsigned long long sum = 0;
+    if (live) for (int l = la; l < lb; l++) sum += lr[(size_t)l * P.num_kmer];
+    sums[g][lane] = sum;
+    __syncthreads();
+    unsigned long long excl = 0, total = 0;
+    for (int w = 0; w < 16; w++) { const unsigned long long x = sums[w][lane]; if (w < g) excl += x; total += x; }
+    if (!live) return;
+    const uint32_t base = wrow[j];
+    // the row after n more samples (k > 6: n < 2^32 - (M-1)/2, checked at staging)
+    auto at = [&](unsigned long long n) -> uint32_t {
+        if (!DIRECT) return base + (uint32_t)n;
+        if (!n) return base;
+        return lcg_mul(base, lcg_jump2(P.pw, n < 4294967296ull ? (uint32_t)n : (uint32_t)(n % LCG_ORD2)));
+    };
+    uint32_t st = at(excl);
+    for (int l = la; l < lb; l++) {
+        const uint32_t cnt = lr[(size_t)l * P.num_kmer];
+        lr[(size_t)l * P.num_kmer] = st;
+        if (DIRECT) { if (cnt) st = lcg_mul(st, cnt < POW_N ? P.pw[2 * POW_N + cnt] : lcg_jump2(P.pw, cnt)); }
+        else st += cnt;
+    }
+    if (g == 0) wrow[j] = at(total);
+}
+
+// k > 6: the rows count samples; a stream's state only depends on the count mod (M-1)/2
+__global__ __launch_bounds__(256) void k_rows_normalize(uint32_t* __restrict__ rows, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) rows[i] %= LCG_ORD2;
+}
+
 // ---- k_events + k_samples ------------------------------------------------------------------
 // The per-read loop nest of src/gensig.c:249-282 is split at its only sequential dependency:
 //
@@ -244,7 +295,9 @@ __device__ static inline void lds_barrier() {
 
 // DW: 0 = dwell comes from memory (k_dwell ran) or is constant; 1 = drawn here, certified fp32 path with
 // out-of-line FP64 fallback; 2 = drawn here in FP64 (src/gensig.c:254-257)
-template <int NT, bool DIRECT, int DW, int EPT>
+// HIST: only the front half -- dwell draws, ranks, and the samples each k-mer stream is asked for, accumulated into the
+// workgroup's row (split chains, see above)
+template <int NT, bool DIRECT, int DW, int EPT, bool HIST = false>
 __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams P) {
     typedef EvLds<NT, DIRECT, EPT> Lds;
     __shared__ Lds L;
@@ -256,13 +309,14 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
 
     const int chain = P.chain_order[blockIdx.x];
     const int c_lo = P.chain_off[chain], c_hi = P.chain_off[chain + 1];
-    uint32_t* row = P.rows ? P.rows + (size_t)P.reads[P.chain_reads[c_lo]].worker * P.num_kmer : nullptr;
+    uint32_t* row = P.link_rows ? P.link_rows + (size_t)chain * P.num_kmer
+                  : P.rows ? P.rows + (size_t)P.reads[P.chain_reads[c_lo]].worker * P.num_kmer : nullptr;
     const int k = P.k;
     const uint32_t kmask = (k >= 16) ? 0xffffffffu : ((1u << (2 * k)) - 1u);
     // k > 6: initial state of this worker's k-mer j is (seed_w + j) mod M (src/sim.c:249)
     const uint32_t seed_w = (uint32_t)(((unsigned long long)P.seed_base +
                                         (unsigned long long)(P.rows ? P.reads[P.chain_reads[c_lo]].worker : 0) * P.seed_step) % LCG_M);
-    if (DIRECT && P.use_streams) for (int i = tid; i < P.num_kmer; i += NT) L.row[i] = row[i];
+    if (DIRECT && P.use_streams) for (int i = tid; i < P.num_kmer; i += NT) L.row[i] = HIST ? 0u : row[i];
     const uint32_t a2nt = DW ? lcg_jump2(P.pw, (uint32_t)SEG) : 0u;      // time-stream jump over one segment
     const uint32_t a2jn = DW ? lcg_jump2(P.pw, (uint32_t)EV_JUMP_N) : 0u; // ... and over EV_JUMP_N events
     const float dw_sf = (float)P.dstd, dw_mf = (float)P.dmean;
@@ -295,6 +349,20 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
             }
             if (tid < EV_HALO && b0 + SEG + tid < nbytes) b_halo = rbases[b0 + SEG + tid];
         }
+        // the next segment's inputs: EPT base bytes (+ halo) and EPT dwells per thread
+        auto prefetch_next = [&](const int s0) {
+            const int s1 = s0 + SEG;
+            if (s1 < ne) {
+                const int b1 = EV_BASE(s1);
+#pragma unroll
+                for (int q = 0; q < EPT; q++) {
+                    const int bi = b1 + tid * EPT + q;
+                    b_cur[q] = bi < nbytes ? rbases[bi] : (uint8_t)'A';
+                    if (!DW && s1 + tid * EPT + q < ne && P.dwell) d_cur[q] = P.dwell[rd.ev_off + s1 + tid * EPT + q];
+                }
+                if (tid < EV_HALO) b_halo = (b1 + SEG + tid < nbytes) ? rbases[b1 + SEG + tid] : (uint8_t)'A';
+            }
+        };
         // One segment.  FULL: every event of the segment exists (all but a read's last segment) -- the per-lane
         // validity tests, and the exec-mask juggling they cost on the scalar unit, are compiled out.
         #define EV_IN(e_) (FULL || (e_) < ne)
@@ -358,7 +426,7 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
             for (int q = 0; q < EPT; q++) lane_total += sps[q];
             const int incl = wave_incl_scan_dpp(lane_total);
             if (lane == 63) L.wsum[wid] = incl;
-            if (!DIRECT && P.use_streams) for (int i = tid; i < HT; i += NT) { L.keys[i] = BIN_EMPTY; L.head[i] = EV_NIL; }
+            if (!DIRECT && !HIST && P.use_streams) for (int i = tid; i < HT; i += NT) { L.keys[i] = BIN_EMPTY; L.head[i] = EV_NIL; }
             lds_barrier();                                                                    // (1)
             int woff = 0, seg_total = 0;
             for (int w = 0; w < NW; w++) { const int x = L.wsum[w]; if (w < wid) woff += x; seg_total += x; }
@@ -387,7 +455,9 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
                     }
                 }
                 h[q] = DIRECT ? rank[q] : (rank[q] * 2654435761u) >> (32 - (31 - __builtin_clz(HT)));
-                if (P.use_streams && EV_IN(e)) {
+                if (HIST) {
+                    if (P.use_streams && EV_IN(e)) { if (DIRECT) atomicAdd(&L.row[rank[q]], (uint32_t)sps[q]); else atomicAdd(&row[rank[q]], (uint32_t)sps[q]); }
+                } else if (P.use_streams && EV_IN(e)) {
                     const uint32_t id = (uint32_t)(tid * EPT + q);    // event within the segment, in event order
                     if (DIRECT) {
                         // the bin's members chain through row[rank]; the first one of the segment takes the state out
@@ -405,21 +475,20 @@ __global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams 
                     }
                 }
             }
-            if (DIRECT) lds_barrier(); else __syncthreads();                                  // (2) global rows: + earlier row stores have landed
-            // prefetch the next segment's inputs; they land while this segment waits for its states
-            {
-                const int s1 = s0 + SEG;
-                if (s1 < ne) {
-                    const int b1 = EV_BASE(s1);
+            if (HIST) {
+                prefetch_next(s0);
+                int run = lane_excl;
 #pragma unroll
-                    for (int q = 0; q < EPT; q++) {
-                        const int bi = b1 + tid * EPT + q;
-                        b_cur[q] = bi < nbytes ? rbases[bi] : (uint8_t)'A';
-                        if (!DW && s1 + tid * EPT + q < ne && P.dwell) d_cur[q] = P.dwell[rd.ev_off + s1 + tid * EPT + q];
-                    }
-                    if (tid < EV_HALO) b_halo = (b1 + SEG + tid < nbytes) ? rbases[b1 + SEG + tid] : (uint8_t)'A';
+                for (int q = 0; q < EPT; q++) {
+                    if (DW && EV_IN(e0 + q) && e0 + q == rd.ne0) n1_sh = (long long)done + run;   // samples of segment 0
+                    run += sps[q];
                 }
+                done += (uint32_t)seg_total;
+                lds_barrier();                                        // codes / wsum are rewritten by the next segment
+                return;
             }
+            if (DIRECT) lds_barrier(); else __syncthreads();                                  // (2) global rows: + earlier row stores have landed
+            prefetch_next(s0);                                        // lands while this segment waits for its states
             // first sample of every 64-event tile (TL lanes) within the read
             if ((lane & (TL - 1)) == 0 && EV_IN(e0)) P.tile_so[rd.tile_off + (e0 >> 6)] = done + (uint32_t)lane_excl;
             uint32_t c_ev[EPT];

@@ -57,8 +57,78 @@ __device__ static inline int count_N(const uint8_t* __restrict__ p, int n, int l
     return cnt;
 }
 
-// one wavefront per worker chain (that worker's reads of the batch, in order): every lane makes the same draws, the
-// lanes share the scan of the candidate for 'N's
+// a^n mod M
+__device__ static inline uint32_t lcg_pow_a(unsigned long long n) {
+    uint32_t r = 1, b = LCG_A;
+    while (n) { if (n & 1) r = lcg_mul(r, b); b = lcg_mul(b, b); n >>= 1; }
+    return r;
+}
+
+// draws one attempt takes from (ref_pos, rand_strand, rand_rlen): fixed per sampler variant, whatever the outcome
+__device__ static inline void samp_draws(int flags, int& dp, int& ds, int& dl) {
+    if (flags & (SQG_SAMPLE_RNA | SQG_SAMPLE_CDNA)) { dp = 1; ds = (flags & SQG_SAMPLE_CDNA) ? 1 : 0; dl = (flags & SQG_SAMPLE_TRUNC) ? 2 : 0; }
+    else { dp = 1; ds = 1; dl = 2; }
+}
+
+// one attempt of gen_read (src/genread.c:125-370) by a wavefront: every lane makes the same draws, the lanes share the
+// scan of the candidate for 'N's.  true: accepted, rec filled
+__device__ static inline bool samp_attempt(const GenomeParams& G, uint32_t& c_pos, uint32_t& c_strand, uint32_t& c_len, int lane, SampleRec& rec) {
+    int idx, pos, len, strand = '+';
+    if (G.flags & (SQG_SAMPLE_RNA | SQG_SAMPLE_CDNA)) {
+        // src/genread.c:283-300: uniform over transcripts, or by the abundance CDF (uniform narrowed to float)
+        if (G.n_trans == 0) idx = (int)round(samp_rng(c_pos) * (G.n_contigs - 1));
+        else {
+            const float r = (float)samp_rng(c_pos);
+            idx = 0;
+            for (int i = 0; i < G.n_trans; i++) if (r <= G.trans_csum[i]) { idx = G.trans_idx[i]; break; }
+        }
+        const int clen = (int)(G.contig_off[idx + 1] - G.contig_off[idx]);
+        len = clen; pos = 0;
+        if (G.flags & SQG_SAMPLE_TRUNC) {                     // src/genread.c:303-309
+            double acc = 0.0;
+            acc += -log(1 - samp_rng(c_len));
+            acc += -log(1 - samp_rng(c_len));
+            const double frac = (acc * G.grng_b) / (double)G.rlen;
+            int tl = (int)(frac * clen);
+            tl = tl > clen ? clen : tl;
+            pos = clen - tl; len = tl;
+        }
+        if (G.flags & SQG_SAMPLE_CDNA) strand = ((long long)round(samp_rng(c_strand))) ? '+' : '-';
+    } else {
+        // src/genread.c:243-281
+        double acc = 0.0;                                     // grng, src/rand.h:96-102 (Erlang-2)
+        acc += -log(1 - samp_rng(c_len));
+        acc += -log(1 - samp_rng(c_len));
+        len = (int)(acc * G.grng_b);
+        const long long at = (long long)round(samp_rng(c_pos) * (double)G.sum);   // src/genread.c:181
+        idx = 0;
+        while (idx < G.n_contigs - 1 && G.cum[idx] < at) idx++;
+        pos = (int)(at - G.cum[idx]) + (int)(G.contig_off[idx + 1] - G.contig_off[idx]);
+        strand = ((long long)round(samp_rng(c_strand))) ? '+' : '-';            // src/genread.c:196-200
+    }
+    if (len < 0) len = 0;
+    const int clen = (int)(G.contig_off[idx + 1] - G.contig_off[idx]);
+    const int n = min(len, clen - pos);                       // src/genread.c:149-177: clipped at the contig's end
+    if (n < 200) return false;                                // src/genread.c:126
+    const long long src = G.contig_off[idx] + pos;
+    const int nN = count_N(G.seq + src, n, lane);
+    if ((double)nN > 0.1 * (double)n) return false;           // src/genread.c:139-142
+    rec.src = src; rec.ref_idx = idx; rec.ref_pos = pos; rec.rlen = n; rec.strand = strand; rec.n_N = nN;
+    rec.ref_len = (G.flags & (SQG_SAMPLE_RNA | SQG_SAMPLE_CDNA)) ? len : clen;
+    return true;
+}
+
+// attempts until one is accepted (the reference has no limit; 100000 rejections in a row flag an unusable genome)
+__device__ static inline void samp_read(const GenomeParams& G, uint32_t& c_pos, uint32_t& c_strand, uint32_t& c_len, int lane, SampleRec& rec,
+                                        unsigned int* err, long long* n_attempts) {
+    for (int attempt = 0;; attempt++) {
+        if (attempt > 100000) { atomicOr(err, 16u); rec.src = 0; rec.ref_idx = 0; rec.ref_pos = 0; rec.rlen = 0; rec.strand = '+'; rec.n_N = 0; rec.ref_len = 0; return; }
+        if (n_attempts) ++*n_attempts;
+        if (samp_attempt(G, c_pos, c_strand, c_len, lane, rec)) return;
+    }
+}
+
+// one wavefront per worker chain (that worker's reads of the batch, in order)
 __global__ __launch_bounds__(64) void k_sample(const GenomeParams G, uint32_t* __restrict__ st, const int* __restrict__ chain_off,
                                                const int* __restrict__ chain_reads, const int* __restrict__ chain_worker,
                                                int n_chains, SampleRec* __restrict__ out, unsigned int* __restrict__ err) {
@@ -68,55 +138,76 @@ __global__ __launch_bounds__(64) void k_sample(const GenomeParams G, uint32_t* _
     uint32_t c_pos = st[3 * w], c_strand = st[3 * w + 1], c_len = st[3 * w + 2];
     for (int ci = chain_off[ch]; ci < chain_off[ch + 1]; ci++) {
         SampleRec rec;
-        for (int attempt = 0;; attempt++) {
-            if (attempt > 100000) { atomicOr(err, 16u); rec.src = 0; rec.ref_idx = 0; rec.ref_pos = 0; rec.rlen = 0; rec.strand = '+'; rec.n_N = 0; rec.ref_len = 0; break; }
-            int idx, pos, len, strand = '+';
-            if (G.flags & (SQG_SAMPLE_RNA | SQG_SAMPLE_CDNA)) {
-                // src/genread.c:283-300: uniform over transcripts, or by the abundance CDF (uniform narrowed to float)
-                if (G.n_trans == 0) idx = (int)round(samp_rng(c_pos) * (G.n_contigs - 1));
-                else {
-                    const float r = (float)samp_rng(c_pos);
-                    idx = 0;
-                    for (int i = 0; i < G.n_trans; i++) if (r <= G.trans_csum[i]) { idx = G.trans_idx[i]; break; }
-                }
-                const int clen = (int)(G.contig_off[idx + 1] - G.contig_off[idx]);
-                len = clen; pos = 0;
-                if (G.flags & SQG_SAMPLE_TRUNC) {                     // src/genread.c:303-309
-                    double acc = 0.0;
-                    acc += -log(1 - samp_rng(c_len));
-                    acc += -log(1 - samp_rng(c_len));
-                    const double frac = (acc * G.grng_b) / (double)G.rlen;
-                    int tl = (int)(frac * clen);
-                    tl = tl > clen ? clen : tl;
-                    pos = clen - tl; len = tl;
-                }
-                if (G.flags & SQG_SAMPLE_CDNA) strand = ((long long)round(samp_rng(c_strand))) ? '+' : '-';
-            } else {
-                // src/genread.c:243-281
-                double acc = 0.0;                                     // grng, src/rand.h:96-102 (Erlang-2)
-                acc += -log(1 - samp_rng(c_len));
-                acc += -log(1 - samp_rng(c_len));
-                len = (int)(acc * G.grng_b);
-                const long long at = (long long)round(samp_rng(c_pos) * (double)G.sum);   // src/genread.c:181
-                idx = 0;
-                while (idx < G.n_contigs - 1 && G.cum[idx] < at) idx++;
-                pos = (int)(at - G.cum[idx]) + (int)(G.contig_off[idx + 1] - G.contig_off[idx]);
-                strand = ((long long)round(samp_rng(c_strand))) ? '+' : '-';            // src/genread.c:196-200
-            }
-            if (len < 0) len = 0;
-            const int clen = (int)(G.contig_off[idx + 1] - G.contig_off[idx]);
-            const int n = min(len, clen - pos);                       // src/genread.c:149-177: clipped at the contig's end
-            if (n < 200) continue;                                    // src/genread.c:126
-            const long long src = G.contig_off[idx] + pos;
-            const int nN = count_N(G.seq + src, n, lane);
-            if ((double)nN > 0.1 * (double)n) continue;               // src/genread.c:139-142
-            rec.src = src; rec.ref_idx = idx; rec.ref_pos = pos; rec.rlen = n; rec.strand = strand; rec.n_N = nN;
-            rec.ref_len = (G.flags & (SQG_SAMPLE_RNA | SQG_SAMPLE_CDNA)) ? len : clen;
-            break;
-        }
+        samp_read(G, c_pos, c_strand, c_len, lane, rec, err, nullptr);
         if (lane == 0) out[chain_reads[ci]] = rec;
     }
     if (lane == 0) { st[3 * w] = c_pos; st[3 * w + 1] = c_strand; st[3 * w + 2] = c_len; }
+}
+
+// Long chains (few workers, many reads).  An attempt takes a fixed number of draws from each stream, so attempt a of a
+// chain is a function of a alone: the attempts are evaluated concurrently (k_sample_try, one wavefront each) and the
+// chain's reads are the accepted ones in attempt order (k_sample_pick).  att_off[ch]..att_off[ch+1]: the chain's
+// attempt slots; should they hold fewer acceptable reads than the chain needs, k_sample_pick goes on one by one.
+__global__ __launch_bounds__(256) void k_sample_try(const GenomeParams G, const uint32_t* __restrict__ st, const int* __restrict__ chain_worker,
+                                                    const long long* __restrict__ att_off, SampleRec* __restrict__ try_rec, unsigned char* __restrict__ try_ok) {
+    const int ch = blockIdx.y, lane = threadIdx.x & 63;
+    const long long a = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= att_off[ch + 1] - att_off[ch]) return;
+    const int w = chain_worker[ch];
+    int dp, ds, dl;
+    samp_draws(G.flags, dp, ds, dl);
+    uint32_t c_pos = lcg_mul(st[3 * w], lcg_pow_a((unsigned long long)a * dp));
+    uint32_t c_strand = lcg_mul(st[3 * w + 1], lcg_pow_a((unsigned long long)a * ds));
+    uint32_t c_len = lcg_mul(st[3 * w + 2], lcg_pow_a((unsigned long long)a * dl));
+    SampleRec rec;
+    const bool ok = samp_attempt(G, c_pos, c_strand, c_len, lane, rec);
+    if (lane == 0) { try_ok[att_off[ch] + a] = ok ? 1 : 0; if (ok) try_rec[att_off[ch] + a] = rec; }
+}
+
+__global__ __launch_bounds__(256) void k_sample_pick(const GenomeParams G, uint32_t* __restrict__ st, const int* __restrict__ chain_off,
+                                                     const int* __restrict__ chain_reads, const int* __restrict__ chain_worker,
+                                                     const long long* __restrict__ att_off, const SampleRec* __restrict__ try_rec,
+                                                     const unsigned char* __restrict__ try_ok, SampleRec* __restrict__ out,
+                                                     long long* __restrict__ att_used, unsigned int* __restrict__ err) {
+    __shared__ int wcnt[4];
+    __shared__ long long s_used;
+    const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int m = chain_off[ch + 1] - chain_off[ch];
+    const long long o = att_off[ch], A = att_off[ch + 1] - o;
+    const int* reads = chain_reads + chain_off[ch];
+    if (tid == 0) s_used = 0;
+    int found = 0;                                                    // accepted so far (the same in every thread)
+    for (long long a0 = 0; a0 < A && found < m; a0 += 256) {
+        const long long a = a0 + tid;
+        const bool ok = a < A && try_ok[o + a];
+        const unsigned long long bal = __ballot(ok);
+        if (lane == 0) wcnt[wid] = __popcll(bal);
+        __syncthreads();
+        int before = found;
+        for (int w2 = 0; w2 < wid; w2++) before += wcnt[w2];
+        before += __popcll(bal & ((1ull << lane) - 1));
+        if (ok && before < m) {
+            out[reads[before]] = try_rec[o + a];
+            if (before == m - 1) s_used = a + 1;
+        }
+        found += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+    __syncthreads();
+    if (wid != 0) return;
+    const int w = chain_worker[ch];
+    int dp, ds, dl;
+    samp_draws(G.flags, dp, ds, dl);
+    long long used = found >= m ? s_used : A;
+    uint32_t c_pos = lcg_mul(st[3 * w], lcg_pow_a((unsigned long long)used * dp));
+    uint32_t c_strand = lcg_mul(st[3 * w + 1], lcg_pow_a((unsigned long long)used * ds));
+    uint32_t c_len = lcg_mul(st[3 * w + 2], lcg_pow_a((unsigned long long)used * dl));
+    for (int i = found; i < m; i++) {                                 // the slots did not hold enough: one by one from here
+        SampleRec rec;
+        samp_read(G, c_pos, c_strand, c_len, lane, rec, err, &used);
+        if (lane == 0) out[reads[i]] = rec;
+    }
+    if (lane == 0) { st[3 * w] = c_pos; st[3 * w + 1] = c_strand; st[3 * w + 2] = c_len; att_used[ch] = used; }
 }
 
 __device__ static const char kd_stall_dna[] = "TTTTTTTTTTTTTTTTTTAATCAA";                       // src/genread.c:110

@@ -58,6 +58,8 @@ struct sqg_ctx {
         hipEvent_t done = nullptr;                 // recorded on stream2 after the slot's last sample kernel
     } slot[2];
     hipStream_t stream2 = nullptr;                 // the sample kernels (k_samples_lean, generic, fix-ups)
+    uint32_t* d_link_rows = nullptr; size_t link_rows_cap = 0;   // split chains: one row per link of the running batch
+    double row_bound = 0;                          // k > 6: upper bound of any sample count held in d_rows
     // device block, pinned offsets and events of freed batches, kept for the next sqg_batch_stage / sqg_batch_sample
     struct Recycled { uint8_t* d_block; size_t block_bytes; long long* h_sigoff; long long* h_sigoff_dev; size_t h_n; hipEvent_t ev[8]; };
     std::vector<Recycled> pool;
@@ -81,6 +83,7 @@ struct sqg_ctx {
     uint32_t* d_samp = nullptr;                                 // [nw][3] sampler stream states: ref_pos, rand_strand, rand_rlen
     GenomeParams genome{};
     bool genome_loaded = false;
+    double samp_ratio = 1.1;                                    // attempts per accepted read seen so far (long chains)
     uint8_t* d_svb = nullptr; size_t svb_cap = 0;               // svb-zd encodings of the last compressed batch
     long long* d_svb_size = nullptr; size_t svb_size_cap = 0;   // per read
     long long* d_svb_off = nullptr; size_t svb_off_cap = 0;
@@ -104,6 +107,11 @@ struct sqg_batch {
     int* d_chain_off = nullptr;
     int* d_chain_reads = nullptr;
     int* d_chain_order = nullptr;
+    bool split = false;                  // the worker chains are cut into links (d_chain_off describes the links)
+    int n_wchains = 0;                   // workers with reads in this batch
+    int* d_wlink_off = nullptr;          // [n_wchains+1] links of each worker chain
+    int* d_wlink_worker = nullptr;       // [n_wchains]
+    long long max_wchain_ev = 0;         // events of the longest worker chain
     int* d_tile_read = nullptr;
     int* d_stile_read = nullptr;
     long long n_tiles = 0, n_stiles = 0;
@@ -186,7 +194,7 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
-    (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err);
+    (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err);
     for (auto& S : ctx->slot) {
         (void)hipFree(S.d_sig); (void)hipFree(S.d_dwell); (void)hipFree(S.d_seglen); (void)hipFree(S.d_sigoff);
         (void)hipFree(S.d_fix); (void)hipFree(S.d_fix_count);
@@ -249,7 +257,7 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     CHK(hipMemcpy(c->d_model, hm.data(), (size_t)nk * sizeof(float2), hipMemcpyHostToDevice));
 
     // jump tables
-    std::vector<uint32_t> pw((size_t)POW_TABLES * POW_N);
+    std::vector<uint32_t> pw((size_t)POW_WORDS);
     {
         const uint32_t a2 = lcg_mul(LCG_A, LCG_A);
         uint32_t p = 1;                                     // a^(2j)
@@ -264,7 +272,7 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
         for (int j = 0; j < POW_N; j++) { pw[3 * POW_N + j] = p; p = lcg_mul(p, step1); }
         const uint32_t step2 = p;                           // a^(2*1024*1024)
         p = 1;
-        for (int j = 0; j < POW_N; j++) { pw[4 * POW_N + j] = p; p = lcg_mul(p, step2); }
+        for (int j = 0; j < POW_TOP; j++) { pw[4 * POW_N + j] = p; p = lcg_mul(p, step2); }
     }
     CHK(hipMalloc(&c->d_pow, pw.size() * sizeof(uint32_t)));
     CHK(hipMemcpy(c->d_pow, pw.data(), pw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -522,9 +530,55 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     std::vector<int> fill(chain_off.begin(), chain_off.end() - 1), chain_reads((size_t)n);
     for (int i = 0; i < n; i++) chain_reads[(size_t)fill[(size_t)chain_of[(size_t)wk[(size_t)i]]]++] = i;
 
+    // Few workers, many reads (`-t 1`, `-t 8 -K 1000`): a worker chain would be one workgroup walking its reads one after
+    // the other.  It is cut into links of whole reads, which k_events walks concurrently after k_link_hist/k_link_prefix
+    // have prepared each link's view of the worker's k-mer streams.  SQG_SPLIT_CHAINS=0 disables this, =N forces it
+    // with N links as the target (tests).
+    const std::vector<int> wchain_off = chain_off;              // the worker chains: the host's scalar streams follow these
+    const int n_wchains = b->n_chains;
+    b->n_wchains = n_wchains;
+    std::vector<long long> wchain_ev((size_t)n_wchains, 0);
+    for (int i = 0; i < n; i++) wchain_ev[(size_t)chain_of[(size_t)wk[(size_t)i]]] += rd[(size_t)i].ne0 + rd[(size_t)i].ne1;
+    for (long long v : wchain_ev) b->max_wchain_ev = std::max(b->max_wchain_ev, v);
+    if (c->use_kmer_streams && k > 6 && (double)b->max_wchain_ev * c->dwell_hi >= 4294967295.0 - (double)LCG_ORD2) {
+        delete b; c->err = "one worker's reads of a batch may draw more than 3.2e9 samples (k > 6): use smaller batches"; return SQG_EINVAL;
+    }
+    std::vector<int> wlink_off(1, 0), wlink_worker;
+    {
+        const char* env = getenv("SQG_SPLIT_CHAINS");
+        const int forced = env ? atoi(env) : -1;
+        const bool multi = n > n_wchains;
+        const bool want = forced >= 0 ? (forced > 0 && multi) : (multi && n_wchains < 1024 && nev >= 65536);
+        if (c->use_kmer_streams && want) {
+            const size_t row_bytes = (size_t)c->num_kmer * sizeof(uint32_t);
+            long long target = forced > 0 ? forced : 2048;
+            target = std::min<long long>(target, std::max<long long>(8, (long long)(((size_t)1 << 30) / row_bytes)));
+            std::vector<int> link_off(1, 0);
+            for (int q = 0; q < n_wchains; q++) {
+                const int lo = wchain_off[(size_t)q], hi = wchain_off[(size_t)q + 1];
+                long long lq = nev > 0 ? (target * wchain_ev[(size_t)q] + nev - 1) / nev : 1;
+                lq = std::max<long long>(1, std::min<long long>(lq, hi - lo));
+                const long long per = (wchain_ev[(size_t)q] + lq - 1) / lq;
+                long long acc = 0;
+                for (int ci = lo; ci < hi; ci++) {
+                    const ReadDesc& d = rd[(size_t)chain_reads[(size_t)ci]];
+                    acc += d.ne0 + d.ne1;
+                    // a link's per-k-mer sample counts are 32-bit
+                    const long long nxt = ci + 1 < hi ? rd[(size_t)chain_reads[(size_t)ci + 1]].ne0 + rd[(size_t)chain_reads[(size_t)ci + 1]].ne1 : 0;
+                    if (ci + 1 == hi || acc >= per || (double)(acc + nxt) * c->dwell_hi >= 2147483648.0) { link_off.push_back(ci + 1); acc = 0; }
+                }
+                wlink_off.push_back((int)link_off.size() - 1);
+                wlink_worker.push_back(rd[(size_t)chain_reads[(size_t)lo]].worker);
+            }
+            chain_off.swap(link_off);
+            b->n_chains = (int)chain_off.size() - 1;
+            b->split = true;
+        }
+    }
     // launch order: longest chain first, so the tail of the grid is made of short chains
     std::vector<long long> chain_ev((size_t)b->n_chains, 0);
-    for (int i = 0; i < n; i++) chain_ev[(size_t)chain_of[(size_t)wk[(size_t)i]]] += rd[(size_t)i].ne0 + rd[(size_t)i].ne1;
+    for (int q = 0; q < b->n_chains; q++)
+        for (int ci = chain_off[(size_t)q]; ci < chain_off[(size_t)q + 1]; ci++) chain_ev[(size_t)q] += rd[(size_t)chain_reads[(size_t)ci]].ne0 + rd[(size_t)chain_reads[(size_t)ci]].ne1;
     // (a counting sort over 4096 length classes: exact order within a class does not matter for the tail)
     std::vector<int> chain_order((size_t)b->n_chains);
     {
@@ -544,7 +598,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     // chains are independent, a few host threads share them
     auto chain_range = [&](int q_lo, int q_hi) {
         for (int q = q_lo; q < q_hi; q++)
-            for (int ci = chain_off[(size_t)q]; ci < chain_off[(size_t)q + 1]; ci++) {   // batch order within the worker
+            for (int ci = wchain_off[(size_t)q]; ci < wchain_off[(size_t)q + 1]; ci++) {   // batch order within the worker
                 const int i = chain_reads[(size_t)ci];
                 ReadDesc& d = rd[(size_t)i];
                 const size_t w = (size_t)d.worker;
@@ -563,12 +617,12 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
             }
     };
     {
-        const int nth = (b->n_chains >= 1024) ? (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
-        if (nth <= 1) chain_range(0, b->n_chains);
+        const int nth = (n_wchains >= 1024) ? (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        if (nth <= 1) chain_range(0, n_wchains);
         else {
             std::vector<std::thread> th;
-            const int per = (b->n_chains + nth - 1) / nth;
-            for (int t = 0; t < nth; t++) th.emplace_back(chain_range, std::min(t * per, b->n_chains), std::min((t + 1) * per, b->n_chains));
+            const int per = (n_wchains + nth - 1) / nth;
+            for (int t = 0; t < nth; t++) th.emplace_back(chain_range, std::min(t * per, n_wchains), std::min((t + 1) * per, n_wchains));
             for (auto& t : th) t.join();
         }
     }
@@ -600,7 +654,8 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
                      o_blk = carve(blk_read.size() * sizeof(int)), o_coff = carve(chain_off.size() * sizeof(int)),
                      o_crd = carve(std::max<size_t>(1, chain_reads.size()) * sizeof(int)),
                      o_st = carve((size_t)std::max<long long>(nst, 1) * sizeof(int)), o_t = carve((size_t)std::max<long long>(ntile, 1) * sizeof(int)),
-                     o_ord = carve(std::max<size_t>(1, chain_order.size()) * sizeof(int));
+                     o_ord = carve(std::max<size_t>(1, chain_order.size()) * sizeof(int)),
+                     o_wlo = carve(wlink_off.size() * sizeof(int)), o_wlw = carve(std::max<size_t>(1, wlink_worker.size()) * sizeof(int));
         // a freed batch's block, pinned offsets and events are reused when they are large enough
         for (size_t pi = 0; pi < c->pool.size(); pi++) {
             sqg_ctx::Recycled& r = c->pool[pi];
@@ -624,6 +679,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         b->d_bases = base + o_bases; b->d_reads = (ReadDesc*)(base + o_reads); b->d_blk_read = (int*)(base + o_blk);
         b->d_chain_off = (int*)(base + o_coff); b->d_chain_reads = (int*)(base + o_crd); b->d_stile_read = (int*)(base + o_st);
         b->d_tile_read = (int*)(base + o_t); b->d_chain_order = (int*)(base + o_ord);
+        b->d_wlink_off = (int*)(base + o_wlo); b->d_wlink_worker = (int*)(base + o_wlw);
     }
     if (seqs) CHKB(hipMemcpyAsync(b->d_bases, hb.data(), hb.size(), hipMemcpyHostToDevice, c->stage_stream));
     else CHKB(hipMemsetAsync(b->d_bases + nb, 'A', 16, c->stage_stream));
@@ -644,6 +700,10 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     CHKB(hipMemcpyAsync(b->d_chain_off, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
     if (n) CHKB(hipMemcpyAsync(b->d_chain_reads, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
     if (b->n_chains) CHKB(hipMemcpyAsync(b->d_chain_order, chain_order.data(), chain_order.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+    if (b->split) {
+        CHKB(hipMemcpyAsync(b->d_wlink_off, wlink_off.data(), wlink_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+        CHKB(hipMemcpyAsync(b->d_wlink_worker, wlink_worker.data(), wlink_worker.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+    }
     if (!b->h_sigoff) {
         b->h_n = (size_t)n + 1 + (size_t)n / 8;
         CHKB(hipHostMalloc(&b->h_sigoff, b->h_n * sizeof(long long), hipHostMallocMapped));
@@ -736,9 +796,10 @@ extern "C" int sqg_batch_sample(sqg_ctx_t* c, int32_t n, const int32_t* worker, 
 
     SampleRec* d_rec = nullptr;
     int *d_co = nullptr, *d_cr = nullptr, *d_cw = nullptr;
+    SampleRec* d_try = nullptr; unsigned char* d_ok = nullptr; long long* d_ao = nullptr;
     std::vector<SampleRec> rec((size_t)n);
     int rc = SQG_OK;
-    auto cleanup = [&]() { (void)hipFree(d_rec); (void)hipFree(d_co); (void)hipFree(d_cr); (void)hipFree(d_cw); };
+    auto cleanup = [&]() { (void)hipFree(d_rec); (void)hipFree(d_co); (void)hipFree(d_cr); (void)hipFree(d_cw); (void)hipFree(d_try); (void)hipFree(d_ok); (void)hipFree(d_ao); };
 #define CHKS(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE; } } while (0)
     CHKS(hipMalloc(&d_rec, std::max<size_t>(1, (size_t)n) * sizeof(SampleRec)));
     if (n > 0) {
@@ -748,11 +809,46 @@ extern "C" int sqg_batch_sample(sqg_ctx_t* c, int32_t n, const int32_t* worker, 
         CHKS(hipMemcpyAsync(d_co, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
         CHKS(hipMemcpyAsync(d_cr, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
         CHKS(hipMemcpyAsync(d_cw, chain_worker.data(), chain_worker.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
-        hipLaunchKernelGGL(k_sample, dim3((unsigned)n_chains), dim3(64), 0, c->stage_stream, c->genome, c->d_samp, d_co, d_cr, d_cw,
-                           n_chains, d_rec, c->d_err);
-        CHKS(hipGetLastError());
+        int max_m = 0;
+        for (int q = 0; q < n_chains; q++) max_m = std::max(max_m, chain_off[(size_t)q + 1] - chain_off[(size_t)q]);
+        std::vector<long long> att_used;
+        if (max_m >= 16 && !getenv("SQG_SAMPLER_SERIAL")) {
+            // long chains: the attempts are evaluated concurrently, 25 % more than the acceptance rate seen so far asks for
+            std::vector<long long> att_off((size_t)n_chains + 1, 0);
+            long long max_a = 0;
+            for (int q = 0; q < n_chains; q++) {
+                const long long m = chain_off[(size_t)q + 1] - chain_off[(size_t)q];
+                const long long a = (long long)std::ceil((double)m * c->samp_ratio * 1.25) + 64;
+                att_off[(size_t)q + 1] = att_off[(size_t)q] + a; max_a = std::max(max_a, a);
+            }
+            const size_t na = (size_t)att_off.back();
+            CHKS(hipMalloc(&d_try, na * sizeof(SampleRec)));
+            CHKS(hipMalloc(&d_ok, na));
+            CHKS(hipMalloc(&d_ao, (att_off.size() + (size_t)n_chains) * sizeof(long long)));
+            long long* d_used = d_ao + att_off.size();
+            CHKS(hipMemcpyAsync(d_ao, att_off.data(), att_off.size() * sizeof(long long), hipMemcpyHostToDevice, c->stage_stream));
+            hipLaunchKernelGGL(k_sample_try, dim3((unsigned)((max_a + 3) / 4), (unsigned)n_chains), dim3(256), 0, c->stage_stream, c->genome, c->d_samp,
+                               d_cw, d_ao, d_try, d_ok);
+            hipLaunchKernelGGL(k_sample_pick, dim3((unsigned)n_chains), dim3(256), 0, c->stage_stream, c->genome, c->d_samp, d_co, d_cr, d_cw,
+                               d_ao, d_try, d_ok, d_rec, d_used, c->d_err);
+            CHKS(hipGetLastError());
+            att_used.resize((size_t)n_chains);
+            CHKS(hipMemcpyAsync(att_used.data(), d_used, att_used.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stage_stream));
+        } else {
+            hipLaunchKernelGGL(k_sample, dim3((unsigned)n_chains), dim3(64), 0, c->stage_stream, c->genome, c->d_samp, d_co, d_cr, d_cw,
+                               n_chains, d_rec, c->d_err);
+            CHKS(hipGetLastError());
+        }
         CHKS(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(SampleRec), hipMemcpyDeviceToHost, c->stage_stream));
         CHKS(hipStreamSynchronize(c->stage_stream));
+        if (!att_used.empty()) {
+            double r = 1.0;
+            for (int q = 0; q < n_chains; q++) {
+                const int m = chain_off[(size_t)q + 1] - chain_off[(size_t)q];
+                if (m >= 16) r = std::max(r, (double)att_used[(size_t)q] / (double)m);
+            }
+            c->samp_ratio = r;
+        }
         unsigned int e = 0;
         CHKS(hipMemcpy(&e, c->d_err, sizeof e, hipMemcpyDeviceToHost));
         if (e & 16u) { CHKS(hipMemset(c->d_err, 0, sizeof e)); c->err = "read sampler: no acceptable read after 100000 attempts"; cleanup(); return SQG_EINVAL; }
@@ -824,8 +920,22 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     // Dwell draws are made inside k_events (SQG_SEPARATE_DWELL=1 keeps the stand-alone k_dwell for A/B runs).
     static const bool separate_dwell = getenv("SQG_SEPARATE_DWELL") != nullptr;
     const bool inline_dwell = c->use_dwell_stream && !separate_dwell;
+    const bool direct = c->k <= 6;
+    if (!direct && c->use_kmer_streams && n > 0) {
+        // the rows count samples in 32 bits; only the count mod (M-1)/2 matters
+        const double bnd = (double)b->max_wchain_ev * c->dwell_hi;
+        if (c->row_bound + bnd >= 4294967295.0) {
+            const size_t nrow = (size_t)c->nw * (size_t)c->num_kmer;
+            hipLaunchKernelGGL(k_rows_normalize, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, c->stream, c->d_rows, nrow);
+            HIPCHK(c, hipGetLastError());
+            c->row_bound = (double)LCG_ORD2;
+        }
+        c->row_bound += bnd;
+    }
+    if (b->split && (rc = ensure(c, (void**)&c->d_link_rows, &c->link_rows_cap, (size_t)b->n_chains * (size_t)c->num_kmer, sizeof(uint32_t)))) return rc;
     SigParams P;
     memset(&P, 0, sizeof P);
+    P.link_rows = b->split ? c->d_link_rows : nullptr;
     P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
     P.dwell = c->use_dwell_stream ? S.d_dwell : nullptr; P.dwell_out = S.d_dwell; P.seglen_out = S.d_seglen;
     P.dmean = p.dwell_mean; P.dstd = p.dwell_std;
@@ -838,12 +948,13 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     P.rna = (c->cfg.flags & SQG_RNA) ? 1 : 0;
     P.evrec = S.d_evrec; P.tile_so = S.d_tile_so; P.tile_read = b->d_tile_read; P.stile_read = b->d_stile_read;
     constexpr int NT = SQG_EVENT_THREADS;
-    auto launch_events = [&](int dw) {
+    auto launch_events = [&](int dw, bool hist) {
         const dim3 g((unsigned)b->n_chains), t(NT);
-        const bool direct = c->k <= 6;
-#define EVL(D, W) hipLaunchKernelGGL((k_events<NT, D, W, SQG_EVENT_EPT>), g, t, 0, c->stream, P)
-        if (direct) { if (dw == 0) EVL(true, 0); else if (dw == 1) EVL(true, 1); else EVL(true, 2); }
-        else { if (dw == 0) EVL(false, 0); else if (dw == 1) EVL(false, 1); else EVL(false, 2); }
+#define EVL(D, W, H) hipLaunchKernelGGL((k_events<NT, D, W, SQG_EVENT_EPT, H>), g, t, 0, c->stream, P)
+#define EVD(D, H) do { if (dw == 0) EVL(D, 0, H); else if (dw == 1) EVL(D, 1, H); else EVL(D, 2, H); } while (0)
+        if (direct) { if (hist) EVD(true, true); else EVD(true, false); }
+        else { if (hist) EVD(false, true); else EVD(false, false); }
+#undef EVD
 #undef EVL
     };
 
@@ -868,7 +979,18 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     b->dwell_timed = c->use_dwell_stream && !inline_dwell;        // stand-alone k_dwell (A/B runs): two more timing events
     if (b->dwell_timed) { HIPCHK(c, hipEventRecord(b->ev[1], c->stream)); HIPCHK(c, hipEventRecord(b->ev[2], c->stream)); }
     if (n > 0 && b->n_chains > 0) {
-        launch_events(inline_dwell ? (certified && c->dwell_hi < 1.0e6 ? 1 : 2) : 0);
+        const int dw = inline_dwell ? (certified && c->dwell_hi < 1.0e6 ? 1 : 2) : 0;
+        if (b->split) {
+            // links: samples per (link, k-mer) with the dwell draws, then each link's view of its worker's streams
+            if (!direct) HIPCHK(c, hipMemsetAsync(c->d_link_rows, 0, (size_t)b->n_chains * (size_t)c->num_kmer * sizeof(uint32_t), c->stream));
+            launch_events(dw, true);
+            const dim3 pg((unsigned)((c->num_kmer + 63) / 64), (unsigned)b->n_wchains);
+            if (direct) hipLaunchKernelGGL(k_link_prefix<true>, pg, dim3(1024), 0, c->stream, P, b->d_wlink_off, b->d_wlink_worker);
+            else hipLaunchKernelGGL(k_link_prefix<false>, pg, dim3(1024), 0, c->stream, P, b->d_wlink_off, b->d_wlink_worker);
+            HIPCHK(c, hipGetLastError());
+            if ((rc = dbg_sync(c, "k_events<hist>/k_link_prefix"))) return rc;
+            launch_events(0, false);                              // the dwell is in memory now
+        } else launch_events(dw, false);
         HIPCHK(c, hipGetLastError());
         if ((rc = dbg_sync(c, "k_events"))) return rc;
     }

@@ -112,6 +112,46 @@ def test_random_genomes(seed, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,batches", [(1, [40, 25, 16]), (3, [100, 64])], ids=["t1", "t3"])
+def test_long_chains_are_sampled_concurrently_and_match_the_oracle(T, batches):
+    """>= 16 reads per worker: the attempts are evaluated side by side (k_sample_try / k_sample_pick)"""
+    _run("dna-r9-prom", 6, NCOV, T, batches, rlen=800)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,oflags,mode,tc", [
+    ("uniform", 0, api.SAMPLE_RNA, None),
+    ("trans_trunc", 0x100, api.SAMPLE_RNA | api.SAMPLE_TRUNC, SEQUIN_TC),
+    ("cdna", 0x200, api.SAMPLE_CDNA, SEQUIN_TC),
+], ids=lambda x: x if isinstance(x, str) else None)
+def test_long_chains_rna_variants(name, oflags, mode, tc):
+    if mode & api.SAMPLE_CDNA:
+        _run("dna-r9-prom", 6, SEQUIN, 2, [40, 33], rlen=10000, oflags=oflags, mode=mode, trans_count=tc)
+    else:
+        _run("rna004-prom", 9, SEQUIN, 2, [40, 33], rlen=10000, oflags=oflags, sflags=profiles.SQ_PREFIX, mode=mode, trans_count=tc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_long_chains_on_genomes_that_reject_most_attempts(seed, tmp_path):
+    """tiny contigs and N runs: most attempts are rejected, so the attempt slots run out and the chain is finished one
+    read at a time; the next batch sizes its slots by the rate seen"""
+    rng = np.random.default_rng(900 + seed)
+    contigs = []
+    for _ in range(int(rng.integers(2, 9))):
+        n = int(rng.choice([205, 230, 300, 900, 4000]))
+        a = rng.choice(list(b"ACGTN"), n, p=[.24, .24, .24, .24, .04]).astype(np.uint8)
+        q = int(rng.integers(0, max(n - 50, 1)))
+        a[q:q + int(rng.integers(5, 60))] = ord("N")
+        contigs.append(bytes(a))
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(f">c{i}\n{c.decode()}\n" for i, c in enumerate(contigs)))
+    T = int(rng.integers(1, 4))
+    _run("dna-r9-prom", 6, str(fa), T, [int(rng.integers(16 * T, 30 * T)) for _ in range(3)], rlen=int(rng.choice([250, 600])),
+         seed=int(rng.integers(1, 1 << 20)))
+
+
+@pytest.mark.gpu
 def test_sampler_shards_equal_one_context():
     """Multi-GPU sharding of the sampler: a context that owns workers [lo, hi) draws exactly the reads the
     single-context run draws for those workers (streams are per worker; no exchange)."""

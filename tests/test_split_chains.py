@@ -1,0 +1,88 @@
+"""Few workers, many reads (the reference's `-t 1` regime, which every golden in its test/ directory uses): the worker
+chains are cut into links that k_events walks concurrently (k_link_hist, k_link_prefix).  The result has to be the
+one the serial walk gives -- the oracle's -- whatever the cut."""
+import numpy as np
+import pytest
+
+import orc
+from squigulator_amd import api, model, profiles
+
+FLAG_SETS = [0, profiles.SQ_PREFIX, profiles.SQ_RNA | profiles.SQ_PREFIX, profiles.SQ_IDEAL_TIME, profiles.SQ_RNA]
+
+
+def _reads(rng, n, k, longest):
+    lens = rng.choice([1, k - 1, k, 64, 65, 200, 513, 1025, longest], n)
+    return [bytes(rng.choice(list(b"ACGTN"), int(m), p=[.245, .245, .245, .245, .02]).astype(np.uint8)) for m in lens]
+
+
+def _check(prof, flags, k, T, s, batches, modes=(api.MODE_CERTIFIED, api.MODE_EXACT), salt=0):
+    mean, stdv = model.synthetic_model(k, salt=salt)
+    orac = orc.Oracle(prof, flags, k, mean, stdv, s, num_workers=T)
+    want = [orac.run_batch_seqs(bt) for bt in batches]
+    orac.close()
+    for mode in modes:
+        gen = api.SignalGenerator(prof, flags, k, mean, stdv, s, num_workers=T, mode=mode)
+        for bi, bt in enumerate(batches):
+            b = gen.submit(bt)
+            sig, dw = b.signal(), b.dwell()
+            for i, w in enumerate(want[bi]):
+                np.testing.assert_array_equal(sig[b.sig_off[i]:b.sig_off[i + 1]], w.sig, err_msg=f"mode {mode} batch {bi} read {i}")
+                np.testing.assert_array_equal(dw[b.ev_off[i]:b.ev_off[i + 1]], w.ss)
+                assert b.offset[i] == w.offset and b.median_before[i] == w.median_before
+            b.free()
+        gen.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("links", ["1", "5", "100000"])
+@pytest.mark.parametrize("seed", range(10))
+def test_any_cut_of_the_worker_chains_gives_the_serial_result(seed, links, monkeypatch):
+    monkeypatch.setenv("SQG_SPLIT_CHAINS", links)
+    rng = np.random.default_rng(7000 + seed)
+    name = ["dna-r9-prom", "dna-r10-prom", "rna004-prom", "rna-r9-prom", "dna-r9-min"][seed % 5]
+    prof, fl = profiles.get_profile(name)
+    k = profiles.default_kmer_size(fl)
+    flags = fl | FLAG_SETS[seed % len(FLAG_SETS)] if not (fl & profiles.SQ_RNA) else fl | (profiles.SQ_PREFIX if seed % 2 else 0)
+    T = int(rng.choice([1, 1, 2, 3]))
+    batches = [_reads(rng, int(rng.integers(T + 1, 6 * T + 12)), k, 3000) for _ in range(3)]
+    _check(prof, flags, k, T, int(rng.integers(1, 1 << 30)), batches, salt=seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T", [("dna-r9-prom", 1), ("dna-r10-prom", 1), ("dna-r9-prom", 8), ("rna004-prom", 2)])
+def test_t1_regime_is_split_by_default_and_matches_the_oracle(name, T):
+    """enough events for the heuristic to cut the chains (no environment override); two batches, carried state"""
+    rng = np.random.default_rng(99)
+    prof, fl = profiles.get_profile(name)
+    k = profiles.default_kmer_size(fl)
+    if fl & profiles.SQ_RNA:
+        fl |= profiles.SQ_PREFIX
+    batches = [_reads(rng, 160, k, 4000) for _ in range(2)]
+    assert sum(len(r) for r in batches[0]) > 70000
+    _check(prof, fl, k, T, 42, batches, modes=(api.MODE_CERTIFIED,))
+
+
+@pytest.mark.gpu
+def test_split_and_unsplit_runs_agree_at_size(monkeypatch):
+    """-t 4 with 4000 reads per batch: the split walk against the serial one, every int16"""
+    rng = np.random.default_rng(5)
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    mean, stdv = model.synthetic_model(6)
+    batches = [[bytes(rng.choice(list(b"ACGT"), int(m)).astype(np.uint8)) for m in rng.integers(500, 3000, 4000)] for _ in range(2)]
+    out = {}
+    for setting in ("0", None):
+        if setting is None:
+            monkeypatch.delenv("SQG_SPLIT_CHAINS", raising=False)
+        else:
+            monkeypatch.setenv("SQG_SPLIT_CHAINS", setting)
+        gen = api.SignalGenerator(prof, fl, 6, mean, stdv, 42, num_workers=4, mode=api.MODE_CERTIFIED)
+        res = []
+        for bt in batches:
+            b = gen.submit(bt)
+            res.append((b.signal().copy(), np.array(b.sig_off).copy()))
+            b.free()
+        gen.close()
+        out[setting] = res
+    for (s0, o0), (s1, o1) in zip(out["0"], out[None]):
+        np.testing.assert_array_equal(o0, o1)
+        np.testing.assert_array_equal(s0, s1)
