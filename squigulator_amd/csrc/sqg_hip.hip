@@ -350,7 +350,12 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
         } else {
             // 1 MiB per worker, ~4 % of it used by a read: rows hold the number of SAMPLES each stream has produced, so
             // that one returning atomic add per k-mer bin replaces a load and a store; the state is seed * a^(2*count)
-            CHK(hipMemsetAsync(c->d_rows, 0, (size_t)total * sizeof(uint32_t), c->stream));
+            // (test hook SQG_TEST_ROW_TURNS=t: start every count at t*(M-1)/2, which is the same stream position; t = 3
+            // makes the first batch normalise the counts, t = 2 exercises the top of the jump tables)
+            const char* turns_env = getenv("SQG_TEST_ROW_TURNS");
+            const int turns = turns_env ? std::min(3, std::max(0, atoi(turns_env))) : 0;
+            CHK(hipMemsetD32Async((hipDeviceptr_t)c->d_rows, (int)((unsigned)turns * LCG_ORD2), (size_t)total, c->stream));
+            c->row_bound = (double)turns * (double)LCG_ORD2 + (turns == 3 ? (double)LCG_ORD2 : 0.0);
         }
     }
     // scalar streams (src/sim.c:241-247): time = s+2, offset = s+4, median = s+5

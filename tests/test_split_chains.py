@@ -86,3 +86,17 @@ def test_split_and_unsplit_runs_agree_at_size(monkeypatch):
     for (s0, o0), (s1, o1) in zip(out["0"], out[None]):
         np.testing.assert_array_equal(o0, o1)
         np.testing.assert_array_equal(s0, s1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("turns", ["2", "3"])
+@pytest.mark.parametrize("T", [1, 5])
+def test_nine_mer_sample_counts_wrap_correctly(turns, T, monkeypatch):
+    """k > 6 keeps, per stream, the number of samples drawn so far; the state depends on it mod (M-1)/2 only.  The hook
+    starts every count at 2 or 3 times that (the same stream position): 2 exercises the top of the jump tables, 3 makes
+    the first batch normalise the counts.  Output must not change."""
+    monkeypatch.setenv("SQG_TEST_ROW_TURNS", turns)
+    rng = np.random.default_rng(31)
+    prof, fl = profiles.get_profile("dna-r10-prom")
+    batches = [_reads(rng, 3 * T + 4, 9, 2000) for _ in range(3)]
+    _check(prof, fl, 9, T, 1234, batches)
