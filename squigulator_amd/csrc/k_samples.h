@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_st
 
 template <int EPL>
 struct LeanWaveLds {
-    uint4 rec[64 * EPL];                // {c_ev, ((8*first sample) & 0xfff) << 16 | I (16 bits), F - 1/2, sdk}
+    uint4 rec[64 * EPL];                // {c_ev, (4*first sample) << 16 | I (16 bits), F - 1/2, sdk}
     unsigned long long bm[64];          // bit s-1 set: an event (other than the item's first) starts at sample s
     int nfix;                           // undecided samples of the item so far
     int pad[3];
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
                 const double fl0 = floor(mk);
                 const float Fh = (float)(mk - fl0 - 0.5);
                 const float sdk = (float)((double)md[q].y * P.kd);
-                W.rec[lane * LEAN_EPL + q] = make_uint4(er[q].x, ((((uint32_t)so << 3) & 0xfffu) << 16) | ((uint32_t)(int)fl0 & 0xffffu),
+                W.rec[lane * LEAN_EPL + q] = make_uint4(er[q].x, ((uint32_t)so << 18) | ((uint32_t)(int)fl0 & 0xffffu),   // so < 4096
                                                         __float_as_uint(Fh), __float_as_uint(sdk));
                 if ((e0 + q < ne) && (lane | q) != 0)                  // so >= 1: every earlier event has >= 1 sample
                     atomicOr(reinterpret_cast<unsigned int*>(W.bm) + ((so - 1) >> 5), 1u << ((so - 1) & 31));
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         char* const out_b = reinterpret_cast<char*>(P.sig + it.sig_base);               // wave-uniform: global_store saddr + 32-bit lane offset
         // byte offset of my sample of step 0 within the read: generation index i is stored at at0 + i (RNA: at0 - i)
         uint32_t voff = RNA ? 2u * (it.at0 - (uint32_t)lane) : 2u * (it.at0 + (uint32_t)lane);
-        uint32_t idx8 = (uint32_t)lane << 3;                           // 8 * (my sample index within the item)
+        uint32_t idx4 = (uint32_t)lane << 2;                           // 4 * (my sample index within the item), advanced every second step
         const int ev_read0 = it.ev_read0;                               // event index (within the read) of rec[0]
 #if defined(SQG_ABL_NOLOOP)
         const int nfull = 0, rem = wave_total & 1;
@@ -211,37 +211,43 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
 #endif
         int base_ev;
 
-        // event of my sample in step c: events begun in earlier steps + start bits below my lane
-        #define LEAN_MAP(c_, ev_) {                                                                              \
+        // event of my sample in step c = evb_ (events begun in earlier steps: scalar) + evl_ (start bits below my lane)
+        #define LEAN_MAP(c_, evl_, evb_) {                                                                       \
             const uint32_t lo_ = __builtin_amdgcn_readlane(bm_lo, (c_)), hi_ = __builtin_amdgcn_readlane(bm_hi, (c_)); \
-            ev_ = (int)__builtin_amdgcn_mbcnt_hi(hi_, __builtin_amdgcn_mbcnt_lo(lo_, (uint32_t)base_ev));          \
+            evb_ = base_ev;                                                                                       \
+            evl_ = (int)__builtin_amdgcn_mbcnt_hi(hi_, __builtin_amdgcn_mbcnt_lo(lo_, 0u));                        \
             base_ev += __builtin_popcount(lo_) + __builtin_popcount(hi_); }
-        // one step: issue the loads of step c_+1 into (RN, MN, EN), then the arithmetic of step c_ from (RA, MU, EV)
-        #define LEAN_STEP(SH, TAIL, c_, RA, MU, EV, RN, MN, EN) {                                                    \
-            LEAN_MAP(min((c_) + 1, 63), EN)                                                                       \
-            RN = W.rec[EN];                                                                                       \
+        // one step: issue the loads of step c_+1 into (RN, MN, ENL/ENB), then the arithmetic of step c_ from (RA, MU, EVL/EVB).
+        // DI: 0 / 1 = first / second step of a pair; idx4 and voff advance once per pair, the second step's +64 samples ride
+        // in the immediate offsets of its LDS read and its store.
+        #define LEAN_STEP(SH, TAIL, c_, DI, RA, MU, EVL, EVB, RN, MN, ENL, ENB) {                                    \
+            LEAN_MAP(min((c_) + 1, 63), ENL, ENB)                                                                 \
+            RN = (W.rec + ENB)[ENL];                                                                              \
             LEAN_ARITH(RA, MU)                                                                                    \
             const float vh = __builtin_fmaf(x, __uint_as_float(RA.w), __uint_as_float(RA.z));                     \
             const float t = vh + LEAN_MAGIC;                                                                      \
             const float d = vh - (t - LEAN_MAGIC);                                                                \
-            const bool act = !(TAIL) || (int)(idx8 >> 3) < wave_total;                                            \
+            const int si_ = (int)(idx4 >> 2) + 64 * (DI);              /* my sample index within the item */         \
+            const bool act = !(TAIL) || si_ < wave_total;                                                         \
             const bool ok = fabsf(d) < thr && c1 <= LCG_M - (1u << NEAR_ONE_BITS);                                \
             /* RNA adaptor window: the ADC value gets -(int16)(30*dig/range) with int16 wrap (src/genread.c:79-86) */ \
-            const bool shf = (SH) && (uint32_t)((int)(idx8 >> 3) - it.shift_lo) < (uint32_t)(it.shift_hi - it.shift_lo);       \
-            if (act && ok LEAN_STORE_COND) *reinterpret_cast<uint16_t*>(out_b + voff) =                            \
+            const bool shf = (SH) && (uint32_t)(si_ - it.shift_lo) < (uint32_t)(it.shift_hi - it.shift_lo);       \
+            char* const dst_b = out_b + (RNA ? -128 * (DI) : 128 * (DI));                                         \
+            if (act && ok LEAN_STORE_COND) *reinterpret_cast<uint16_t*>(dst_b + voff) =                            \
                 (uint16_t)((__float_as_uint(t) + RA.y - (shf ? (uint32_t)P.shift : 0u)) & 0xffffu);                \
             else if (act) {                                        /* ~1 % of steps: park the undecided samples (no round trip) */ \
                 const unsigned long long am = __builtin_amdgcn_ballot_w64(true);                                  \
                 const int n0 = W.nfix;                                                                            \
                 const int slot = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)); \
-                if (slot < FIX_SLOTS) P.tfix[(size_t)g * FIX_SLOTS + slot] = make_uint4(voff >> 1, c1, (uint32_t)(ev_read0 + EV), shf ? 1u : 0u); \
-                else push_fix_one(P, it.sig_base + (voff >> 1), c1, it.ev_first + EV, it.read, shf ? 1 : 0);   /* overflow (never in practice): global list */ \
+                const uint32_t at_ = (RNA ? voff - 128u * (DI) : voff + 128u * (DI)) >> 1;                        \
+                const int ev_ = EVB + EVL;                                                                        \
+                if (slot < FIX_SLOTS) P.tfix[(size_t)g * FIX_SLOTS + slot] = make_uint4(at_, c1, (uint32_t)(ev_read0 + ev_), shf ? 1u : 0u); \
+                else push_fix_one(P, it.sig_base + at_, c1, it.ev_first + ev_, it.read, shf ? 1 : 0);   /* overflow (never in practice): global list */ \
                 if (slot + 1 == n0 + __popcll(am)) W.nfix = slot + 1;          /* the last of them publishes the new count */ \
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                            \
             }                                                                                                     \
-            idx8 += 512u;                                                                                         \
-            voff = RNA ? voff - 128u : voff + 128u;                                                               \
-            MN = *reinterpret_cast<const uint32_t*>(mult_b + (((idx8 - (RN.y >> 16)) & 0xff8u) >> 1)); }
+            if (DI) { idx4 += 512u; voff = RNA ? voff - 256u : voff + 256u; }                                     \
+            MN = *reinterpret_cast<const uint32_t*>(mult_b + ((DI) ? 0 : 256) + (idx4 - (RN.y >> 16))); }
 
         /* ablation builds (tools/ab_variants.sh; results are wrong): -DSQG_ABL_NOARITH, -DSQG_ABL_NOSTORE, -DSQG_ABL_NOLOOP */
 #if defined(SQG_ABL_NOSTORE)
@@ -254,23 +260,24 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
 #else
         #define LEAN_ARITH(RA, MU) const uint32_t c1 = lcg_mul(RA.x, MU); const float x = box_muller_fast(c1);
 #endif
-        uint4 ra, rb; uint32_t ma, mb; int eva, evb;
+        uint4 ra, rb; uint32_t ma, mb; int eva, evb, eba, ebb;
         base_ev = 0;
-        LEAN_MAP(0, eva)
-        ra = W.rec[eva];
-        ma = *reinterpret_cast<const uint32_t*>(mult_b + (((idx8 - (ra.y >> 16)) & 0xff8u) >> 1));
+        LEAN_MAP(0, eva, eba)
+        ra = (W.rec + eba)[eva];
+        ma = *reinterpret_cast<const uint32_t*>(mult_b + (idx4 - (ra.y >> 16)));
         int c = 0;
         // the (few) items that overlap the RNA level-shift window run the variant that tests every sample against it
         #define LEAN_LOOP(SH)                                                                                    \
             for (; c + 2 <= nfull; c += 2) {                                                                      \
-                LEAN_STEP(SH, false, c, ra, ma, eva, rb, mb, evb)                                                 \
-                LEAN_STEP(SH, false, c + 1, rb, mb, evb, ra, ma, eva)                                             \
+                LEAN_STEP(SH, false, c, 0, ra, ma, eva, eba, rb, mb, evb, ebb)                                    \
+                LEAN_STEP(SH, false, c + 1, 1, rb, mb, evb, ebb, ra, ma, eva, eba)                                \
             }                                                                                                     \
             if (c < nfull) {                                                                                      \
-                LEAN_STEP(SH, false, c, ra, ma, eva, rb, mb, evb)                                                 \
-                ra = rb; ma = mb; eva = evb; c++;                                                                 \
+                LEAN_STEP(SH, false, c, 0, ra, ma, eva, eba, rb, mb, evb, ebb)                                    \
+                ra = rb; ma = mb; eva = evb; eba = ebb; c++;                                                      \
+                idx4 += 256u; voff = RNA ? voff - 128u : voff + 128u;                                             \
             }                                                                                                     \
-            if (rem) LEAN_STEP(SH, true, c, ra, ma, eva, rb, mb, evb)
+            if (rem) LEAN_STEP(SH, true, c, 0, ra, ma, eva, eba, rb, mb, evb, ebb)
         if (RNA && it.shift_hi > it.shift_lo) { LEAN_LOOP(true) } else { LEAN_LOOP(false) }
         #undef LEAN_LOOP
         #undef LEAN_STEP
