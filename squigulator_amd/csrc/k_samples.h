@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_st
 template <int EPL>
 struct LeanWaveLds {
     uint4 rec[64 * EPL];                // {c_ev, (4*first sample) << 16 | I (16 bits), F - 1/2, sdk}
-    unsigned long long bm[64];          // bit s-1 set: an event (other than the item's first) starts at sample s
+    uint4 tb[66];                       // per 64-sample step c: {x,y: bit s-1-64c set: an event (other than the item's first) starts at
+                                        // sample s; z: events begun before the step; w: 0}; entries 64, 65 are read ahead, never used
     int nfix;                           // undecided samples of the item so far
     int pad[3];
 };
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         for (int q = 0; q < LEAN_EPL; q++) lane_total += sps[q];
         const int incl = wave_incl_scan_dpp(lane_total);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // previous item's LDS reads are done
-        W.bm[lane] = 0ull;
+        W.tb[lane] = make_uint4(0u, 0u, 0u, 0u);
         if (lane == 0) W.nfix = 0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         {
@@ -192,13 +193,19 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
                 const float sdk = (float)((double)md[q].y * P.kd);
                 W.rec[lane * LEAN_EPL + q] = make_uint4(er[q].x, ((uint32_t)so << 18) | ((uint32_t)(int)fl0 & 0xffffu),   // so < 4096
                                                         __float_as_uint(Fh), __float_as_uint(sdk));
-                if ((e0 + q < ne) && (lane | q) != 0)                  // so >= 1: every earlier event has >= 1 sample
-                    atomicOr(reinterpret_cast<unsigned int*>(W.bm) + ((so - 1) >> 5), 1u << ((so - 1) & 31));
+                if ((e0 + q < ne) && (lane | q) != 0) {                // so >= 1: every earlier event has >= 1 sample
+                    const uint32_t bit = (uint32_t)(so - 1);
+                    atomicOr(reinterpret_cast<unsigned int*>(W.tb) + ((bit >> 6) << 2) + ((bit >> 5) & 1u), 1u << (bit & 31u));
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        const unsigned long long my_bm = W.bm[lane];
-        const uint32_t bm_lo = (uint32_t)my_bm, bm_hi = (uint32_t)(my_bm >> 32);
+        {   // events begun before each step
+            const uint4 mine = W.tb[lane];
+            const int pc = __builtin_popcount(mine.x) + __builtin_popcount(mine.y);
+            W.tb[lane].z = (uint32_t)(wave_incl_scan_dpp(pc) - pc);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         char* const out_b = reinterpret_cast<char*>(P.sig + it.sig_base);               // wave-uniform: global_store saddr + 32-bit lane offset
         // byte offset of my sample of step 0 within the read: generation index i is stored at at0 + i (RNA: at0 - i)
         uint32_t voff = RNA ? 2u * (it.at0 - (uint32_t)lane) : 2u * (it.at0 + (uint32_t)lane);
@@ -209,20 +216,17 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
 #else
         const int nfull = wave_total >> 6, rem = wave_total & 63;
 #endif
-        int base_ev;
-
-        // event of my sample in step c = evb_ (events begun in earlier steps: scalar) + evl_ (start bits below my lane)
-        #define LEAN_MAP(c_, evl_, evb_) {                                                                       \
-            const uint32_t lo_ = __builtin_amdgcn_readlane(bm_lo, (c_)), hi_ = __builtin_amdgcn_readlane(bm_hi, (c_)); \
-            evb_ = base_ev;                                                                                       \
-            evl_ = (int)__builtin_amdgcn_mbcnt_hi(hi_, __builtin_amdgcn_mbcnt_lo(lo_, 0u));                        \
-            base_ev += __builtin_popcount(lo_) + __builtin_popcount(hi_); }
-        // one step: issue the loads of step c_+1 into (RN, MN, ENL/ENB), then the arithmetic of step c_ from (RA, MU, EVL/EVB).
-        // DI: 0 / 1 = first / second step of a pair; idx4 and voff advance once per pair, the second step's +64 samples ride
-        // in the immediate offsets of its LDS read and its store.
-        #define LEAN_STEP(SH, TAIL, c_, DI, RA, MU, EVL, EVB, RN, MN, ENL, ENB) {                                    \
-            LEAN_MAP(min((c_) + 1, 63), ENL, ENB)                                                                 \
-            RN = (W.rec + ENB)[ENL];                                                                              \
+        // event (within the item) of my sample in the step whose table entry is tq_: events begun in earlier steps + start bits
+        // below my lane
+        #define LEAN_EVOF(tq_) (int)__builtin_amdgcn_mbcnt_hi((tq_).y, __builtin_amdgcn_mbcnt_lo((tq_).x, (tq_).z))
+        // one step: issue the loads of step c_+1 into (RN, MN, EN) and the table entry of step c_+2 into TQN, then the arithmetic
+        // of step c_ from (RA, MU, EV).  TQ: the table entry of step c_+1, loaded one step ago.
+        // DI: 0 / 1 = first / second step of a pair; idx4, voff and tbp advance once per pair, the second step's +64 samples
+        // ride in the immediate offsets of its LDS reads and its store.
+        #define LEAN_STEP(SH, TAIL, c_, DI, RA, MU, EV, RN, MN, EN, TQ, TQN) {                                       \
+            EN = LEAN_EVOF(TQ);                                                                                   \
+            RN = W.rec[EN];                                                                                       \
+            TQN = tbp[2 + (DI)];                                                                                  \
             LEAN_ARITH(RA, MU)                                                                                    \
             const float vh = __builtin_fmaf(x, __uint_as_float(RA.w), __uint_as_float(RA.z));                     \
             const float t = vh + LEAN_MAGIC;                                                                      \
@@ -240,13 +244,13 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
                 const int n0 = W.nfix;                                                                            \
                 const int slot = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)); \
                 const uint32_t at_ = (RNA ? voff - 128u * (DI) : voff + 128u * (DI)) >> 1;                        \
-                const int ev_ = EVB + EVL;                                                                        \
+                const int ev_ = EV;                                                                               \
                 if (slot < FIX_SLOTS) P.tfix[(size_t)g * FIX_SLOTS + slot] = make_uint4(at_, c1, (uint32_t)(ev_read0 + ev_), shf ? 1u : 0u); \
                 else push_fix_one(P, it.sig_base + at_, c1, it.ev_first + ev_, it.read, shf ? 1 : 0);   /* overflow (never in practice): global list */ \
                 if (slot + 1 == n0 + __popcll(am)) W.nfix = slot + 1;          /* the last of them publishes the new count */ \
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                            \
             }                                                                                                     \
-            if (DI) { idx4 += 512u; voff = RNA ? voff - 256u : voff + 256u; }                                     \
+            if (DI) { idx4 += 512u; voff = RNA ? voff - 256u : voff + 256u; tbp += 2; }                           \
             MN = *reinterpret_cast<const uint32_t*>(mult_b + ((DI) ? 0 : 256) + (idx4 - (RN.y >> 16))); }
 
         /* ablation builds (tools/ab_variants.sh; results are wrong): -DSQG_ABL_NOARITH, -DSQG_ABL_NOSTORE, -DSQG_ABL_NOLOOP */
@@ -260,28 +264,32 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
 #else
         #define LEAN_ARITH(RA, MU) const uint32_t c1 = lcg_mul(RA.x, MU); const float x = box_muller_fast(c1);
 #endif
-        uint4 ra, rb; uint32_t ma, mb; int eva, evb, eba, ebb;
-        base_ev = 0;
-        LEAN_MAP(0, eva, eba)
-        ra = (W.rec + eba)[eva];
+        uint4 ra, rb, tqa, tqb; uint32_t ma, mb; int eva, evb;
+        const uint4* tbp = W.tb;                                        // table entry of the current pair's first step
+        {
+            const uint4 tq0 = tbp[0];
+            eva = LEAN_EVOF(tq0);
+        }
+        ra = W.rec[eva];
+        tqa = tbp[1];
         ma = *reinterpret_cast<const uint32_t*>(mult_b + (idx4 - (ra.y >> 16)));
         int c = 0;
         // the (few) items that overlap the RNA level-shift window run the variant that tests every sample against it
         #define LEAN_LOOP(SH)                                                                                    \
             for (; c + 2 <= nfull; c += 2) {                                                                      \
-                LEAN_STEP(SH, false, c, 0, ra, ma, eva, eba, rb, mb, evb, ebb)                                    \
-                LEAN_STEP(SH, false, c + 1, 1, rb, mb, evb, ebb, ra, ma, eva, eba)                                \
+                LEAN_STEP(SH, false, c, 0, ra, ma, eva, rb, mb, evb, tqa, tqb)                                    \
+                LEAN_STEP(SH, false, c + 1, 1, rb, mb, evb, ra, ma, eva, tqb, tqa)                                \
             }                                                                                                     \
             if (c < nfull) {                                                                                      \
-                LEAN_STEP(SH, false, c, 0, ra, ma, eva, eba, rb, mb, evb, ebb)                                    \
-                ra = rb; ma = mb; eva = evb; eba = ebb; c++;                                                      \
-                idx4 += 256u; voff = RNA ? voff - 128u : voff + 128u;                                             \
+                LEAN_STEP(SH, false, c, 0, ra, ma, eva, rb, mb, evb, tqa, tqb)                                    \
+                ra = rb; ma = mb; eva = evb; tqa = tqb; c++;                                                      \
+                idx4 += 256u; voff = RNA ? voff - 128u : voff + 128u; tbp += 1;                                   \
             }                                                                                                     \
-            if (rem) LEAN_STEP(SH, true, c, 0, ra, ma, eva, eba, rb, mb, evb, ebb)
+            if (rem) LEAN_STEP(SH, true, c, 0, ra, ma, eva, rb, mb, evb, tqa, tqb)
         if (RNA && it.shift_hi > it.shift_lo) { LEAN_LOOP(true) } else { LEAN_LOOP(false) }
         #undef LEAN_LOOP
         #undef LEAN_STEP
-        #undef LEAN_MAP
+        #undef LEAN_EVOF
         #undef LEAN_ARITH
         #undef LEAN_STORE_COND
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
