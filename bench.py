@@ -255,6 +255,11 @@ def main():
     ap.add_argument("--host-sampler", action="store_true",
                     help="sample the reads with numpy on the host (same distribution) instead of the device-side gen_read")
     ap.add_argument("--no-store-probe", action="store_true")
+    ap.add_argument("--job-workers", type=int, default=0,
+                    help="T of the whole job (the reference's -t).  Default: one worker per read, sharded by worker over the "
+                         "GPUs, no data-path collective.  With a value (e.g. 1: the reference's reproducible regime) every "
+                         "GPU owns all T workers and generates a range of each batch's reads; the per-stream sample counts "
+                         "are all-gathered over RCCL once per batch (range sharding, include/sqg.h)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for one rank per GPU; gloo only to exercise the N>1 control flow on a "
                          "box with fewer GPUs than ranks (ranks then share GPUs)")
@@ -299,11 +304,17 @@ def main():
         mean, stdv = shard.broadcast_model(mean, stdv, src=0)
 
     K = args.batch_reads
-    T = K * world
-    w_lo, w_hi = shard.worker_range(rank, world, T)              # contiguous block of K virtual workers
+    range_mode = args.job_workers > 0
+    if range_mode and args.host_sampler:
+        raise SystemExit("--job-workers needs the device sampler")
+    T = args.job_workers if range_mode else K * world
+    w_lo, w_hi = (0, T) if range_mode else shard.worker_range(rank, world, T)   # default: contiguous block of K virtual workers
     gen = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=T, device=local_rank,
                               mode=api.MODE_EXACT if args.mode == "exact" else api.MODE_CERTIFIED,
                               worker_lo=w_lo, worker_hi=w_hi)
+    if range_mode:
+        gen.set_range_mode(True)
+    r_lo, r_hi = shard.read_range(rank, world, K * world)          # range mode: my reads of the job's K*world-read batches
     if args.workload == "synth-r10":
         contigs = synthetic_genome(args.genome_mb)
     elif args.workload == "sequin-rna004":
@@ -325,7 +336,7 @@ def main():
         # resident genome, sampled on the device at staging time (outside the timed region)
         gen.load_genome(contigs, args.rlen, api.SAMPLE_RNA if wl_mode == "rna" else api.SAMPLE_DNA)
         for _ in range(nsteps):
-            batches.append(gen.sample(K, workers))
+            batches.append(gen.sample(K * world, None, lo=r_lo, hi=r_hi) if range_mode else gen.sample(K, workers))
 
     def sync_all():
         torch.cuda.synchronize()
@@ -333,16 +344,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    n_rows = T * n_k
+    keep = []
+
+    def run(b):
+        """default: one asynchronous launch sequence.  Range mode: counts -> all-gather in range order -> the rest"""
+        if not range_mode or not gen_has_streams:
+            return b.run()
+        mine = shard.counts_tensor(b.run_begin(), n_rows, torch.device("cuda", local_rank))
+        if world > 1:
+            before, after = shard.exchange_counts(mine)
+        else:
+            before = after = torch.zeros_like(mine)
+        torch.cuda.synchronize()
+        keep.append((before, after))                               # alive until the batch has run
+        return b.run_end(before.data_ptr(), after.data_ptr())
+
+    gen_has_streams = not (flags & (profiles.SQ_IDEAL | profiles.SQ_IDEAL_AMP))
     iso_lean_ms = []                  # warm-up batches run one at a time: the sample kernel alone on the machine
     for b in batches[:args.warmup]:
-        b.run().wait()
+        run(b).wait()
         iso_lean_ms.append(gen.timing()["lean_ms"])
     sync_all()
     t0 = time.perf_counter()
     sig_ms, dwell_ms, ev_ms, lean_ms = [], [], [], []
     samples = bases = reads = 0
     for b in batches[args.warmup:]:
-        b.run()                       # asynchronous: all K steps are queued back to back
+        run(b)                        # asynchronous: all K steps are queued back to back (range mode: one exchange per step)
     for b in batches[args.warmup:]:
         b.wait()
         tm = gen.timing()
@@ -383,7 +411,9 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{wl_desc}; -x {args.profile} --seed 42 -r {args.rlen}, "
-                            f"-t {T} -K {T} (T=K virtual workers, {K} per GPU), {args.steps} batches",
+                            + (f"-t {T} -K {K * world} (range sharding: every GPU owns all {T} worker(s) and generates {K} reads of each "
+                               f"batch; one all-gather of {4 * n_rows} B per batch), {args.steps} batches" if range_mode else
+                               f"-t {T} -K {T} (T=K virtual workers, {K} per GPU), {args.steps} batches"),
                 "reads_per_step_per_gpu": K, "kmer_size": k, "mode": args.mode,
                 "reads": "numpy draws of gen_read's distribution (host)" if args.host_sampler
                          else "gen_read on the device-resident genome (library sampler), as the reference with these options",

@@ -204,6 +204,28 @@ int  sqg_batch_sample(sqg_ctx_t *ctx, int32_t n_reads, const int32_t *worker, sq
 /* the sampled reads as gen_read returned them (after N substitution and revcomp), for the FASTA/SAM writers */
 int  sqg_fetch_reads(sqg_ctx_t *ctx, sqg_batch_t *b, char *dst /* seq_off[n_reads] bytes */);
 
+/* ---- SURVEY.md section 8e, "strict -t 1" over several GPUs: range sharding ----
+ * A job is normally sharded by worker (worker_lo/worker_hi): no exchange at all.  With fewer workers than GPUs -- the
+ * reference's reproducible regime is -t 1 -- every GPU's context instead owns ALL workers and generates a contiguous
+ * range [lo, hi) of each batch's reads.  What a worker's streams need to know about the reads generated elsewhere:
+ *   scalar streams (offset, median_before, time; the sampler's three): a fixed number of draws per read / event /
+ *     gen_read attempt.  sqg_batch_sample_range samples the whole batch on every GPU, stages [lo, hi) and moves the
+ *     streams over the rest; sqg_skip_reads does the latter for reads staged with sqg_batch_stage (call it for the
+ *     reads before the range, stage, call it for the reads after it; seq_len = bases of each read, worker = its id);
+ *   k-mer streams: how many samples the other ranges draw from each (worker, k-mer) stream -- the path's one
+ *     exchange step.  sqg_batch_run_begin leaves this range's counts on the device ([num_workers][4^k] uint32, complete
+ *     when it returns, valid until the next begin; d_before / d_after must be complete when sqg_batch_run_end is called); the caller all-gathers them over the GPUs in range order (RCCL) and passes
+ *     sqg_batch_run_end the element-wise sums over the earlier (d_before) and the later (d_after) ranges.  A batch
+ *     may draw at most 2^32-1 samples from one stream over all ranges (k > 6: 3.2e9).
+ * sqg_set_range_mode(ctx, 1) must be on when such batches are staged (no staged batch may be pending);
+ * sqg_batch_run still works and equals begin + end(NULL, NULL): the whole batch is then this context's. */
+int  sqg_set_range_mode(sqg_ctx_t *ctx, int on);
+int  sqg_skip_reads(sqg_ctx_t *ctx, int32_t n_reads, const int64_t *seq_len, const int32_t *worker);
+int  sqg_batch_sample_range(sqg_ctx_t *ctx, int32_t n_reads, const int32_t *worker, int32_t lo, int32_t hi,
+                            sqg_batch_t **out, sqg_sample_t *info);
+int  sqg_batch_run_begin(sqg_ctx_t *ctx, sqg_batch_t *b, const uint32_t **d_counts);
+int  sqg_batch_run_end(sqg_ctx_t *ctx, sqg_batch_t *b, const uint32_t *d_before, const uint32_t *d_after);
+
 /* Page-locked host memory for the sqg_fetch_* destinations: the D2H copy of a batch's signal (2 B/sample, or ~1.3
  * with sqg_batch_compress) is what bounds a host that consumes the output (Measurement); into pinned
  * memory it runs at the link rate instead of through a staging buffer.  Plain malloc'd destinations keep working. */

@@ -77,7 +77,8 @@ EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_d
            "sqg_batch_stage", "sqg_batch_run", "sqg_batch_wait", "sqg_fetch_signal", "sqg_fetch_dwell",
            "sqg_batch_free", "sqg_get_timing", "sqg_submit", "sqg_worker_of", "sqg_probe_store_bandwidth",
            "sqg_batch_compress", "sqg_fetch_svb", "sqg_genome_load", "sqg_batch_sample", "sqg_fetch_reads",
-           "sqg_host_alloc", "sqg_host_free")
+           "sqg_host_alloc", "sqg_host_free", "sqg_set_range_mode", "sqg_skip_reads", "sqg_batch_sample_range",
+           "sqg_batch_run_begin", "sqg_batch_run_end")
 
 _lib = None
 
@@ -136,6 +137,16 @@ def load_library(path: str | None = None):
     L.sqg_host_alloc.argtypes = [C.c_size_t]
     L.sqg_host_free.restype = None
     L.sqg_host_free.argtypes = [vp]
+    L.sqg_set_range_mode.restype = C.c_int
+    L.sqg_set_range_mode.argtypes = [vp, C.c_int]
+    L.sqg_skip_reads.restype = C.c_int
+    L.sqg_skip_reads.argtypes = [vp, i32, C.POINTER(i64), C.POINTER(i32)]
+    L.sqg_batch_sample_range.restype = C.c_int
+    L.sqg_batch_sample_range.argtypes = [vp, i32, C.POINTER(i32), i32, i32, C.POINTER(vp), C.POINTER(CSample)]
+    L.sqg_batch_run_begin.restype = C.c_int
+    L.sqg_batch_run_begin.argtypes = [vp, vp, C.POINTER(vp)]
+    L.sqg_batch_run_end.restype = C.c_int
+    L.sqg_batch_run_end.argtypes = [vp, vp, vp, vp]
     if path == _build.LIB:
         _lib = L
     return L
@@ -150,6 +161,19 @@ class Batch:
 
     def run(self):
         self.gen._chk(self.gen.L.sqg_batch_run(self.gen.ctx, self.handle), "sqg_batch_run")
+        return self
+
+    def run_begin(self) -> int:
+        """Range sharding: first phase of the run; returns the DEVICE address of this range's per-stream sample counts
+        (uint32 [num_workers][4^k], valid until the next run_begin)."""
+        p = C.c_void_p()
+        self.gen._chk(self.gen.L.sqg_batch_run_begin(self.gen.ctx, self.handle, C.byref(p)), "sqg_batch_run_begin")
+        return p.value
+
+    def run_end(self, d_before: int | None = None, d_after: int | None = None):
+        """second phase; d_before / d_after: device addresses of the counts summed over the earlier / later ranges"""
+        self.gen._chk(self.gen.L.sqg_batch_run_end(self.gen.ctx, self.handle, C.c_void_p(d_before), C.c_void_p(d_after)),
+                      "sqg_batch_run_end")
         return self
 
     def wait(self):
@@ -285,13 +309,30 @@ class SignalGenerator:
             g.trans_idx = idx.ctypes.data_as(C.POINTER(C.c_int32))
         self._chk(self.L.sqg_genome_load(self.ctx, C.byref(g)), "sqg_genome_load")
 
-    def sample(self, n: int, workers=None) -> Batch:
-        """gen_read for n reads on the device + staging; the returned batch carries .sampled (per-read arrays)."""
+    def set_range_mode(self, on: bool = True):
+        """range sharding (include/sqg.h): this context owns all workers and generates a range of each batch's reads"""
+        self._chk(self.L.sqg_set_range_mode(self.ctx, 1 if on else 0), "sqg_set_range_mode")
+
+    def skip_reads(self, seq_lens, workers):
+        ln = np.ascontiguousarray(seq_lens, np.int64)
+        wk = np.ascontiguousarray(workers, np.int32)
+        assert ln.shape == wk.shape
+        self._chk(self.L.sqg_skip_reads(self.ctx, len(ln), ln.ctypes.data_as(C.POINTER(C.c_int64)),
+                                        wk.ctypes.data_as(C.POINTER(C.c_int32))), "sqg_skip_reads")
+
+    def sample(self, n: int, workers=None, lo: int | None = None, hi: int | None = None) -> Batch:
+        """gen_read for n reads on the device + staging; the returned batch carries .sampled (per-read arrays).
+        lo/hi (range sharding): all n reads are sampled, reads [lo, hi) are staged."""
         wk = np.ascontiguousarray(workers, np.int32) if workers is not None else None
+        wkp = wk.ctypes.data_as(C.POINTER(C.c_int32)) if wk is not None else None
         h = C.c_void_p()
         info = CSample()
-        rc = self.L.sqg_batch_sample(self.ctx, n, wk.ctypes.data_as(C.POINTER(C.c_int32)) if wk is not None else None,
-                                     C.byref(h), C.byref(info))
+        if lo is None and hi is None:
+            rc = self.L.sqg_batch_sample(self.ctx, n, wkp, C.byref(h), C.byref(info))
+        else:
+            lo, hi = (0 if lo is None else lo), (n if hi is None else hi)
+            rc = self.L.sqg_batch_sample_range(self.ctx, n, wkp, lo, hi, C.byref(h), C.byref(info))
+            n = hi - lo
         self._chk(rc, "sqg_batch_sample")
         b = Batch(self, h, n)
         arr = lambda p, shape, dt: (np.ctypeslib.as_array(p, shape=shape).copy() if n else np.zeros(0, dt))  # noqa: E731

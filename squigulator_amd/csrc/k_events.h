@@ -179,15 +179,26 @@ __global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restr
 //   k_events       as usual, one workgroup per link, dwell from memory
 // grid (num_kmer/64, worker chains), 1024 threads: 64 k-mers x 16 groups of consecutive links.
 // wlink_off[q]..wlink_off[q+1]: the links of worker chain q, in chain order
+// the row `base` after n more samples (k > 6: base + n < 2^32, checked at staging)
 template <bool DIRECT>
-__global__ __launch_bounds__(1024) void k_link_prefix(const SigParams P, const int* __restrict__ wlink_off, const int* __restrict__ wlink_worker) {
+__device__ static inline uint32_t row_after(const uint32_t* __restrict__ pw, uint32_t base, unsigned long long n) {
+    if (!DIRECT) return base + (uint32_t)n;
+    if (!n) return base;
+    return lcg_mul(base, lcg_jump2(pw, n < 4294967296ull ? (uint32_t)n : (uint32_t)(n % LCG_ORD2)));
+}
+
+// before (optional, [n_local_workers][num_kmer]): samples other GPUs draw from each stream ahead of this batch's local
+// reads (range sharding, sqg_batch_run_end); the worker's own row is then left to k_rows_advance
+template <bool DIRECT>
+__global__ __launch_bounds__(1024) void k_link_prefix(const SigParams P, const int* __restrict__ wlink_off, const int* __restrict__ wlink_worker,
+                                                      const uint32_t* __restrict__ before) {
     __shared__ unsigned long long sums[16][64];
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, q = blockIdx.y;
     const int j = blockIdx.x * 64 + lane;
     const bool live = j < P.num_kmer;
     const int l0 = wlink_off[q], l1 = wlink_off[q + 1];
     const int per = (l1 - l0 + 15) / 16, la = min(l0 + g * per, l1), lb = min(la + per, l1);
-    uint32_t* wrow = P.rows + (size_t)wlink_worker[q] * P.num_kmer;
+    const size_t wj = (size_t)wlink_worker[q] * P.num_kmer + j;
     uint32_t* lr = P.link_rows + j;
     unsigned long long sum = 0;
     if (live) for (int l = la; l < lb; l++) sum += lr[(size_t)l * P.num_kmer];
@@ -196,21 +207,48 @@ __global__ __launch_bounds__(1024) void k_link_prefix(const SigParams P, const i
     unsigned long long excl = 0, total = 0;
     for (int w = 0; w < 16; w++) { const unsigned long long x = sums[w][lane]; if (w < g) excl += x; total += x; }
     if (!live) return;
-    const uint32_t base = wrow[j];
-    // the row after n more samples (k > 6: n < 2^32 - (M-1)/2, checked at staging)
-    auto at = [&](unsigned long long n) -> uint32_t {
-        if (!DIRECT) return base + (uint32_t)n;
-        if (!n) return base;
-        return lcg_mul(base, lcg_jump2(P.pw, n < 4294967296ull ? (uint32_t)n : (uint32_t)(n % LCG_ORD2)));
-    };
-    uint32_t st = at(excl);
+    const uint32_t base = P.rows[wj];
+    if (before) excl += before[wj];
+    uint32_t st = row_after<DIRECT>(P.pw, base, excl);
     for (int l = la; l < lb; l++) {
         const uint32_t cnt = lr[(size_t)l * P.num_kmer];
         lr[(size_t)l * P.num_kmer] = st;
         if (DIRECT) { if (cnt) st = lcg_mul(st, cnt < POW_N ? P.pw[2 * POW_N + cnt] : lcg_jump2(P.pw, cnt)); }
         else st += cnt;
     }
-    if (g == 0) wrow[j] = at(total);
+    if (g == 0 && !before) P.rows[wj] = row_after<DIRECT>(P.pw, base, total);
+}
+
+// range sharding: samples this batch's local reads draw from each (worker, k-mer) stream, from the link histograms
+// (counts zeroed beforehand; workers without local reads stay 0).  Same grid as k_link_prefix.
+__global__ __launch_bounds__(1024) void k_link_totals(const SigParams P, const int* __restrict__ wlink_off, const int* __restrict__ wlink_worker,
+                                                      uint32_t* __restrict__ counts) {
+    __shared__ unsigned long long sums[16][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, q = blockIdx.y;
+    const int j = blockIdx.x * 64 + lane;
+    const bool live = j < P.num_kmer;
+    const int l0 = wlink_off[q], l1 = wlink_off[q + 1];
+    const int per = (l1 - l0 + 15) / 16, la = min(l0 + g * per, l1), lb = min(la + per, l1);
+    unsigned long long sum = 0;
+    if (live) for (int l = la; l < lb; l++) sum += P.link_rows[(size_t)l * P.num_kmer + j];
+    sums[g][lane] = sum;
+    __syncthreads();
+    if (g == 0 && live) {
+        unsigned long long total = 0;
+        for (int w = 0; w < 16; w++) total += sums[w][lane];
+        counts[(size_t)wlink_worker[q] * P.num_kmer + j] = (uint32_t)total;
+    }
+}
+
+// range sharding: every local worker's row moves past the whole batch -- the samples drawn here and on the other GPUs
+template <bool DIRECT>
+__global__ __launch_bounds__(256) void k_rows_advance(uint32_t* __restrict__ rows, const uint32_t* __restrict__ pw, size_t n,
+                                                      const uint32_t* __restrict__ before, const uint32_t* __restrict__ mine,
+                                                      const uint32_t* __restrict__ after) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long t = (unsigned long long)before[i] + mine[i] + after[i];
+    if (t) rows[i] = row_after<DIRECT>(pw, rows[i], t);
 }
 
 // k > 6: the rows count samples; a stream's state only depends on the count mod (M-1)/2

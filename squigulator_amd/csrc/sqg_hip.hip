@@ -60,6 +60,8 @@ struct sqg_ctx {
     hipStream_t stream2 = nullptr;                 // the sample kernels (k_samples_lean, generic, fix-ups)
     uint32_t* d_link_rows = nullptr; size_t link_rows_cap = 0;   // split chains: one row per link of the running batch
     double row_bound = 0;                          // k > 6: upper bound of any sample count held in d_rows
+    bool range_mode = false;                       // range sharding (sqg_set_range_mode): every batch is cut into links and run in two phases
+    uint32_t* d_xcounts = nullptr; size_t xcounts_cap = 0;       // [nw][num_kmer] samples the running batch draws per stream (sqg_batch_run_begin)
     // device block, pinned offsets and events of freed batches, kept for the next sqg_batch_stage / sqg_batch_sample
     struct Recycled { uint8_t* d_block; size_t block_bytes; long long* h_sigoff; long long* h_sigoff_dev; size_t h_n; hipEvent_t ev[8]; };
     std::vector<Recycled> pool;
@@ -128,6 +130,7 @@ struct sqg_batch {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel-phase boundaries; [7]: the event side is done
     int slot = 0;                        // which of the context's two buffer sets this batch runs in
     bool ran = false, waited = false, lean_timed = false, dwell_timed = false;
+    bool begun = false, other_fresh = false;   // sqg_batch_run_begin has run; the other slot had never held a batch then
 };
 
 #define HIPCHK(ctx, call)                                                                      \
@@ -194,7 +197,7 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
-    (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err);
+    (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_xcounts); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err);
     for (auto& S : ctx->slot) {
         (void)hipFree(S.d_sig); (void)hipFree(S.d_dwell); (void)hipFree(S.d_seglen); (void)hipFree(S.d_sigoff);
         (void)hipFree(S.d_fix); (void)hipFree(S.d_fix_count);
@@ -553,7 +556,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         const char* env = getenv("SQG_SPLIT_CHAINS");
         const int forced = env ? atoi(env) : -1;
         const bool multi = n > n_wchains;
-        const bool want = forced >= 0 ? (forced > 0 && multi) : (multi && n_wchains < 1024 && nev >= 65536);
+        const bool want = c->range_mode ? n > 0 : forced >= 0 ? (forced > 0 && multi) : (multi && n_wchains < 1024 && nev >= 65536);
         if (c->use_kmer_streams && want) {
             const size_t row_bytes = (size_t)c->num_kmer * sizeof(uint32_t);
             long long target = forced > 0 ? forced : 2048;
@@ -781,7 +784,50 @@ extern "C" int sqg_genome_load(sqg_ctx_t* c, const sqg_genome_t* g) {
     return SQG_OK;
 }
 
+// events of a read of `len` bases once the prefix is attached (src/gensig.c:242-245, src/genread.c:87-123)
+static long long read_events(const sqg_ctx* c, long long len) {
+    const bool rna = c->cfg.flags & SQG_RNA, prefix = c->cfg.flags & SQG_PREFIX;
+    long long len0 = len;
+    if (prefix) len0 += rna ? (kPolyA + (long long)strlen(kAdaptorRna)) : ((long long)strlen(kStallDna) + (long long)strlen(kAdaptorDna));
+    const long long ne0 = len0 < c->k ? 5 : len0 - c->k + 1;
+    const long long ne1 = (prefix && rna) ? (long long)strlen(kStallRna) - c->k + 1 : 0;
+    return ne0 + ne1;
+}
+
+// a read generated elsewhere (range sharding): local worker w's scalar streams move past it -- one offset and one
+// median_before draw (src/gensig.c:315-316), two time-stream draws per event (src/gensig.c:255)
+static void skip_read(sqg_ctx* c, int w, long long n_events) {
+    const sqg_profile_t& p = c->cfg.profile;
+    if (!(c->cfg.flags & SQG_IDEAL)) {
+        (void)host_nrng(p.offset_mean, p.offset_std, &c->off_x[(size_t)w]);
+        (void)host_nrng(p.median_before_mean, p.median_before_std, &c->med_x[(size_t)w]);
+    }
+    if (c->use_dwell_stream)
+        c->time_c[(size_t)w] = lcg_mul(c->time_c[(size_t)w], lcg_pow(lcg_mul(LCG_A, LCG_A), (unsigned long long)n_events));
+}
+
+extern "C" int sqg_skip_reads(sqg_ctx_t* c, int32_t n, const int64_t* seq_len, const int32_t* worker) {
+    if (!c || n < 0 || (n > 0 && (!seq_len || !worker))) return SQG_EINVAL;
+    for (int i = 0; i < n; i++)
+        if (worker[i] < c->wlo || worker[i] >= c->whi || seq_len[i] < 0) { c->err = "sqg_skip_reads: worker not owned by this context, or negative length"; return SQG_EINVAL; }
+    for (int i = 0; i < n; i++) skip_read(c, worker[i] - c->wlo, read_events(c, seq_len[i]));
+    return SQG_OK;
+}
+
+static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t lo, int32_t hi, sqg_batch_t** out, sqg_sample_t* info);
+
 extern "C" int sqg_batch_sample(sqg_ctx_t* c, int32_t n, const int32_t* worker, sqg_batch_t** out, sqg_sample_t* info) {
+    return sample_impl(c, n, worker, 0, n, out, info);
+}
+
+extern "C" int sqg_batch_sample_range(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t lo, int32_t hi, sqg_batch_t** out, sqg_sample_t* info) {
+    if (lo < 0 || hi < lo || hi > n) return SQG_EINVAL;
+    return sample_impl(c, n, worker, lo, hi, out, info);
+}
+
+// gen_read for all n reads of the batch (the sampler streams are consumed read by read); reads [lo, hi) are staged, the
+// workers' scalar streams skip over the others
+static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t lo, int32_t hi, sqg_batch_t** out, sqg_sample_t* info) {
     if (!c || !out || n < 0) return SQG_EINVAL;
     if (!c->genome_loaded) { c->err = "sqg_genome_load has not been called"; return SQG_EINVAL; }
     *out = nullptr;
@@ -860,14 +906,25 @@ extern "C" int sqg_batch_sample(sqg_ctx_t* c, int32_t n, const int32_t* worker, 
     }
 #undef CHKS
     // lengths are known now: stage as sqg_batch_stage would, the base buffer being filled on the device
-    std::vector<int64_t> seq_off((size_t)n + 1, 0);
-    for (int i = 0; i < n; i++) seq_off[(size_t)i + 1] = seq_off[(size_t)i] + rec[(size_t)i].rlen;
-    rc = stage_common(c, n, nullptr, seq_off.data(), worker, d_rec, out);
+    const int m = hi - lo;                                       // reads staged here
+    std::vector<int64_t> seq_off((size_t)m + 1, 0);
+    for (int i = 0; i < m; i++) seq_off[(size_t)i + 1] = seq_off[(size_t)i] + rec[(size_t)(lo + i)].rlen;
+    std::vector<int32_t> wk_glob;                                // global worker ids of the whole batch (the partition depends on n)
+    if (m != n) {
+        wk_glob.resize((size_t)n);
+        for (int i = 0; i < n; i++) wk_glob[(size_t)i] = wk[(size_t)i] + c->wlo;
+        for (int i = 0; i < lo; i++) skip_read(c, wk[(size_t)i], read_events(c, rec[(size_t)i].rlen));
+    }
+    rc = stage_common(c, m, nullptr, seq_off.data(), m != n ? wk_glob.data() + lo : worker, d_rec + lo, out);
+    if (rc == SQG_OK && m != n)
+        for (int i = hi; i < n; i++) skip_read(c, wk[(size_t)i], read_events(c, rec[(size_t)i].rlen));
     cleanup();
     if (rc) return rc;
     sqg_batch* b = *out;
     const bool rna = c->cfg.flags & SQG_RNA, prefix = c->cfg.flags & SQG_PREFIX;
     const long long read_at = (prefix && !rna) ? (long long)(strlen(kStallDna) + strlen(kAdaptorDna)) : 0;
+    rec.erase(rec.begin(), rec.begin() + lo); rec.resize((size_t)m);
+    n = m;
     b->s_ref_idx.resize((size_t)n); b->s_ref_len.resize((size_t)n); b->s_ref_pos.resize((size_t)n); b->s_rlen.resize((size_t)n);
     b->s_strand.resize((size_t)n + 1); b->s_seq_off.assign(seq_off.begin(), seq_off.end()); b->s_read_at.resize((size_t)n);
     for (int i = 0; i < n; i++) {
@@ -904,9 +961,12 @@ static int dbg_sync(sqg_ctx* c, const char* what) {
     return SQG_OK;
 }
 
-extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
+// phase 0: the whole run; 1: up to the per-stream sample counts of a split batch (sqg_batch_run_begin); 2: the rest
+// (sqg_batch_run_end), `before` / `after` being what the other ranges of the batch draw from each stream
+static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* before, const uint32_t* after) {
     if (!c || !b) return SQG_EINVAL;
-    if (b->ran || b->seq != c->next_run) return SQG_ESEQUENCE;
+    if (phase == 2 ? (!b->begun || b->ran) : (b->ran || b->begun || b->seq != c->next_run)) return SQG_ESEQUENCE;
+    if ((before == nullptr) != (after == nullptr)) return SQG_EINVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const sqg_profile_t& p = c->cfg.profile;
     const int n = b->n;
@@ -914,22 +974,26 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     int rc;
     b->slot = (int)(b->seq & 1);
     sqg_ctx::Slot& S = c->slot[b->slot];
-    // this slot's buffers were last used by the sample kernels of batch seq-2 (stream2)
-    HIPCHK(c, hipStreamWaitEvent(c->stream, S.done, 0));
-    auto grow = [&](sqg_ctx::Slot& Z) -> int { return grow_slot(c, Z, b, /*with_output=*/false); };
     sqg_ctx::Slot& other = c->slot[b->slot ^ 1];
-    const bool other_fresh = other.reads_cap == 0 && n > 0;
-    if ((rc = grow(S))) return rc;
-    if (other_fresh && (rc = grow(other))) return rc;
+    if (phase != 2) {
+        // this slot's buffers were last used by the sample kernels of batch seq-2 (stream2)
+        HIPCHK(c, hipStreamWaitEvent(c->stream, S.done, 0));
+        auto grow = [&](sqg_ctx::Slot& Z) -> int { return grow_slot(c, Z, b, /*with_output=*/false); };
+        b->other_fresh = other.reads_cap == 0 && n > 0;
+        if ((rc = grow(S))) return rc;
+        if (b->other_fresh && (rc = grow(other))) return rc;
+    }
+    const bool other_fresh = b->other_fresh;
 
     // Dwell draws are made inside k_events (SQG_SEPARATE_DWELL=1 keeps the stand-alone k_dwell for A/B runs).
     static const bool separate_dwell = getenv("SQG_SEPARATE_DWELL") != nullptr;
     const bool inline_dwell = c->use_dwell_stream && !separate_dwell;
     const bool direct = c->k <= 6;
-    if (!direct && c->use_kmer_streams && n > 0) {
-        // the rows count samples in 32 bits; only the count mod (M-1)/2 matters
+    if (phase != 2 && !direct && c->use_kmer_streams && n > 0) {
+        // the rows count samples in 32 bits; only the count mod (M-1)/2 matters (range mode: the other ranges' counts are not
+        // known here, so the rows are reduced before every batch)
         const double bnd = (double)b->max_wchain_ev * c->dwell_hi;
-        if (c->row_bound + bnd >= 4294967295.0) {
+        if (c->range_mode || c->row_bound + bnd >= 4294967295.0) {
             const size_t nrow = (size_t)c->nw * (size_t)c->num_kmer;
             hipLaunchKernelGGL(k_rows_normalize, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, c->stream, c->d_rows, nrow);
             HIPCHK(c, hipGetLastError());
@@ -937,7 +1001,9 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
         }
         c->row_bound += bnd;
     }
-    if (b->split && (rc = ensure(c, (void**)&c->d_link_rows, &c->link_rows_cap, (size_t)b->n_chains * (size_t)c->num_kmer, sizeof(uint32_t)))) return rc;
+    if (phase != 2 && b->split && (rc = ensure(c, (void**)&c->d_link_rows, &c->link_rows_cap, (size_t)b->n_chains * (size_t)c->num_kmer, sizeof(uint32_t)))) return rc;
+    const size_t n_rows = (size_t)c->nw * (size_t)c->num_kmer;
+    if (phase == 1 && (rc = ensure(c, (void**)&c->d_xcounts, &c->xcounts_cap, n_rows, sizeof(uint32_t)))) return rc;
     SigParams P;
     memset(&P, 0, sizeof P);
     P.link_rows = b->split ? c->d_link_rows : nullptr;
@@ -963,41 +1029,67 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
 #undef EVL
     };
 
-    HIPCHK(c, hipEventRecord(b->ev[0], c->stream));
-    if (n > 0) {
-        if (c->use_dwell_stream && !inline_dwell) {
-            HIPCHK(c, hipMemsetAsync(S.d_seglen, 0, (size_t)2 * n * sizeof(unsigned long long), c->stream));
-            const long long nblk = (b->n_events + DW_EPB - 1) / DW_EPB;
-            if (nblk > 0) {
-                if (certified)
-                    hipLaunchKernelGGL(k_dwell<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, b->d_reads, n, b->d_blk_read,
-                                       b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, c->delta_x, S.d_dwell, S.d_seglen, c->d_err);
-                else
-                    hipLaunchKernelGGL(k_dwell<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, b->d_reads, n, b->d_blk_read,
-                                       b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, 0.f, S.d_dwell, S.d_seglen, c->d_err);
+    if (phase != 2) {
+        HIPCHK(c, hipEventRecord(b->ev[0], c->stream));
+        if (n > 0) {
+            if (c->use_dwell_stream && !inline_dwell) {
+                HIPCHK(c, hipMemsetAsync(S.d_seglen, 0, (size_t)2 * n * sizeof(unsigned long long), c->stream));
+                const long long nblk = (b->n_events + DW_EPB - 1) / DW_EPB;
+                if (nblk > 0) {
+                    if (certified)
+                        hipLaunchKernelGGL(k_dwell<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, b->d_reads, n, b->d_blk_read,
+                                           b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, c->delta_x, S.d_dwell, S.d_seglen, c->d_err);
+                    else
+                        hipLaunchKernelGGL(k_dwell<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, b->d_reads, n, b->d_blk_read,
+                                           b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, 0.f, S.d_dwell, S.d_seglen, c->d_err);
+                }
+                if ((rc = dbg_sync(c, "k_dwell"))) return rc;
+            } else if (!c->use_dwell_stream) {
+                HIPCHK(c, hipMemcpyAsync(S.d_seglen, b->seglen_host.data(), (size_t)2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
             }
-            if ((rc = dbg_sync(c, "k_dwell"))) return rc;
-        } else if (!c->use_dwell_stream) {
-            HIPCHK(c, hipMemcpyAsync(S.d_seglen, b->seglen_host.data(), (size_t)2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
         }
+        b->dwell_timed = c->use_dwell_stream && !inline_dwell;        // stand-alone k_dwell (A/B runs): two more timing events
+        if (b->dwell_timed) { HIPCHK(c, hipEventRecord(b->ev[1], c->stream)); HIPCHK(c, hipEventRecord(b->ev[2], c->stream)); }
     }
-    b->dwell_timed = c->use_dwell_stream && !inline_dwell;        // stand-alone k_dwell (A/B runs): two more timing events
-    if (b->dwell_timed) { HIPCHK(c, hipEventRecord(b->ev[1], c->stream)); HIPCHK(c, hipEventRecord(b->ev[2], c->stream)); }
     if (n > 0 && b->n_chains > 0) {
         const int dw = inline_dwell ? (certified && c->dwell_hi < 1.0e6 ? 1 : 2) : 0;
-        if (b->split) {
-            // links: samples per (link, k-mer) with the dwell draws, then each link's view of its worker's streams
+        const dim3 pg((unsigned)((c->num_kmer + 63) / 64), (unsigned)b->n_wchains);
+        if (b->split && phase != 2) {
+            // links: samples per (link, k-mer) with the dwell draws ...
             if (!direct) HIPCHK(c, hipMemsetAsync(c->d_link_rows, 0, (size_t)b->n_chains * (size_t)c->num_kmer * sizeof(uint32_t), c->stream));
             launch_events(dw, true);
-            const dim3 pg((unsigned)((c->num_kmer + 63) / 64), (unsigned)b->n_wchains);
-            if (direct) hipLaunchKernelGGL(k_link_prefix<true>, pg, dim3(1024), 0, c->stream, P, b->d_wlink_off, b->d_wlink_worker);
-            else hipLaunchKernelGGL(k_link_prefix<false>, pg, dim3(1024), 0, c->stream, P, b->d_wlink_off, b->d_wlink_worker);
+            HIPCHK(c, hipGetLastError());
+            if (phase == 1) {                                     // ... summed per worker for the exchange
+                HIPCHK(c, hipMemsetAsync(c->d_xcounts, 0, n_rows * sizeof(uint32_t), c->stream));
+                hipLaunchKernelGGL(k_link_totals, pg, dim3(1024), 0, c->stream, P, b->d_wlink_off, b->d_wlink_worker, c->d_xcounts);
+                HIPCHK(c, hipGetLastError());
+            }
+        }
+        if (b->split && phase != 1) {
+            // ... then each link's view of its worker's streams
+            if (direct) hipLaunchKernelGGL(k_link_prefix<true>, pg, dim3(1024), 0, c->stream, P, b->d_wlink_off, b->d_wlink_worker, before);
+            else hipLaunchKernelGGL(k_link_prefix<false>, pg, dim3(1024), 0, c->stream, P, b->d_wlink_off, b->d_wlink_worker, before);
+            if (before) {                                         // every worker's row moves past the whole batch, all ranges
+                const dim3 ag((unsigned)((n_rows + 255) / 256));
+                if (direct) hipLaunchKernelGGL(k_rows_advance<true>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
+                else hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
+            }
             HIPCHK(c, hipGetLastError());
             if ((rc = dbg_sync(c, "k_events<hist>/k_link_prefix"))) return rc;
             launch_events(0, false);                              // the dwell is in memory now
-        } else launch_events(dw, false);
+        } else if (!b->split && phase != 1) launch_events(dw, false);
         HIPCHK(c, hipGetLastError());
         if ((rc = dbg_sync(c, "k_events"))) return rc;
+    } else if (phase == 1 && c->d_xcounts) {
+        HIPCHK(c, hipMemsetAsync(c->d_xcounts, 0, n_rows * sizeof(uint32_t), c->stream));
+    }
+    if (phase == 1) { b->begun = true; return SQG_OK; }
+    if (before && !(n > 0 && b->n_chains > 0 && b->split) && c->use_kmer_streams) {
+        // no local reads in this batch: the rows still move past what the other ranges draw
+        const dim3 ag((unsigned)((n_rows + 255) / 256));
+        if (direct) hipLaunchKernelGGL(k_rows_advance<true>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
+        else hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
+        HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(b->ev[3], c->stream));
     if (n > 0) {
@@ -1080,6 +1172,30 @@ extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) {
     HIPCHK(c, hipEventRecord(S.done, c->stream2));
     b->ran = true;
     c->next_run++;
+    return SQG_OK;
+}
+
+extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) { return run_impl(c, b, 0, nullptr, nullptr); }
+
+extern "C" int sqg_batch_run_begin(sqg_ctx_t* c, sqg_batch_t* b, const uint32_t** d_counts) {
+    if (!c || !b || !d_counts) return SQG_EINVAL;
+    if (!c->range_mode) { c->err = "sqg_batch_run_begin needs sqg_set_range_mode(ctx, 1) before the batch is staged"; return SQG_EINVAL; }
+    if (!c->use_kmer_streams) { c->err = "no k-mer streams in --ideal / --ideal-amp: nothing to exchange, use sqg_batch_run"; return SQG_EINVAL; }
+    const int rc = run_impl(c, b, 1, nullptr, nullptr);
+    if (rc != SQG_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));                  // the counts are complete on return: the exchange runs on the caller's stream
+    *d_counts = c->d_xcounts;
+    return SQG_OK;
+}
+
+extern "C" int sqg_batch_run_end(sqg_ctx_t* c, sqg_batch_t* b, const uint32_t* d_before, const uint32_t* d_after) {
+    return run_impl(c, b, 2, d_before, d_after);
+}
+
+extern "C" int sqg_set_range_mode(sqg_ctx_t* c, int on) {
+    if (!c) return SQG_EINVAL;
+    if (c->next_stage != c->next_run) return SQG_ESEQUENCE;       // staged batches pending
+    c->range_mode = on != 0;
     return SQG_OK;
 }
 

@@ -5,6 +5,10 @@ scalar Lehmer streams plus one per k-mer, src/sim.c:238-257).  Workers never exc
 job with T workers on G GPUs gives rank g the contiguous block [g*T/G, (g+1)*T/G) and every batch is
 split the same way: no data-path collective.  The only exchange is the start-up broadcast of the
 pore-model table from rank 0 (RCCL over xGMI on GPUs; gloo in the CPU tests).
+
+Range sharding (include/sqg.h, SURVEY.md section 8e "strict -t 1"): with fewer workers than GPUs every rank owns all
+workers and generates the reads [lo, hi) of each batch (`read_range`); the one exchange step of the path is then the
+all-gather of the per-(worker, k-mer) sample counts of every rank's range (`exchange_counts`).
 """
 from __future__ import annotations
 
@@ -49,3 +53,38 @@ def broadcast_model(mean, stdv, src: int = 0):
     dist.broadcast(t, src=src)
     h = t.cpu().numpy()
     return np.ascontiguousarray(h[:, 0]), np.ascontiguousarray(h[:, 1])
+
+
+def read_range(rank: int, world: int, n_rec: int):
+    """[lo, hi) of the reads of a batch that `rank` generates under range sharding (contiguous, in batch order)."""
+    return n_rec * rank // world, n_rec * (rank + 1) // world
+
+
+class _DevArray:
+    """a raw device pointer dressed for torch.as_tensor (zero-copy)"""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+def counts_tensor(ptr: int, n: int, device):
+    """the counts sqg_batch_run_begin left on the device, as an int32 torch tensor (same bits as the uint32 counts)"""
+    import torch
+    return torch.as_tensor(_DevArray(ptr, n), device=device)
+
+
+def exchange_counts(mine):
+    """All-gather the per-stream sample counts of every rank's range (rank order = range order) and return
+    (before, after): element-wise sums over the earlier and the later ranks, as int32 tensors on `mine`'s device.
+    uint32 arithmetic is done on the int32 bit patterns (two's complement wrap-around is the same addition)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    on_cpu = dist.get_backend() != "nccl"
+    t = mine.cpu() if on_cpu else mine
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous())
+    zero = torch.zeros_like(t, dtype=torch.int64)
+    before = sum((p.to(torch.int64) for p in parts[:rank]), zero).to(torch.int32)
+    after = sum((p.to(torch.int64) for p in parts[rank + 1:]), zero).to(torch.int32)
+    return before.to(mine.device).contiguous(), after.to(mine.device).contiguous()

@@ -86,3 +86,73 @@ def test_two_rank_sharding_equals_single_process(T, K):
             want.append((b, i, len(r.sig), int(np.int64(r.sig.astype(np.int64) @ np.arange(1, len(r.sig) + 1) % 1000003)), r.offset))
     o.close()
     assert got == sorted(want)
+
+
+def _stream_counts(reads, results, k, T, worker):
+    """samples each (worker, k-mer) stream is asked for by these reads: what sqg_batch_run_begin leaves on the device"""
+    code = np.zeros(256, np.int64)
+    code[[ord(x) for x in "Cc"]], code[[ord(x) for x in "Gg"]], code[[ord(x) for x in "Tt"]] = 1, 2, 3
+    c = np.zeros((T, 4 ** k), np.uint64)
+    for r, res, w in zip(reads, results, worker):
+        b = code[np.frombuffer(r, np.uint8)]
+        ranks = np.zeros(len(b) - k + 1, np.int64)
+        for i in range(k):                                        # src/seq.h:31-42: the first base is the most significant
+            ranks = ranks * 4 + b[i:len(b) - k + 1 + i]
+        np.add.at(c[w], ranks, np.asarray(res.ss, np.uint64))
+    return c.reshape(-1)
+
+
+def _range_worker(rank, world, port, T, K, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch
+    import orc
+    from squigulator_amd import model, profiles, shard
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    mean, stdv = model.synthetic_model(6)
+    o = orc.Oracle(prof, fl, 6, mean, stdv, 42, num_workers=T)
+    reads = _reads(K, 7)
+    wk = shard.batch_workers(K, T)
+    res = o.run_batch_assigned(reads, wk, want_ss=True)       # every rank knows the whole batch here; it owns [lo, hi)
+    lo, hi = shard.read_range(rank, world, K)
+    mine = _stream_counts(reads[lo:hi], res[lo:hi], 6, T, wk[lo:hi])
+    t = torch.from_numpy(mine.astype(np.uint32).view(np.int32))
+    before, after = shard.exchange_counts(t)
+    out.put((rank, lo, hi, before.numpy().view(np.uint32).copy(), after.numpy().view(np.uint32).copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+    o.close()
+
+
+@pytest.mark.parametrize("T,K", [(1, 9), (2, 7)])
+def test_range_sharding_exchange_gives_every_rank_the_counts_of_the_other_ranges(T, K):
+    """world size 2 over gloo: `before` is exactly what the reads ahead of a rank's range draw from each stream,
+    `after` what the reads behind it draw"""
+    sys.path.insert(0, HERE)
+    import orc
+    from squigulator_amd import model, profiles, shard
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_range_worker, args=(r, 2, port, T, K, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    mean, stdv = model.synthetic_model(6)
+    o = orc.Oracle(prof, fl, 6, mean, stdv, 42, num_workers=T)
+    reads = _reads(K, 7)
+    wk = shard.batch_workers(K, T)
+    res = o.run_batch_assigned(reads, wk, want_ss=True)
+    o.close()
+    ranges = sorted((lo, hi) for _, lo, hi, _, _ in got)
+    assert ranges[0][0] == 0 and ranges[-1][1] == K and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    for rank, lo, hi, before, after in got:
+        np.testing.assert_array_equal(before, _stream_counts(reads[:lo], res[:lo], 6, T, wk[:lo]).astype(np.uint32))
+        np.testing.assert_array_equal(after, _stream_counts(reads[hi:], res[hi:], 6, T, wk[hi:]).astype(np.uint32))
