@@ -1,0 +1,175 @@
+// h_common.h -- context and batch objects, error macros, the host-side Lehmer / Box-Muller restatement, shared constants
+// Host side of include/sqg.h; included by sqg_hip.hip (one translation unit with the kernels), in the order listed there.
+#pragma once
+
+static uint32_t lcg_pow(uint32_t base, unsigned long long e) {
+    uint32_t r = 1, b = base;
+    while (e) { if (e & 1) r = lcg_mul(r, b); b = lcg_mul(b, b); e >>= 1; }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct sqg_ctx {
+    sqg_cfg_t cfg;
+    int k = 0, num_kmer = 0, T = 0, wlo = 0, whi = 0, nw = 0;
+    hipStream_t stream = nullptr;
+    uint32_t* d_rows = nullptr;
+    float2* d_model = nullptr;
+    uint32_t* d_pow = nullptr;
+    unsigned int* d_err = nullptr;
+    // Everything a batch's kernels write lives in one of two SLOTS (batch seq & 1): a batch's results stay valid while
+    // the next one runs (sqg_batch_wait / sqg_fetch_* of batch i do not wait for batch i+1), and with SQG_OVERLAP=1 the
+    // event kernels of batch i+1 (stream) run while the sample kernels of batch i (stream2) are still busy.
+    struct Slot {
+        int16_t* d_sig = nullptr; size_t sig_cap = 0;
+        uint16_t* d_dwell = nullptr; size_t dwell_cap = 0;
+        unsigned long long* d_seglen = nullptr; long long* d_sigoff = nullptr; size_t reads_cap = 0;
+        FixEntry* d_fix = nullptr; size_t fix_cap = 0;
+        unsigned int* d_fix_count = nullptr;       // [0] fix-up entries, [1] slow tiles
+        uint2* d_evrec = nullptr; size_t evrec_cap = 0;
+        uint32_t* d_tile_so = nullptr; size_t tile_cap = 0;
+        int* d_slow = nullptr; size_t slow_cap = 0;
+        uint4* d_tfix = nullptr; size_t tfix_cap = 0;
+        unsigned char* d_tfix_n = nullptr; size_t tfixn_cap = 0;
+        ItemDesc* d_items = nullptr; size_t items_cap = 0;          // [n_stiles] work items of the lean kernel (k_items)
+        hipEvent_t done = nullptr;                 // recorded on stream2 after the slot's last sample kernel
+    } slot[2];
+    hipStream_t stream2 = nullptr;                 // the sample kernels (k_samples_lean, generic, fix-ups)
+    uint32_t* d_link_rows = nullptr; size_t link_rows_cap = 0;   // split chains: one row per link of the running batch
+    double row_bound = 0;                          // k > 6: upper bound of any sample count held in d_rows
+    bool range_mode = false;                       // range sharding (sqg_set_range_mode): every batch is cut into links and run in two phases
+    uint32_t* d_xcounts = nullptr; size_t xcounts_cap = 0;       // [nw][num_kmer] samples the running batch draws per stream (sqg_batch_run_begin)
+    // device block, pinned offsets and events of freed batches, kept for the next sqg_batch_stage / sqg_batch_sample
+    struct Recycled { uint8_t* d_block; size_t block_bytes; long long* h_sigoff; long long* h_sigoff_dev; size_t h_n; hipEvent_t ev[8]; };
+    std::vector<Recycled> pool;
+    hipStream_t stage_stream = nullptr;            // uploads and the staging kernels (k_sample, k_copy_reads, k_fill_tiles): a host
+                                                   // can stage batch i+1 while batch i runs
+    std::vector<uint32_t> time_c;          // canonical time-stream state per local worker
+    std::vector<long long> off_x, med_x;   // raw Schrage states (as the reference keeps them)
+    unsigned long long next_stage = 0, next_run = 0, compress_seq = 0;
+    sqg_timing_t timing = {0, 0, 0, 0, 0, 0};
+    bool use_dwell_stream = true, use_kmer_streams = true;
+    float delta_x = 0.f;                   // certified mode: swept |x_fast - x_exact| bound incl. margin
+    float delta_x_measured = 0.f;
+    double amp_floor = 0, amp_ceil = 0;    // min/max over k-mers of m*kd -/+ 7|sd*kd| (ADC value range before the offset)
+    float thr_all = -1.f;                  // lean-kernel acceptance threshold (0.5 - largest eps over the table)
+    int lean_epl = 4;                      // events per lane of the lean kernel (work item = 64*lean_epl events)
+    double dwell_hi = 1;                   // hard upper bound of a dwell draw
+    bool force_fix = false;
+    uint8_t* d_genome = nullptr;                                // resident reference (sqg_genome_load)
+    long long* d_contig_off = nullptr; long long* d_cum = nullptr;
+    float* d_trans_csum = nullptr; int* d_trans_idx = nullptr;
+    uint32_t* d_samp = nullptr;                                 // [nw][3] sampler stream states: ref_pos, rand_strand, rand_rlen
+    GenomeParams genome{};
+    bool genome_loaded = false;
+    double samp_ratio = 1.1;                                    // attempts per accepted read seen so far (long chains)
+    uint8_t* d_svb = nullptr; size_t svb_cap = 0;               // svb-zd encodings of the last compressed batch
+    long long* d_svb_size = nullptr; size_t svb_size_cap = 0;   // per read
+    long long* d_svb_off = nullptr; size_t svb_off_cap = 0;
+    long long tile_fix = 0;                // undecided samples parked per tile in the last batch (timing info)
+    std::string err;
+};
+
+struct sqg_batch {
+    unsigned long long seq = 0;
+    int n = 0;
+    long long n_events = 0, n_bases = 0, n_samples = 0;
+    int n_chains = 0;
+    std::vector<long long> ev_off, sig_off;
+    std::vector<double> offset, median;
+    std::vector<unsigned long long> seglen_host;   // only when dwell is constant
+    uint8_t* d_block = nullptr;          // the batch's one device allocation; the pointers below point into it
+    size_t block_bytes = 0, h_n = 0;     // its size; entries of h_sigoff
+    uint8_t* d_bases = nullptr;
+    ReadDesc* d_reads = nullptr;
+    int* d_blk_read = nullptr;
+    int* d_chain_off = nullptr;
+    int* d_chain_reads = nullptr;
+    int* d_chain_order = nullptr;
+    bool split = false;                  // the worker chains are cut into links (d_chain_off describes the links)
+    int n_wchains = 0;                   // workers with reads in this batch
+    int* d_wlink_off = nullptr;          // [n_wchains+1] links of each worker chain
+    int* d_wlink_worker = nullptr;       // [n_wchains]
+    long long max_wchain_ev = 0;         // events of the longest worker chain
+    int* d_tile_read = nullptr;
+    int* d_stile_read = nullptr;
+    long long n_tiles = 0, n_stiles = 0;
+    long long* h_sigoff = nullptr;   // pinned, device-mapped: k_scan writes it directly
+    long long* h_sigoff_dev = nullptr;   // its device-side address
+    long long n_bases_total = 0;         // bytes in d_bases
+    std::vector<long long> h_base_off;   // per read: its segment 0 in d_bases
+    std::vector<int32_t> s_ref_idx, s_ref_len, s_ref_pos, s_rlen;   // sqg_batch_sample: what gen_read returned
+    std::vector<char> s_strand;
+    std::vector<long long> s_seq_off, s_read_at;                    // offsets of the reads in sqg_fetch_reads / in d_bases
+    long long* h_svboff = nullptr;       // pinned, device-mapped: offsets of the svb-zd encodings (sqg_batch_compress)
+    long long n_svb = -1;
+    unsigned long long compress_seq = 0;
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel-phase boundaries; [7]: the event side is done
+    int slot = 0;                        // which of the context's two buffer sets this batch runs in
+    bool ran = false, waited = false, lean_timed = false, dwell_timed = false;
+    bool begun = false, other_fresh = false;   // sqg_batch_run_begin has run; the other slot had never held a batch then
+};
+
+#define HIPCHK(ctx, call)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+            return e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE;                       \
+        }                                                                                      \
+    } while (0)
+
+// the reference's rng()/nrng() on the host, for the two per-read scalar draws that are
+// RETURNED as doubles (offset, median_before; src/gensig.c:311-317): made with the host's libm
+// so they are the very doubles the CPU reference produces on this machine.
+static double host_rng(long long* xp) {            // src/rand.h:79-85
+    const long long x = *xp;
+    const long long nx = 16807LL * (x % 127773LL) - 2836LL * (x / 127773LL);
+    *xp = nx;
+    return (double)(nx > 0 ? nx : nx + 2147483647LL) / 2147483647;
+}
+static double host_nrng(double m, double s, long long* xp) {   // src/rand.h:87-94
+    double u = 0.0, t = 0.0;
+    while (u == 0.0) u = host_rng(xp);
+    while (t == 0.0) t = 2.0 * 3.14159265 * host_rng(xp);
+    const double z = std::sqrt(-2.0 * std::log(u)) * std::cos(t);
+    return (z * s) + m;
+}
+
+static uint32_t canon(long long s) {
+    s %= (long long)LCG_M;
+    if (s < 0) s += LCG_M;
+    return (uint32_t)s;
+}
+
+static int ensure(sqg_ctx* c, void** p, size_t* cap, size_t need, size_t elem) {
+    if (need <= *cap) return SQG_OK;
+    size_t ncap = std::max(need + need / 4, *cap + *cap / 2);     // slack: batches of similar size never re-allocate
+    if (*p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); HIPCHK(c, hipFree(*p)); *p = nullptr; *cap = 0; }
+    HIPCHK(c, hipMalloc(p, ncap * elem));
+    *cap = ncap;
+    return SQG_OK;
+}
+
+static const char kStallRna[] = "AAAAAGAAAAAACCCCCCCCCCCCCCCCCC";                  // src/genread.c:87
+static const char kStallDna[] = "TTTTTTTTTTTTTTTTTTAATCAA";                       // src/genread.c:110
+static const char kAdaptorDna[] = "GGCGTCTGCTTGGGTGTTTAACCTTTTTTTTTTAATGTACTTCGTTCAGTTACGTATTGCT";  // src/genread.c:38
+static const char kAdaptorRna[] = "TGATGATGAGGGATAGACGATGGTTGTTTCTGTTGGTGCTGATATTGCTTTTTTTTTTTTTATGATGCAAGATACGCAC";  // src/genread.c:39
+static const int kPolyA = 158;                                                   // src/genread.c:37
+static const char kShortHack[] = "ACGTACGTACGTA";   // src/gensig.c:242-245: "ACGTACGTACGT" + its NUL (rank 0)
+
+// debugging aid: SQG_DEBUG_SYNC=1 synchronises after every launch and names the kernel that faulted
+static int dbg_sync(sqg_ctx* c, const char* what) {
+    static const bool on = getenv("SQG_DEBUG_SYNC") != nullptr;
+    if (!on) return SQG_OK;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream2);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { c->err = std::string(what) + ": " + hipGetErrorString(e); fprintf(stderr, "[sqg] %s\n", c->err.c_str()); return SQG_EDEVICE; }
+    fprintf(stderr, "[sqg] %s ok\n", what);
+    return SQG_OK;
+}
+
+// phase 0: the whole run; 1: up to the per-stream sample counts of a split batch (sqg_batch_run_begin); 2: the rest

@@ -1,0 +1,164 @@
+// h_results.h -- waiting for a batch, fetching results, svb-zd compression, timing, pinned host memory, the store probe
+// Host side of include/sqg.h; included by sqg_hip.hip (one translation unit with the kernels), in the order listed there.
+#pragma once
+
+extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
+    if (!c || !b || !b->ran) return SQG_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipEventSynchronize(b->ev[4]));              // this batch only: later batches keep running
+    sqg_ctx::Slot& S = c->slot[b->slot];
+    if (!b->waited) {
+        b->n_samples = b->h_sigoff[b->n];
+        for (int i = 0; i <= b->n; i++) b->sig_off[(size_t)i] = b->h_sigoff[i];
+        unsigned int e = 0;
+        HIPCHK(c, hipMemcpy(&e, c->d_err, sizeof e, hipMemcpyDeviceToHost));
+#if defined(SQG_ABL_EV_NOSTORE) || defined(SQG_ABL_NOSTORE)       /* timing-only ablation builds: results are garbage by design */
+        if (e) { HIPCHK(c, hipMemset(c->d_err, 0, sizeof e)); e = 0; }
+#endif
+        if (e) {
+            HIPCHK(c, hipMemset(c->d_err, 0, sizeof e));
+            c->err = "device reported: " + std::string((e & 1) ? "dwell>65535 " : "") + ((e & 2) ? "read>=UINT32_MAX samples " : "") + ((e & 4) ? "internal length mismatch " : "") + ((e & 8) ? "FP64 fix-up list overflow" : "");
+            return (e & 12) ? SQG_EDEVICE : SQG_EOVERFLOW;
+        }
+        float d = 0, s = 0, t = 0, ee = 0;
+        if (b->dwell_timed) HIPCHK(c, hipEventElapsedTime(&d, b->ev[0], b->ev[1]));
+        HIPCHK(c, hipEventElapsedTime(&ee, b->ev[b->dwell_timed ? 2 : 0], b->ev[3]));
+        HIPCHK(c, hipEventElapsedTime(&s, b->ev[3], b->ev[4]));
+        HIPCHK(c, hipEventElapsedTime(&t, b->ev[0], b->ev[4]));
+        c->timing.events_ms = ee;
+        c->timing.lean_ms = 0.f;
+        if (b->lean_timed) HIPCHK(c, hipEventElapsedTime(&c->timing.lean_ms, b->ev[5], b->ev[6]));
+        unsigned int nfix = 0;
+        if (c->cfg.mode == SQG_MODE_CERTIFIED) {
+            unsigned int cnt[4] = {0, 0, 0, 0};
+            HIPCHK(c, hipMemcpy(cnt, S.d_fix_count, sizeof cnt, hipMemcpyDeviceToHost));
+            nfix = cnt[0];                                  // global list ...
+            if (c->use_kmer_streams && b->n_stiles > 0) {   // ... plus the per-tile slots of the lean kernel
+                std::vector<unsigned char> tn((size_t)b->n_stiles);
+                HIPCHK(c, hipMemcpy(tn.data(), S.d_tfix_n, tn.size(), hipMemcpyDeviceToHost));
+                for (unsigned char v : tn) nfix += v;
+            }
+        }
+        c->timing.dwell_ms = d; c->timing.samples_ms = s; c->timing.total_ms = t; c->timing.fallback_samples = nfix;
+        b->waited = true;
+    }
+    if (res) {
+        res->n_reads = b->n; res->n_events = b->n_events; res->n_samples = b->n_samples; res->n_bases = b->n_bases;
+        res->sig_off = (const int64_t*)b->sig_off.data(); res->ev_off = (const int64_t*)b->ev_off.data();
+        res->offset = b->offset.data(); res->median_before = b->median.data();
+        res->d_signal = S.d_sig; res->d_dwell = c->use_dwell_stream ? S.d_dwell : nullptr;
+    }
+    return SQG_OK;
+}
+
+extern "C" int sqg_fetch_signal(sqg_ctx_t* c, sqg_batch_t* b, int16_t* dst) {
+    if (!c || !b || !b->ran || !dst) return SQG_EINVAL;
+    if (b->seq + 2 < c->next_run) return SQG_ESEQUENCE;       // slab already reused (two batches later)
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipEventSynchronize(b->ev[4]));
+    if (!b->waited) b->n_samples = b->h_sigoff[b->n];
+    if (b->n_samples) HIPCHK(c, hipMemcpy(dst, c->slot[b->slot].d_sig, (size_t)b->n_samples * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return SQG_OK;
+}
+
+extern "C" int sqg_fetch_dwell(sqg_ctx_t* c, sqg_batch_t* b, int32_t* dst) {
+    if (!c || !b || !b->ran || !dst) return SQG_EINVAL;
+    if (b->seq + 2 < c->next_run) return SQG_ESEQUENCE;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipEventSynchronize(b->ev[4]));
+    if (!c->use_dwell_stream) {
+        for (long long i = 0; i < b->n_events; i++) dst[i] = (int)c->cfg.profile.dwell_mean;
+        return SQG_OK;
+    }
+    std::vector<uint16_t> tmp((size_t)b->n_events);
+    if (b->n_events) HIPCHK(c, hipMemcpy(tmp.data(), c->slot[b->slot].d_dwell, tmp.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < tmp.size(); i++) dst[i] = tmp[i];
+    return SQG_OK;
+}
+
+extern "C" int sqg_get_timing(sqg_ctx_t* c, sqg_timing_t* t) {
+    if (!c || !t) return SQG_EINVAL;
+    *t = c->timing;
+    return SQG_OK;
+}
+
+extern "C" int sqg_submit(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t* seq_off,
+                          const int32_t* worker, sqg_batch_t** out, sqg_result_t* res) {
+    if (!out) return SQG_EINVAL;
+    int rc = sqg_batch_stage(c, n, seqs, seq_off, worker, out);
+    if (rc) return rc;
+    if ((rc = sqg_batch_run(c, *out)) || (rc = sqg_batch_wait(c, *out, res))) { sqg_batch_free(c, *out); *out = nullptr; }
+    return rc;
+}
+
+extern "C" int sqg_batch_compress(sqg_ctx_t* c, sqg_batch_t* b, sqg_svb_t* out) {
+    if (!c || !b || !b->ran || !out) return SQG_EINVAL;
+    if (b->seq + 2 < c->next_run) return SQG_ESEQUENCE;       // the signals of an older batch are gone
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipEventSynchronize(b->ev[4]));
+    sqg_ctx::Slot& S = c->slot[b->slot];
+    int rc;
+    const int n = b->n;
+    if (!b->h_svboff) {
+        HIPCHK(c, hipHostMalloc(&b->h_svboff, ((size_t)n + 1) * sizeof(long long), hipHostMallocMapped));
+    }
+    long long* h_dev = nullptr;
+    HIPCHK(c, hipHostGetDevicePointer((void**)&h_dev, b->h_svboff, 0));
+    b->h_svboff[0] = 0;
+    if (n > 0) {
+        if ((rc = ensure(c, (void**)&c->d_svb_size, &c->svb_size_cap, (size_t)n + 64, sizeof(long long)))) return rc;
+        if ((rc = ensure(c, (void**)&c->d_svb_off, &c->svb_off_cap, (size_t)n + 64, sizeof(long long)))) return rc;
+        hipLaunchKernelGGL(k_svb_size, dim3((unsigned)n), dim3(256), 0, c->stream2, S.d_sig, S.d_sigoff, n, c->d_svb_size);
+        hipLaunchKernelGGL(k_svb_scan, dim3(1), dim3(1024), 0, c->stream2, c->d_svb_size, n, c->d_svb_off, h_dev);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream2));           // the total sizes the output buffer
+        const long long total = b->h_svboff[n];
+        if ((rc = ensure(c, (void**)&c->d_svb, &c->svb_cap, (size_t)total + 64, 1))) return rc;
+        hipLaunchKernelGGL(k_svb_encode, dim3((unsigned)n), dim3(256), 0, c->stream2, S.d_sig, S.d_sigoff, n, c->d_svb_off, c->d_svb);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream2));
+    }
+    b->n_svb = b->h_svboff[n];
+    b->compress_seq = ++c->compress_seq;
+    out->n_bytes = b->n_svb;
+    out->svb_off = (const int64_t*)b->h_svboff;
+    out->d_svb = c->d_svb;
+    return SQG_OK;
+}
+
+extern "C" int sqg_fetch_svb(sqg_ctx_t* c, sqg_batch_t* b, uint8_t* dst) {
+    if (!c || !b || !dst || b->n_svb < 0) return SQG_EINVAL;
+    if (b->compress_seq != c->compress_seq) return SQG_ESEQUENCE;      // a later sqg_batch_compress reused the buffer
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (b->n_svb > 0) HIPCHK(c, hipMemcpy(dst, c->d_svb, (size_t)b->n_svb, hipMemcpyDeviceToHost));
+    return SQG_OK;
+}
+
+extern "C" void* sqg_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void sqg_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+extern "C" int sqg_probe_store_bandwidth(sqg_ctx_t* c, size_t bytes, int iters, float* ms_per_pass) {
+    if (!c || !ms_per_pass || iters < 1 || bytes < 4096) return SQG_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    void* buf = nullptr;
+    HIPCHK(c, hipMalloc(&buf, bytes));
+    const size_t n16 = bytes / 16;
+    hipEvent_t a, z;
+    HIPCHK(c, hipEventCreate(&a)); HIPCHK(c, hipEventCreate(&z));
+    hipLaunchKernelGGL(k_store_probe, dim3(256 * 8), dim3(256), 0, c->stream, (uint4*)buf, n16, 1u);   // warm-up
+    HIPCHK(c, hipEventRecord(a, c->stream));
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_store_probe, dim3(256 * 8), dim3(256), 0, c->stream, (uint4*)buf, n16, (uint32_t)i);
+    HIPCHK(c, hipEventRecord(z, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(c, hipEventElapsedTime(&ms, a, z));
+    *ms_per_pass = ms / iters;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(z); (void)hipFree(buf);
+    return SQG_OK;
+}
+

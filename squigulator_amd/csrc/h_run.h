@@ -1,0 +1,240 @@
+// h_run.h -- the launch sequence of a batch (sqg_batch_run, and its two halves for range sharding)
+// Host side of include/sqg.h; included by sqg_hip.hip (one translation unit with the kernels), in the order listed there.
+#pragma once
+
+// (sqg_batch_run_end), `before` / `after` being what the other ranges of the batch draw from each stream
+static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* before, const uint32_t* after) {
+    if (!c || !b) return SQG_EINVAL;
+    if (phase == 2 ? (!b->begun || b->ran) : (b->ran || b->begun || b->seq != c->next_run)) return SQG_ESEQUENCE;
+    if ((before == nullptr) != (after == nullptr)) return SQG_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const sqg_profile_t& p = c->cfg.profile;
+    const int n = b->n;
+    const bool certified = c->cfg.mode == SQG_MODE_CERTIFIED;
+    int rc;
+    b->slot = (int)(b->seq & 1);
+    sqg_ctx::Slot& S = c->slot[b->slot];
+    sqg_ctx::Slot& other = c->slot[b->slot ^ 1];
+    if (phase != 2) {
+        // this slot's buffers were last used by the sample kernels of batch seq-2 (stream2)
+        HIPCHK(c, hipStreamWaitEvent(c->stream, S.done, 0));
+        auto grow = [&](sqg_ctx::Slot& Z) -> int { return grow_slot(c, Z, b, /*with_output=*/false); };
+        b->other_fresh = other.reads_cap == 0 && n > 0;
+        if ((rc = grow(S))) return rc;
+        if (b->other_fresh && (rc = grow(other))) return rc;
+    }
+    const bool other_fresh = b->other_fresh;
+
+    // Dwell draws are made inside k_events (SQG_SEPARATE_DWELL=1 keeps the stand-alone k_dwell for A/B runs).
+    static const bool separate_dwell = getenv("SQG_SEPARATE_DWELL") != nullptr;
+    const bool inline_dwell = c->use_dwell_stream && !separate_dwell;
+    const bool direct = c->k <= 6;
+    if (phase != 2 && !direct && c->use_kmer_streams && n > 0) {
+        // the rows count samples in 32 bits; only the count mod (M-1)/2 matters (range mode: the other ranges' counts are not
+        // known here, so the rows are reduced before every batch)
+        const double bnd = (double)b->max_wchain_ev * c->dwell_hi;
+        if (c->range_mode || c->row_bound + bnd >= 4294967295.0) {
+            const size_t nrow = (size_t)c->nw * (size_t)c->num_kmer;
+            hipLaunchKernelGGL(k_rows_normalize, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, c->stream, c->d_rows, nrow);
+            HIPCHK(c, hipGetLastError());
+            c->row_bound = (double)LCG_ORD2;
+        }
+        c->row_bound += bnd;
+    }
+    if (phase != 2 && b->split && (rc = ensure(c, (void**)&c->d_link_rows, &c->link_rows_cap, (size_t)b->n_chains * (size_t)c->num_kmer, sizeof(uint32_t)))) return rc;
+    const size_t n_rows = (size_t)c->nw * (size_t)c->num_kmer;
+    if (phase == 1 && (rc = ensure(c, (void**)&c->d_xcounts, &c->xcounts_cap, n_rows, sizeof(uint32_t)))) return rc;
+    SigParams P;
+    memset(&P, 0, sizeof P);
+    P.link_rows = b->split ? c->d_link_rows : nullptr;
+    P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
+    P.dwell = c->use_dwell_stream ? S.d_dwell : nullptr; P.dwell_out = S.d_dwell; P.seglen_out = S.d_seglen;
+    P.dmean = p.dwell_mean; P.dstd = p.dwell_std;
+    P.seglen = S.d_seglen; P.sig_off = S.d_sigoff; P.model = c->d_model; P.pw = c->d_pow; P.rows = c->d_rows;
+    P.seed_base = canon((long long)c->cfg.seed + (long long)c->wlo * ((long long)(1u << (2 * c->k)) + 10)); P.seed_step = canon((long long)(1u << (2 * c->k)) + 10);
+    P.err = c->d_err; P.dig = p.digitisation; P.range = p.range; P.kd = p.digitisation / p.range;
+    P.chain_order = b->d_chain_order; P.delta_x = c->delta_x; P.thr_all = c->thr_all;
+    P.k = c->k; P.num_kmer = c->num_kmer; P.const_sps = (int)p.dwell_mean;
+    P.use_streams = c->use_kmer_streams ? 1 : 0;
+    P.rna = (c->cfg.flags & SQG_RNA) ? 1 : 0;
+    P.evrec = S.d_evrec; P.tile_so = S.d_tile_so; P.tile_read = b->d_tile_read; P.stile_read = b->d_stile_read;
+    constexpr int NT = SQG_EVENT_THREADS;
+    auto launch_events = [&](int dw, bool hist) {
+        const dim3 g((unsigned)b->n_chains), t(NT);
+#define EVL(D, W, H) hipLaunchKernelGGL((k_events<NT, D, W, SQG_EVENT_EPT, H>), g, t, 0, c->stream, P)
+#define EVD(D, H) do { if (dw == 0) EVL(D, 0, H); else if (dw == 1) EVL(D, 1, H); else EVL(D, 2, H); } while (0)
+        if (direct) { if (hist) EVD(true, true); else EVD(true, false); }
+        else { if (hist) EVD(false, true); else EVD(false, false); }
+#undef EVD
+#undef EVL
+    };
+
+    if (phase != 2) {
+        HIPCHK(c, hipEventRecord(b->ev[0], c->stream));
+        if (n > 0) {
+            if (c->use_dwell_stream && !inline_dwell) {
+                HIPCHK(c, hipMemsetAsync(S.d_seglen, 0, (size_t)2 * n * sizeof(unsigned long long), c->stream));
+                const long long nblk = (b->n_events + DW_EPB - 1) / DW_EPB;
+                if (nblk > 0) {
+                    if (certified)
+                        hipLaunchKernelGGL(k_dwell<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, b->d_reads, n, b->d_blk_read,
+                                           b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, c->delta_x, S.d_dwell, S.d_seglen, c->d_err);
+                    else
+                        hipLaunchKernelGGL(k_dwell<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, b->d_reads, n, b->d_blk_read,
+                                           b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, 0.f, S.d_dwell, S.d_seglen, c->d_err);
+                }
+                if ((rc = dbg_sync(c, "k_dwell"))) return rc;
+            } else if (!c->use_dwell_stream) {
+                HIPCHK(c, hipMemcpyAsync(S.d_seglen, b->seglen_host.data(), (size_t)2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+            }
+        }
+        b->dwell_timed = c->use_dwell_stream && !inline_dwell;        // stand-alone k_dwell (A/B runs): two more timing events
+        if (b->dwell_timed) { HIPCHK(c, hipEventRecord(b->ev[1], c->stream)); HIPCHK(c, hipEventRecord(b->ev[2], c->stream)); }
+    }
+    if (n > 0 && b->n_chains > 0) {
+        const int dw = inline_dwell ? (certified && c->dwell_hi < 1.0e6 ? 1 : 2) : 0;
+        const dim3 pg((unsigned)((c->num_kmer + 63) / 64), (unsigned)b->n_wchains);
+        if (b->split && phase != 2) {
+            // links: samples per (link, k-mer) with the dwell draws ...
+            if (!direct) HIPCHK(c, hipMemsetAsync(c->d_link_rows, 0, (size_t)b->n_chains * (size_t)c->num_kmer * sizeof(uint32_t), c->stream));
+            launch_events(dw, true);
+            HIPCHK(c, hipGetLastError());
+            if (phase == 1) {                                     // ... summed per worker for the exchange
+                HIPCHK(c, hipMemsetAsync(c->d_xcounts, 0, n_rows * sizeof(uint32_t), c->stream));
+                hipLaunchKernelGGL(k_link_totals, pg, dim3(1024), 0, c->stream, P, b->d_wlink_off, b->d_wlink_worker, c->d_xcounts);
+                HIPCHK(c, hipGetLastError());
+            }
+        }
+        if (b->split && phase != 1) {
+            // ... then each link's view of its worker's streams
+            if (direct) hipLaunchKernelGGL(k_link_prefix<true>, pg, dim3(1024), 0, c->stream, P, b->d_wlink_off, b->d_wlink_worker, before);
+            else hipLaunchKernelGGL(k_link_prefix<false>, pg, dim3(1024), 0, c->stream, P, b->d_wlink_off, b->d_wlink_worker, before);
+            if (before) {                                         // every worker's row moves past the whole batch, all ranges
+                const dim3 ag((unsigned)((n_rows + 255) / 256));
+                if (direct) hipLaunchKernelGGL(k_rows_advance<true>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
+                else hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
+            }
+            HIPCHK(c, hipGetLastError());
+            if ((rc = dbg_sync(c, "k_events<hist>/k_link_prefix"))) return rc;
+            launch_events(0, false);                              // the dwell is in memory now
+        } else if (!b->split && phase != 1) launch_events(dw, false);
+        HIPCHK(c, hipGetLastError());
+        if ((rc = dbg_sync(c, "k_events"))) return rc;
+    } else if (phase == 1 && c->d_xcounts) {
+        HIPCHK(c, hipMemsetAsync(c->d_xcounts, 0, n_rows * sizeof(uint32_t), c->stream));
+    }
+    if (phase == 1) { b->begun = true; return SQG_OK; }
+    if (before && !(n > 0 && b->n_chains > 0 && b->split) && c->use_kmer_streams) {
+        // no local reads in this batch: the rows still move past what the other ranges draw
+        const dim3 ag((unsigned)((n_rows + 255) / 256));
+        if (direct) hipLaunchKernelGGL(k_rows_advance<true>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
+        else hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
+        HIPCHK(c, hipGetLastError());
+    }
+    HIPCHK(c, hipEventRecord(b->ev[3], c->stream));
+    if (n > 0) {
+        // the scan also writes the offsets through the batch's pinned host mapping (no copy between kernels)
+        // (k_items, when it runs, does that part with more parallelism)
+        const bool items_run = certified && c->use_kmer_streams && b->n_chains > 0 && c->dwell_hi * (double)b->n_events <= 4.0e10;
+        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, S.d_seglen, n, S.d_sigoff, items_run ? nullptr : b->h_sigoff_dev, c->d_err, S.d_fix_count);
+        HIPCHK(c, hipGetLastError());
+        if ((rc = dbg_sync(c, "k_scan"))) return rc;
+    } else HIPCHK(c, hipMemsetAsync(S.d_fix_count, 0, 4 * sizeof(unsigned int), c->stream));
+    // Output size is data-dependent.  A hard bound exists (|z| <= sqrt(2 ln(2^31-1)) = 6.5546 for any
+    // draw), so the slab is sized by it and the launches continue without a host round trip; only
+    // if that bound is unreasonable (huge dwell spread) is the scan read back first.
+    if (n == 0) b->h_sigoff[0] = 0;
+    size_t need_samples;
+    {
+        const double hi = c->dwell_hi;
+        const double bound = hi * (double)b->n_events;
+        if (bound <= 4.0e10) need_samples = (size_t)bound;
+        else {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            need_samples = (size_t)b->h_sigoff[n];
+        }
+    }
+    for (int z = 0; z < (other_fresh ? 2 : 1); z++) {
+        sqg_ctx::Slot& Z = z ? other : S;
+        if ((rc = ensure(c, (void**)&Z.d_sig, &Z.sig_cap, need_samples + 64, sizeof(int16_t)))) return rc;
+        if (certified && c->use_kmer_streams) {
+            if ((rc = ensure(c, (void**)&Z.d_fix, &Z.fix_cap, (c->force_fix ? need_samples : need_samples / 256) + 65536, sizeof(FixEntry)))) return rc;
+        }
+    }
+
+    if (n > 0 && b->n_chains > 0) {
+        P.sig = S.d_sig; P.fix = S.d_fix; P.fix_count = S.d_fix_count;
+        P.fix_cap = (unsigned int)std::min<size_t>(S.fix_cap, 0xffffffffu);
+        const bool rna_prefix = (c->cfg.flags & SQG_RNA) && (c->cfg.flags & SQG_PREFIX);
+        P.shift_len = rna_prefix ? (int)strlen(kAdaptorRna) * (int)p.dwell_mean : 0;
+        {   // int16_t off = 30*dig/range (src/genread.c:82): double -> int16 as the CPU does it
+            const double v = 30 * p.digitisation / p.range;
+            int32_t t = (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000u;
+            P.shift = (int)(int16_t)(uint16_t)((uint32_t)t & 0xffffu);
+        }
+        P.slow_tiles = nullptr; P.slow_count = S.d_fix_count + 1; P.tfix = S.d_tfix; P.tfix_n = S.d_tfix_n; P.items = S.d_items; P.lean_epl = c->lean_epl;
+        const int n_tiles = (int)b->n_tiles;
+        const unsigned sgrid = (unsigned)((n_tiles + 3) / 4);
+        if (certified && c->use_kmer_streams) {
+            P.slow_tiles = S.d_slow;
+            const int n_stiles = (int)b->n_stiles;
+            unsigned lgrid = (unsigned)((n_stiles + 3) / 4);
+            static const int lean_grid_cap = getenv("SQG_LEAN_GRID") ? atoi(getenv("SQG_LEAN_GRID")) : 0;   // A/B knob
+            if (lean_grid_cap > 0) lgrid = std::min(lgrid, (unsigned)lean_grid_cap);
+            hipLaunchKernelGGL(k_items, dim3((unsigned)((std::max(n_stiles, n + 1) + 255) / 256)), dim3(256), 0, c->stream, P, n_stiles, n, b->h_sigoff_dev);
+            HIPCHK(c, hipEventRecord(b->ev[7], c->stream));              // event side done: the sample kernels may start ...
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, b->ev[7], 0));      // ... on their own stream, next to the next batch's k_events
+            HIPCHK(c, hipEventRecord(b->ev[5], c->stream2));
+#define LEANL(R, E) hipLaunchKernelGGL((k_samples_lean<R, E>), dim3(lgrid), dim3(256), 0, c->stream2, P, n_stiles)
+            if (P.rna) { if (c->lean_epl == 4) LEANL(true, 4); else if (c->lean_epl == 2) LEANL(true, 2); else LEANL(true, 1); }
+            else { if (c->lean_epl == 4) LEANL(false, 4); else if (c->lean_epl == 2) LEANL(false, 2); else LEANL(false, 1); }
+#undef LEANL
+            HIPCHK(c, hipEventRecord(b->ev[6], c->stream2));
+            b->lean_timed = true;
+            if ((rc = dbg_sync(c, "k_samples_lean"))) return rc;
+            hipLaunchKernelGGL((k_samples<1, true>), dim3(std::min(sgrid, 4096u)), dim3(256), 0, c->stream2, P, n_tiles);
+            if ((rc = dbg_sync(c, "k_samples<generic>"))) return rc;
+            hipLaunchKernelGGL(k_fixup, dim3(512), dim3(256), 0, c->stream2, P);
+            hipLaunchKernelGGL(k_fixup_tiles, dim3((unsigned)((n_stiles + 255) / 256)), dim3(256), 0, c->stream2, P, n_stiles);
+            if ((rc = dbg_sync(c, "k_fixup"))) return rc;
+        } else {
+            HIPCHK(c, hipEventRecord(b->ev[7], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, b->ev[7], 0));
+            if (certified) hipLaunchKernelGGL((k_samples<1, true>), dim3(sgrid), dim3(256), 0, c->stream2, P, n_tiles);
+            else hipLaunchKernelGGL((k_samples<0, true>), dim3(sgrid), dim3(256), 0, c->stream2, P, n_tiles);
+        }
+        HIPCHK(c, hipGetLastError());
+    } else {
+        HIPCHK(c, hipEventRecord(b->ev[7], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, b->ev[7], 0));
+    }
+    HIPCHK(c, hipEventRecord(b->ev[4], c->stream2));
+    HIPCHK(c, hipEventRecord(S.done, c->stream2));
+    b->ran = true;
+    c->next_run++;
+    return SQG_OK;
+}
+
+extern "C" int sqg_batch_run(sqg_ctx_t* c, sqg_batch_t* b) { return run_impl(c, b, 0, nullptr, nullptr); }
+
+extern "C" int sqg_batch_run_begin(sqg_ctx_t* c, sqg_batch_t* b, const uint32_t** d_counts) {
+    if (!c || !b || !d_counts) return SQG_EINVAL;
+    if (!c->range_mode) { c->err = "sqg_batch_run_begin needs sqg_set_range_mode(ctx, 1) before the batch is staged"; return SQG_EINVAL; }
+    if (!c->use_kmer_streams) { c->err = "no k-mer streams in --ideal / --ideal-amp: nothing to exchange, use sqg_batch_run"; return SQG_EINVAL; }
+    const int rc = run_impl(c, b, 1, nullptr, nullptr);
+    if (rc != SQG_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));                  // the counts are complete on return: the exchange runs on the caller's stream
+    *d_counts = c->d_xcounts;
+    return SQG_OK;
+}
+
+extern "C" int sqg_batch_run_end(sqg_ctx_t* c, sqg_batch_t* b, const uint32_t* d_before, const uint32_t* d_after) {
+    return run_impl(c, b, 2, d_before, d_after);
+}
+
+extern "C" int sqg_set_range_mode(sqg_ctx_t* c, int on) {
+    if (!c) return SQG_EINVAL;
+    if (c->next_stage != c->next_run) return SQG_ESEQUENCE;       // staged batches pending
+    c->range_mode = on != 0;
+    return SQG_OK;
+}

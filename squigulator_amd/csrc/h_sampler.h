@@ -1,0 +1,214 @@
+// h_sampler.h -- resident genome and the device-side read sampler (sqg_genome_load, sqg_batch_sample*, sqg_skip_reads, sqg_fetch_reads)
+// Host side of include/sqg.h; included by sqg_hip.hip (one translation unit with the kernels), in the order listed there.
+#pragma once
+
+// ---- resident genome + device-side read sampler ("next" row of SURVEY.md section 8f) ----
+extern "C" int sqg_genome_load(sqg_ctx_t* c, const sqg_genome_t* g) {
+    if (!c || !g || g->n_contigs <= 0 || !g->seqs || !g->contig_off || g->rlen <= 0) return SQG_EINVAL;
+    if (g->n_trans < 0 || (g->n_trans > 0 && (!g->trans_csum || !g->trans_idx))) return SQG_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const int nc = g->n_contigs;
+    const long long total = g->contig_off[nc] - g->contig_off[0];
+    std::vector<long long> off((size_t)nc + 1), cum((size_t)nc);
+    for (int i = 0; i <= nc; i++) off[(size_t)i] = g->contig_off[i] - g->contig_off[0];
+    long long run = 0;
+    for (int i = 0; i < nc; i++) {
+        const long long len = off[(size_t)i + 1] - off[(size_t)i];
+        if (len < 0 || len > 2000000000LL) return SQG_EINVAL;
+        run += len; cum[(size_t)i] = run;
+    }
+    (void)hipFree(c->d_genome); (void)hipFree(c->d_contig_off); (void)hipFree(c->d_cum);
+    (void)hipFree(c->d_trans_csum); (void)hipFree(c->d_trans_idx); (void)hipFree(c->d_samp);
+    c->d_genome = nullptr; c->d_contig_off = nullptr; c->d_cum = nullptr; c->d_trans_csum = nullptr; c->d_trans_idx = nullptr; c->d_samp = nullptr;
+    HIPCHK(c, hipMalloc(&c->d_genome, (size_t)total + 16));
+    HIPCHK(c, hipMemcpy(c->d_genome, g->seqs + g->contig_off[0], (size_t)total, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(c->d_genome + total, 0, 16));
+    HIPCHK(c, hipMalloc(&c->d_contig_off, off.size() * sizeof(long long)));
+    HIPCHK(c, hipMemcpy(c->d_contig_off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_cum, cum.size() * sizeof(long long)));
+    HIPCHK(c, hipMemcpy(c->d_cum, cum.data(), cum.size() * sizeof(long long), hipMemcpyHostToDevice));
+    if (g->n_trans > 0) {
+        HIPCHK(c, hipMalloc(&c->d_trans_csum, (size_t)g->n_trans * sizeof(float)));
+        HIPCHK(c, hipMemcpy(c->d_trans_csum, g->trans_csum, (size_t)g->n_trans * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc(&c->d_trans_idx, (size_t)g->n_trans * sizeof(int)));
+        HIPCHK(c, hipMemcpy(c->d_trans_idx, g->trans_idx, (size_t)g->n_trans * sizeof(int), hipMemcpyHostToDevice));
+    }
+    // the workers' sampler streams: ref_pos = s, rand_strand = s+1, rand_rlen = s+3 (src/sim.c:238-247)
+    HIPCHK(c, hipMalloc(&c->d_samp, (size_t)c->nw * 3 * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_init_sampler, dim3((unsigned)((c->nw + 255) / 256)), dim3(256), 0, c->stage_stream, c->d_samp,
+                       (long long)c->cfg.seed, c->wlo, c->nw, (int)(1u << (2 * c->k)));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stage_stream));
+    GenomeParams& G = c->genome;
+    G.seq = c->d_genome; G.contig_off = c->d_contig_off; G.cum = c->d_cum;
+    G.trans_csum = c->d_trans_csum; G.trans_idx = c->d_trans_idx;
+    G.sum = total; G.grng_b = (double)(g->rlen / 2); G.n_contigs = nc; G.n_trans = g->n_trans; G.rlen = g->rlen;
+    G.flags = (int)g->mode;
+    c->genome_loaded = true;
+    return SQG_OK;
+}
+
+// events of a read of `len` bases once the prefix is attached (src/gensig.c:242-245, src/genread.c:87-123)
+static long long read_events(const sqg_ctx* c, long long len) {
+    const bool rna = c->cfg.flags & SQG_RNA, prefix = c->cfg.flags & SQG_PREFIX;
+    long long len0 = len;
+    if (prefix) len0 += rna ? (kPolyA + (long long)strlen(kAdaptorRna)) : ((long long)strlen(kStallDna) + (long long)strlen(kAdaptorDna));
+    const long long ne0 = len0 < c->k ? 5 : len0 - c->k + 1;
+    const long long ne1 = (prefix && rna) ? (long long)strlen(kStallRna) - c->k + 1 : 0;
+    return ne0 + ne1;
+}
+
+// a read generated elsewhere (range sharding): local worker w's scalar streams move past it -- one offset and one
+// median_before draw (src/gensig.c:315-316), two time-stream draws per event (src/gensig.c:255)
+static void skip_read(sqg_ctx* c, int w, long long n_events) {
+    const sqg_profile_t& p = c->cfg.profile;
+    if (!(c->cfg.flags & SQG_IDEAL)) {
+        (void)host_nrng(p.offset_mean, p.offset_std, &c->off_x[(size_t)w]);
+        (void)host_nrng(p.median_before_mean, p.median_before_std, &c->med_x[(size_t)w]);
+    }
+    if (c->use_dwell_stream)
+        c->time_c[(size_t)w] = lcg_mul(c->time_c[(size_t)w], lcg_pow(lcg_mul(LCG_A, LCG_A), (unsigned long long)n_events));
+}
+
+extern "C" int sqg_skip_reads(sqg_ctx_t* c, int32_t n, const int64_t* seq_len, const int32_t* worker) {
+    if (!c || n < 0 || (n > 0 && (!seq_len || !worker))) return SQG_EINVAL;
+    for (int i = 0; i < n; i++)
+        if (worker[i] < c->wlo || worker[i] >= c->whi || seq_len[i] < 0) { c->err = "sqg_skip_reads: worker not owned by this context, or negative length"; return SQG_EINVAL; }
+    for (int i = 0; i < n; i++) skip_read(c, worker[i] - c->wlo, read_events(c, seq_len[i]));
+    return SQG_OK;
+}
+
+static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t lo, int32_t hi, sqg_batch_t** out, sqg_sample_t* info);
+
+extern "C" int sqg_batch_sample(sqg_ctx_t* c, int32_t n, const int32_t* worker, sqg_batch_t** out, sqg_sample_t* info) {
+    return sample_impl(c, n, worker, 0, n, out, info);
+}
+
+extern "C" int sqg_batch_sample_range(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t lo, int32_t hi, sqg_batch_t** out, sqg_sample_t* info) {
+    if (lo < 0 || hi < lo || hi > n) return SQG_EINVAL;
+    return sample_impl(c, n, worker, lo, hi, out, info);
+}
+
+// gen_read for all n reads of the batch (the sampler streams are consumed read by read); reads [lo, hi) are staged, the
+// workers' scalar streams skip over the others
+static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t lo, int32_t hi, sqg_batch_t** out, sqg_sample_t* info) {
+    if (!c || !out || n < 0) return SQG_EINVAL;
+    if (!c->genome_loaded) { c->err = "sqg_genome_load has not been called"; return SQG_EINVAL; }
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    // worker chains in batch order (a worker's reads are sampled in index order, like its signal streams)
+    std::vector<int> wk((size_t)n), count((size_t)c->nw, 0);
+    for (int i = 0; i < n; i++) {
+        const int w = worker ? worker[i] : sqg_worker_of(i, n, c->T);
+        if (w < c->wlo || w >= c->whi) { c->err = "read assigned to a worker this context does not own"; return SQG_EINVAL; }
+        wk[(size_t)i] = w - c->wlo; count[(size_t)wk[(size_t)i]]++;
+    }
+    std::vector<int> chain_of((size_t)c->nw, -1), chain_off(1, 0), chain_worker;
+    for (int w = 0; w < c->nw; w++) if (count[(size_t)w]) { chain_of[(size_t)w] = (int)chain_off.size() - 1; chain_off.push_back(chain_off.back() + count[(size_t)w]); chain_worker.push_back(w); }
+    const int n_chains = (int)chain_off.size() - 1;
+    std::vector<int> fill(chain_off.begin(), chain_off.end() - 1), chain_reads((size_t)n);
+    for (int i = 0; i < n; i++) chain_reads[(size_t)fill[(size_t)chain_of[(size_t)wk[(size_t)i]]]++] = i;
+
+    SampleRec* d_rec = nullptr;
+    int *d_co = nullptr, *d_cr = nullptr, *d_cw = nullptr;
+    SampleRec* d_try = nullptr; unsigned char* d_ok = nullptr; long long* d_ao = nullptr;
+    std::vector<SampleRec> rec((size_t)n);
+    int rc = SQG_OK;
+    auto cleanup = [&]() { (void)hipFree(d_rec); (void)hipFree(d_co); (void)hipFree(d_cr); (void)hipFree(d_cw); (void)hipFree(d_try); (void)hipFree(d_ok); (void)hipFree(d_ao); };
+#define CHKS(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE; } } while (0)
+    CHKS(hipMalloc(&d_rec, std::max<size_t>(1, (size_t)n) * sizeof(SampleRec)));
+    if (n > 0) {
+        CHKS(hipMalloc(&d_co, chain_off.size() * sizeof(int)));
+        CHKS(hipMalloc(&d_cr, chain_reads.size() * sizeof(int)));
+        CHKS(hipMalloc(&d_cw, chain_worker.size() * sizeof(int)));
+        CHKS(hipMemcpyAsync(d_co, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+        CHKS(hipMemcpyAsync(d_cr, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+        CHKS(hipMemcpyAsync(d_cw, chain_worker.data(), chain_worker.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+        int max_m = 0;
+        for (int q = 0; q < n_chains; q++) max_m = std::max(max_m, chain_off[(size_t)q + 1] - chain_off[(size_t)q]);
+        std::vector<long long> att_used;
+        if (max_m >= 16 && !getenv("SQG_SAMPLER_SERIAL")) {
+            // long chains: the attempts are evaluated concurrently, 25 % more than the acceptance rate seen so far asks for
+            std::vector<long long> att_off((size_t)n_chains + 1, 0);
+            long long max_a = 0;
+            for (int q = 0; q < n_chains; q++) {
+                const long long m = chain_off[(size_t)q + 1] - chain_off[(size_t)q];
+                const long long a = (long long)std::ceil((double)m * c->samp_ratio * 1.25) + 64;
+                att_off[(size_t)q + 1] = att_off[(size_t)q] + a; max_a = std::max(max_a, a);
+            }
+            const size_t na = (size_t)att_off.back();
+            CHKS(hipMalloc(&d_try, na * sizeof(SampleRec)));
+            CHKS(hipMalloc(&d_ok, na));
+            CHKS(hipMalloc(&d_ao, (att_off.size() + (size_t)n_chains) * sizeof(long long)));
+            long long* d_used = d_ao + att_off.size();
+            CHKS(hipMemcpyAsync(d_ao, att_off.data(), att_off.size() * sizeof(long long), hipMemcpyHostToDevice, c->stage_stream));
+            hipLaunchKernelGGL(k_sample_try, dim3((unsigned)((max_a + 3) / 4), (unsigned)n_chains), dim3(256), 0, c->stage_stream, c->genome, c->d_samp,
+                               d_cw, d_ao, d_try, d_ok);
+            hipLaunchKernelGGL(k_sample_pick, dim3((unsigned)n_chains), dim3(256), 0, c->stage_stream, c->genome, c->d_samp, d_co, d_cr, d_cw,
+                               d_ao, d_try, d_ok, d_rec, d_used, c->d_err);
+            CHKS(hipGetLastError());
+            att_used.resize((size_t)n_chains);
+            CHKS(hipMemcpyAsync(att_used.data(), d_used, att_used.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stage_stream));
+        } else {
+            hipLaunchKernelGGL(k_sample, dim3((unsigned)n_chains), dim3(64), 0, c->stage_stream, c->genome, c->d_samp, d_co, d_cr, d_cw,
+                               n_chains, d_rec, c->d_err);
+            CHKS(hipGetLastError());
+        }
+        CHKS(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(SampleRec), hipMemcpyDeviceToHost, c->stage_stream));
+        CHKS(hipStreamSynchronize(c->stage_stream));
+        if (!att_used.empty()) {
+            double r = 1.0;
+            for (int q = 0; q < n_chains; q++) {
+                const int m = chain_off[(size_t)q + 1] - chain_off[(size_t)q];
+                if (m >= 16) r = std::max(r, (double)att_used[(size_t)q] / (double)m);
+            }
+            c->samp_ratio = r;
+        }
+        unsigned int e = 0;
+        CHKS(hipMemcpy(&e, c->d_err, sizeof e, hipMemcpyDeviceToHost));
+        if (e & 16u) { CHKS(hipMemset(c->d_err, 0, sizeof e)); c->err = "read sampler: no acceptable read after 100000 attempts"; cleanup(); return SQG_EINVAL; }
+    }
+#undef CHKS
+    // lengths are known now: stage as sqg_batch_stage would, the base buffer being filled on the device
+    const int m = hi - lo;                                       // reads staged here
+    std::vector<int64_t> seq_off((size_t)m + 1, 0);
+    for (int i = 0; i < m; i++) seq_off[(size_t)i + 1] = seq_off[(size_t)i] + rec[(size_t)(lo + i)].rlen;
+    std::vector<int32_t> wk_glob;                                // global worker ids of the whole batch (the partition depends on n)
+    if (m != n) {
+        wk_glob.resize((size_t)n);
+        for (int i = 0; i < n; i++) wk_glob[(size_t)i] = wk[(size_t)i] + c->wlo;
+        for (int i = 0; i < lo; i++) skip_read(c, wk[(size_t)i], read_events(c, rec[(size_t)i].rlen));
+    }
+    rc = stage_common(c, m, nullptr, seq_off.data(), m != n ? wk_glob.data() + lo : worker, d_rec + lo, out);
+    if (rc == SQG_OK && m != n)
+        for (int i = hi; i < n; i++) skip_read(c, wk[(size_t)i], read_events(c, rec[(size_t)i].rlen));
+    cleanup();
+    if (rc) return rc;
+    sqg_batch* b = *out;
+    const bool rna = c->cfg.flags & SQG_RNA, prefix = c->cfg.flags & SQG_PREFIX;
+    const long long read_at = (prefix && !rna) ? (long long)(strlen(kStallDna) + strlen(kAdaptorDna)) : 0;
+    rec.erase(rec.begin(), rec.begin() + lo); rec.resize((size_t)m);
+    n = m;
+    b->s_ref_idx.resize((size_t)n); b->s_ref_len.resize((size_t)n); b->s_ref_pos.resize((size_t)n); b->s_rlen.resize((size_t)n);
+    b->s_strand.resize((size_t)n + 1); b->s_seq_off.assign(seq_off.begin(), seq_off.end()); b->s_read_at.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+        const SampleRec& q = rec[(size_t)i];
+        b->s_ref_idx[(size_t)i] = q.ref_idx; b->s_ref_len[(size_t)i] = q.ref_len; b->s_ref_pos[(size_t)i] = q.ref_pos;
+        b->s_rlen[(size_t)i] = q.rlen; b->s_strand[(size_t)i] = (char)q.strand; b->s_read_at[(size_t)i] = read_at;
+    }
+    if (info) {
+        info->ref_idx = b->s_ref_idx.data(); info->ref_len = b->s_ref_len.data(); info->ref_pos = b->s_ref_pos.data();
+        info->rlen = b->s_rlen.data(); info->strand = b->s_strand.data(); info->seq_off = (const int64_t*)b->s_seq_off.data();
+    }
+    return SQG_OK;
+}
+
+extern "C" int sqg_fetch_reads(sqg_ctx_t* c, sqg_batch_t* b, char* dst) {
+    if (!c || !b || !dst || b->s_seq_off.empty()) return SQG_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    std::vector<uint8_t> all((size_t)b->n_bases_total + 1);
+    if (b->n_bases_total) HIPCHK(c, hipMemcpy(all.data(), b->d_bases, (size_t)b->n_bases_total, hipMemcpyDeviceToHost));
+    for (int i = 0; i < b->n; i++)
+        memcpy(dst + b->s_seq_off[(size_t)i], all.data() + b->h_base_off[(size_t)i] + b->s_read_at[(size_t)i], (size_t)b->s_rlen[(size_t)i]);
+    return SQG_OK;
+}

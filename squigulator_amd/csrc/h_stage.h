@@ -1,0 +1,350 @@
+// h_stage.h -- staging a batch: descriptors, worker chains and links, per-read host draws, uploads; per-batch and per-slot device memory
+// Host side of include/sqg.h; included by sqg_hip.hip (one translation unit with the kernels), in the order listed there.
+#pragma once
+
+extern "C" void sqg_batch_free(sqg_ctx_t* ctx, sqg_batch_t* b) {
+    if (!b) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->cfg.device);
+        if (b->ran && b->ev[4]) (void)hipEventSynchronize(b->ev[4]);      // this batch's kernels only, not the ones queued after it
+    }
+    if (b->h_svboff) (void)hipHostFree(b->h_svboff);
+    if (ctx && b->d_block && b->h_sigoff && b->ev[0] && ctx->pool.size() < 4) {
+        sqg_ctx::Recycled r;
+        r.d_block = b->d_block; r.block_bytes = b->block_bytes; r.h_sigoff = b->h_sigoff; r.h_sigoff_dev = b->h_sigoff_dev; r.h_n = b->h_n;
+        for (int i = 0; i < 8; i++) r.ev[i] = b->ev[i];
+        ctx->pool.push_back(r);
+    } else {
+        (void)hipFree(b->d_block);
+        if (b->h_sigoff) (void)hipHostFree(b->h_sigoff);
+        for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+    }
+    delete b;
+}
+
+// Per-slot device buffers for a batch of this geometry.  with_output: also the signal slab and the fix-up list, sized
+// by the hard bound on the dwell (skipped when that bound is unreasonable; sqg_batch_run then reads the scan back).
+static int grow_slot(sqg_ctx* c, sqg_ctx::Slot& Z, const sqg_batch* b, bool with_output) {
+    int rc2;
+    const int n = b->n;
+    const bool certified = c->cfg.mode == SQG_MODE_CERTIFIED;
+    if ((size_t)n + 1 > Z.reads_cap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
+        (void)hipFree(Z.d_seglen); (void)hipFree(Z.d_sigoff); Z.d_seglen = nullptr; Z.d_sigoff = nullptr;
+        const size_t cap = (size_t)n + 1 + (size_t)n / 2;
+        HIPCHK(c, hipMalloc(&Z.d_seglen, 2 * cap * sizeof(unsigned long long)));
+        HIPCHK(c, hipMalloc(&Z.d_sigoff, cap * sizeof(long long)));
+        Z.reads_cap = cap;
+    }
+    if ((rc2 = ensure(c, (void**)&Z.d_dwell, &Z.dwell_cap, (size_t)b->n_events + 64, sizeof(uint16_t)))) return rc2;
+    if ((rc2 = ensure(c, (void**)&Z.d_evrec, &Z.evrec_cap, (size_t)b->n_events + 64, sizeof(uint2)))) return rc2;
+    if ((rc2 = ensure(c, (void**)&Z.d_tile_so, &Z.tile_cap, (size_t)b->n_tiles + 64, sizeof(uint32_t)))) return rc2;
+    if ((rc2 = ensure(c, (void**)&Z.d_slow, &Z.slow_cap, (size_t)b->n_tiles + 64, sizeof(int)))) return rc2;
+    if (certified && c->use_kmer_streams) {
+        if ((rc2 = ensure(c, (void**)&Z.d_tfix, &Z.tfix_cap, (size_t)b->n_stiles * FIX_SLOTS + 64, sizeof(uint4)))) return rc2;
+        if ((rc2 = ensure(c, (void**)&Z.d_tfix_n, &Z.tfixn_cap, (size_t)b->n_stiles + 64, 1))) return rc2;
+        if ((rc2 = ensure(c, (void**)&Z.d_items, &Z.items_cap, (size_t)b->n_stiles + 64, sizeof(ItemDesc)))) return rc2;
+    }
+    if (with_output) {
+        const double bound = c->dwell_hi * (double)b->n_events;
+        if (bound <= 4.0e10) {
+            const size_t need = (size_t)bound;
+            if ((rc2 = ensure(c, (void**)&Z.d_sig, &Z.sig_cap, need + 64, sizeof(int16_t)))) return rc2;
+            if (certified && c->use_kmer_streams)
+                if ((rc2 = ensure(c, (void**)&Z.d_fix, &Z.fix_cap, (c->force_fix ? need : need / 256) + 65536, sizeof(FixEntry)))) return rc2;
+        }
+    }
+    return SQG_OK;
+}
+
+// Staging shared by sqg_batch_stage (reads come from the host: seqs != null) and sqg_batch_sample (reads were
+// sampled on the device: seqs == null, d_rec holds one SampleRec per read and k_copy_reads fills the base buffer).
+#include <chrono>
+static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t* seq_off,
+                        const int32_t* worker, const SampleRec* d_rec, sqg_batch_t** out) {
+    *out = nullptr;
+    static const bool st_on = getenv("SQG_STAGE_TIMING") != nullptr;
+    auto st_t0 = std::chrono::steady_clock::now();
+    auto st_mark = [&](const char* what) { if (st_on) { auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[stage] %-22s %.3f ms\n", what, std::chrono::duration<double, std::milli>(t - st_t0).count()); st_t0 = t; } };
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const sqg_profile_t& p = c->cfg.profile;
+    const bool rna = c->cfg.flags & SQG_RNA, prefix = c->cfg.flags & SQG_PREFIX;
+    const int k = c->k;
+
+    sqg_batch* b = new (std::nothrow) sqg_batch();
+    if (!b) return SQG_ENOMEM;
+    b->n = n; b->seq = c->next_stage;
+    b->ev_off.assign((size_t)n + 1, 0); b->sig_off.assign((size_t)n + 1, 0);
+    b->offset.resize((size_t)n); b->median.resize((size_t)n);
+    std::vector<ReadDesc> rd((size_t)n);
+    std::vector<int> wk((size_t)n);
+
+    // pass 1: worker ids, segment geometry
+    long long nb = 0, nev = 0;
+    for (int i = 0; i < n; i++) {
+        const int w = worker ? worker[i] : sqg_worker_of(i, n, c->T);
+        if (w < c->wlo || w >= c->whi) { delete b; c->err = "read assigned to a worker this context does not own"; return SQG_EINVAL; }
+        wk[(size_t)i] = w - c->wlo;
+        const long long len = seq_off[i + 1] - seq_off[i];
+        if (len < 0 || len > 2000000000LL) { delete b; return SQG_EINVAL; }
+        long long len0 = len;
+        if (prefix) len0 += rna ? (kPolyA + (long long)strlen(kAdaptorRna)) : ((long long)strlen(kStallDna) + (long long)strlen(kAdaptorDna));
+        int ne0, l0;
+        if (len0 < k) { ne0 = 5; l0 = 5 + k - 1; }                  // src/gensig.c:242-245
+        else { ne0 = (int)(len0 - k + 1); l0 = (int)len0; }
+        int ne1 = 0, l1 = 0;
+        if (prefix && rna) { l1 = (int)strlen(kStallRna); ne1 = l1 - k + 1; }   // src/genread.c:87-88
+        ReadDesc& d = rd[(size_t)i];
+        d.base_off = nb; d.ev_off = nev; d.len0 = l0; d.len1 = l1; d.ne0 = ne0; d.ne1 = ne1; d.worker = wk[(size_t)i];
+        b->ev_off[(size_t)i] = nev;
+        nb += l0 + l1; nev += ne0 + ne1;
+    }
+    b->ev_off[(size_t)n] = nev; b->n_events = nev; b->n_bases = nb;
+    // 64-event tiles (the work unit of k_samples); a tile never spans two reads
+    long long ntile = 0;
+    for (int i = 0; i < n; i++) { rd[(size_t)i].tile_off = (int)ntile; rd[(size_t)i].fast = 0; rd[(size_t)i].stile_off = 0; rd[(size_t)i].pad = 0; ntile += (rd[(size_t)i].ne0 + rd[(size_t)i].ne1 + 63) / 64; }
+    if (ntile > 2000000000LL) { delete b; c->err = "batch too large"; return SQG_EINVAL; }
+    b->n_tiles = ntile;
+    const int lean_ev = 64 * c->lean_epl;
+    long long nst = 0;                                        // super tiles of 64*lean_epl events (work items of k_samples_lean)
+    for (int i = 0; i < n; i++) { rd[(size_t)i].stile_off = (int)nst; rd[(size_t)i].pad = 0; nst += (rd[(size_t)i].ne0 + rd[(size_t)i].ne1 + lean_ev - 1) / lean_ev; }
+    b->n_stiles = nst;
+    // the tile -> read maps are filled on the device (k_fill_tiles) once the descriptors are there
+
+    st_mark("descriptors+tiles");
+    // pass 2: base buffer (prefix/stall attached as src/genread.c:95-123 does)
+    std::vector<uint8_t> hb(seqs ? (size_t)nb + 16 : 0, (uint8_t)'A');
+    for (int i = 0; seqs && i < n; i++) {
+        const ReadDesc& d = rd[(size_t)i];
+        uint8_t* dst = hb.data() + d.base_off;
+        const char* src = seqs + seq_off[i];
+        const long long len = seq_off[i + 1] - seq_off[i];
+        long long len0 = len;
+        if (prefix) len0 += rna ? (kPolyA + (long long)strlen(kAdaptorRna)) : ((long long)strlen(kStallDna) + (long long)strlen(kAdaptorDna));
+        if (len0 < k) {
+            memcpy(dst, kShortHack, (size_t)d.len0);
+        } else if (!prefix) {
+            memcpy(dst, src, (size_t)len);
+        } else if (rna) {
+            memcpy(dst, src, (size_t)len);
+            memset(dst + len, 'A', (size_t)kPolyA);
+            memcpy(dst + len + kPolyA, kAdaptorRna, strlen(kAdaptorRna));
+        } else {
+            const size_t st = strlen(kStallDna), ad = strlen(kAdaptorDna);
+            memcpy(dst, kStallDna, st);
+            memcpy(dst + st, kAdaptorDna, ad);
+            memcpy(dst + st + ad, src, (size_t)len);
+        }
+        if (d.len1) memcpy(dst + d.len0, kStallRna, (size_t)d.len1);
+    }
+
+    st_mark("base buffer");
+    // pass 3: per-worker chains in batch order; host-side scalar streams advance in that order
+    std::vector<int> count((size_t)c->nw, 0);
+    for (int i = 0; i < n; i++) count[(size_t)wk[(size_t)i]]++;
+    std::vector<int> chain_of((size_t)c->nw, -1), chain_off;
+    chain_off.push_back(0);
+    for (int w = 0; w < c->nw; w++) if (count[(size_t)w]) { chain_of[(size_t)w] = (int)chain_off.size() - 1; chain_off.push_back(chain_off.back() + count[(size_t)w]); }
+    b->n_chains = (int)chain_off.size() - 1;
+    std::vector<int> fill(chain_off.begin(), chain_off.end() - 1), chain_reads((size_t)n);
+    for (int i = 0; i < n; i++) chain_reads[(size_t)fill[(size_t)chain_of[(size_t)wk[(size_t)i]]]++] = i;
+
+    // Few workers, many reads (`-t 1`, `-t 8 -K 1000`): a worker chain would be one workgroup walking its reads one after
+    // the other.  It is cut into links of whole reads, which k_events walks concurrently after k_link_hist/k_link_prefix
+    // have prepared each link's view of the worker's k-mer streams.  SQG_SPLIT_CHAINS=0 disables this, =N forces it
+    // with N links as the target (tests).
+    const std::vector<int> wchain_off = chain_off;              // the worker chains: the host's scalar streams follow these
+    const int n_wchains = b->n_chains;
+    b->n_wchains = n_wchains;
+    std::vector<long long> wchain_ev((size_t)n_wchains, 0);
+    for (int i = 0; i < n; i++) wchain_ev[(size_t)chain_of[(size_t)wk[(size_t)i]]] += rd[(size_t)i].ne0 + rd[(size_t)i].ne1;
+    for (long long v : wchain_ev) b->max_wchain_ev = std::max(b->max_wchain_ev, v);
+    if (c->use_kmer_streams && k > 6 && (double)b->max_wchain_ev * c->dwell_hi >= 4294967295.0 - (double)LCG_ORD2) {
+        delete b; c->err = "one worker's reads of a batch may draw more than 3.2e9 samples (k > 6): use smaller batches"; return SQG_EINVAL;
+    }
+    std::vector<int> wlink_off(1, 0), wlink_worker;
+    {
+        const char* env = getenv("SQG_SPLIT_CHAINS");
+        const int forced = env ? atoi(env) : -1;
+        const bool multi = n > n_wchains;
+        const bool want = c->range_mode ? n > 0 : forced >= 0 ? (forced > 0 && multi) : (multi && n_wchains < 1024 && nev >= 65536);
+        if (c->use_kmer_streams && want) {
+            const size_t row_bytes = (size_t)c->num_kmer * sizeof(uint32_t);
+            long long target = forced > 0 ? forced : 2048;
+            target = std::min<long long>(target, std::max<long long>(8, (long long)(((size_t)1 << 30) / row_bytes)));
+            std::vector<int> link_off(1, 0);
+            for (int q = 0; q < n_wchains; q++) {
+                const int lo = wchain_off[(size_t)q], hi = wchain_off[(size_t)q + 1];
+                long long lq = nev > 0 ? (target * wchain_ev[(size_t)q] + nev - 1) / nev : 1;
+                lq = std::max<long long>(1, std::min<long long>(lq, hi - lo));
+                const long long per = (wchain_ev[(size_t)q] + lq - 1) / lq;
+                long long acc = 0;
+                for (int ci = lo; ci < hi; ci++) {
+                    const ReadDesc& d = rd[(size_t)chain_reads[(size_t)ci]];
+                    acc += d.ne0 + d.ne1;
+                    // a link's per-k-mer sample counts are 32-bit
+                    const long long nxt = ci + 1 < hi ? rd[(size_t)chain_reads[(size_t)ci + 1]].ne0 + rd[(size_t)chain_reads[(size_t)ci + 1]].ne1 : 0;
+                    if (ci + 1 == hi || acc >= per || (double)(acc + nxt) * c->dwell_hi >= 2147483648.0) { link_off.push_back(ci + 1); acc = 0; }
+                }
+                wlink_off.push_back((int)link_off.size() - 1);
+                wlink_worker.push_back(rd[(size_t)chain_reads[(size_t)lo]].worker);
+            }
+            chain_off.swap(link_off);
+            b->n_chains = (int)chain_off.size() - 1;
+            b->split = true;
+        }
+    }
+    // launch order: longest chain first, so the tail of the grid is made of short chains
+    std::vector<long long> chain_ev((size_t)b->n_chains, 0);
+    for (int q = 0; q < b->n_chains; q++)
+        for (int ci = chain_off[(size_t)q]; ci < chain_off[(size_t)q + 1]; ci++) chain_ev[(size_t)q] += rd[(size_t)chain_reads[(size_t)ci]].ne0 + rd[(size_t)chain_reads[(size_t)ci]].ne1;
+    // (a counting sort over 4096 length classes: exact order within a class does not matter for the tail)
+    std::vector<int> chain_order((size_t)b->n_chains);
+    {
+        long long mx = 1;
+        for (long long v : chain_ev) mx = std::max(mx, v);
+        constexpr int NB = 4096;
+        std::vector<int> cnt(NB + 1, 0);
+        auto cls = [&](long long v) { return (int)((NB - 1) - (v * (NB - 1)) / mx); };    // longest -> class 0
+        for (long long v : chain_ev) cnt[(size_t)cls(v) + 1]++;
+        for (int q = 0; q < NB; q++) cnt[(size_t)q + 1] += cnt[(size_t)q];
+        for (int q = 0; q < b->n_chains; q++) chain_order[(size_t)cnt[(size_t)cls(chain_ev[(size_t)q])]++] = q;
+    }
+
+    const uint32_t a2 = lcg_mul(LCG_A, LCG_A);
+    const bool no_lean = getenv("SQG_TEST_NO_LEAN") != nullptr;
+    // the per-read scalar draws (host libm, so that `offset` / `median_before` are the doubles the CPU reference prints):
+    // chains are independent, a few host threads share them
+    auto chain_range = [&](int q_lo, int q_hi) {
+        for (int q = q_lo; q < q_hi; q++)
+            for (int ci = wchain_off[(size_t)q]; ci < wchain_off[(size_t)q + 1]; ci++) {   // batch order within the worker
+                const int i = chain_reads[(size_t)ci];
+                ReadDesc& d = rd[(size_t)i];
+                const size_t w = (size_t)d.worker;
+                if (c->cfg.flags & SQG_IDEAL) {                   // src/gensig.c:311-313
+                    d.offset = p.offset_mean; b->median[(size_t)i] = p.median_before_mean;
+                } else {                                          // src/gensig.c:315-316
+                    d.offset = host_nrng(p.offset_mean, p.offset_std, &c->off_x[w]);
+                    b->median[(size_t)i] = host_nrng(p.median_before_mean, p.median_before_std, &c->med_x[w]);
+                }
+                b->offset[(size_t)i] = d.offset;
+                d.fast = (c->cfg.mode == SQG_MODE_CERTIFIED && c->use_kmer_streams && c->dwell_hi <= (double)MULT_N && !no_lean &&
+                          c->amp_floor - d.offset > 4.0 && c->amp_ceil - d.offset < 65000.0) ? 1 : 0;
+                d.time_c0 = c->time_c[w];
+                if (c->use_dwell_stream)                          // two draws per event (src/gensig.c:255)
+                    c->time_c[w] = lcg_mul(c->time_c[w], lcg_pow(a2, (unsigned long long)(d.ne0 + d.ne1)));
+            }
+    };
+    {
+        const int nth = (n_wchains >= 1024) ? (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        if (nth <= 1) chain_range(0, n_wchains);
+        else {
+            std::vector<std::thread> th;
+            const int per = (n_wchains + nth - 1) / nth;
+            for (int t = 0; t < nth; t++) th.emplace_back(chain_range, std::min(t * per, n_wchains), std::min((t + 1) * per, n_wchains));
+            for (auto& t : th) t.join();
+        }
+    }
+    if (!c->use_dwell_stream) {                           // constant dwell: lengths are known now
+        const unsigned long long sps = (unsigned long long)(int)p.dwell_mean;
+        b->seglen_host.resize((size_t)2 * n);
+        for (int i = 0; i < n; i++) { b->seglen_host[(size_t)2 * i] = sps * rd[(size_t)i].ne0; b->seglen_host[(size_t)2 * i + 1] = sps * rd[(size_t)i].ne1; }
+    }
+
+    // dwell kernel launch geometry: first read of every DW_EPB-event block
+    const long long nblk = (nev + DW_EPB - 1) / DW_EPB;
+    std::vector<int> blk_read((size_t)std::max<long long>(nblk, 1), 0);
+    {
+        int r = 0;
+        for (long long bi = 0; bi < nblk; bi++) {
+            const long long g = bi * DW_EPB;
+            while (r + 1 < n && g >= rd[(size_t)r + 1].ev_off) r++;
+            blk_read[(size_t)bi] = r;
+        }
+    }
+
+    st_mark("chains+streams+blocks");
+    auto bail = [&](int code) { sqg_batch_free(c, b); return code; };
+#define CHKB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE); } } while (0)
+    {   // one device allocation per batch, carved into the batch's arrays (256-byte aligned)
+        size_t off = 0;
+        auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+        const size_t o_bases = carve((size_t)nb + 16), o_reads = carve(std::max<size_t>(1, rd.size()) * sizeof(ReadDesc)),
+                     o_blk = carve(blk_read.size() * sizeof(int)), o_coff = carve(chain_off.size() * sizeof(int)),
+                     o_crd = carve(std::max<size_t>(1, chain_reads.size()) * sizeof(int)),
+                     o_st = carve((size_t)std::max<long long>(nst, 1) * sizeof(int)), o_t = carve((size_t)std::max<long long>(ntile, 1) * sizeof(int)),
+                     o_ord = carve(std::max<size_t>(1, chain_order.size()) * sizeof(int)),
+                     o_wlo = carve(wlink_off.size() * sizeof(int)), o_wlw = carve(std::max<size_t>(1, wlink_worker.size()) * sizeof(int));
+        // a freed batch's block, pinned offsets and events are reused when they are large enough
+        for (size_t pi = 0; pi < c->pool.size(); pi++) {
+            sqg_ctx::Recycled& r = c->pool[pi];
+            if (r.block_bytes >= off && r.h_n >= (size_t)n + 1) {
+                b->d_block = r.d_block; b->block_bytes = r.block_bytes; b->h_sigoff = r.h_sigoff; b->h_sigoff_dev = r.h_sigoff_dev; b->h_n = r.h_n;
+                for (int i = 0; i < 8; i++) b->ev[i] = r.ev[i];
+                c->pool.erase(c->pool.begin() + (long)pi);
+                break;
+            }
+        }
+        if (!b->d_block) {
+            if (c->pool.size() >= 4) {                      // nothing fits: make room
+                sqg_ctx::Recycled& r = c->pool.front();
+                (void)hipFree(r.d_block); (void)hipHostFree(r.h_sigoff); for (auto& e : r.ev) if (e) (void)hipEventDestroy(e);
+                c->pool.erase(c->pool.begin());
+            }
+            b->block_bytes = off + off / 8;                 // slack: the next batches are about this size
+            CHKB(hipMalloc(&b->d_block, b->block_bytes));
+        }
+        uint8_t* base = b->d_block;
+        b->d_bases = base + o_bases; b->d_reads = (ReadDesc*)(base + o_reads); b->d_blk_read = (int*)(base + o_blk);
+        b->d_chain_off = (int*)(base + o_coff); b->d_chain_reads = (int*)(base + o_crd); b->d_stile_read = (int*)(base + o_st);
+        b->d_tile_read = (int*)(base + o_t); b->d_chain_order = (int*)(base + o_ord);
+        b->d_wlink_off = (int*)(base + o_wlo); b->d_wlink_worker = (int*)(base + o_wlw);
+    }
+    if (seqs) CHKB(hipMemcpyAsync(b->d_bases, hb.data(), hb.size(), hipMemcpyHostToDevice, c->stage_stream));
+    else CHKB(hipMemsetAsync(b->d_bases + nb, 'A', 16, c->stage_stream));
+    if (n) CHKB(hipMemcpyAsync(b->d_reads, rd.data(), rd.size() * sizeof(ReadDesc), hipMemcpyHostToDevice, c->stage_stream));
+    if (!seqs && n) {                                      // the reads come from the resident genome
+        hipLaunchKernelGGL(k_copy_reads, dim3((unsigned)n), dim3(256), 0, c->stage_stream, c->genome, d_rec, b->d_reads, b->d_bases, n,
+                           rna ? 1 : 0, prefix ? 1 : 0);
+        CHKB(hipGetLastError());
+    }
+    if (n) {
+        hipLaunchKernelGGL(k_fill_tiles, dim3((unsigned)n), dim3(64), 0, c->stage_stream, b->d_reads, n, lean_ev, b->d_tile_read, b->d_stile_read);
+        CHKB(hipGetLastError());
+    }
+    b->n_bases_total = nb;
+    b->h_base_off.resize((size_t)n);
+    for (int i = 0; i < n; i++) b->h_base_off[(size_t)i] = rd[(size_t)i].base_off;
+    CHKB(hipMemcpyAsync(b->d_blk_read, blk_read.data(), blk_read.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+    CHKB(hipMemcpyAsync(b->d_chain_off, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+    if (n) CHKB(hipMemcpyAsync(b->d_chain_reads, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+    if (b->n_chains) CHKB(hipMemcpyAsync(b->d_chain_order, chain_order.data(), chain_order.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+    if (b->split) {
+        CHKB(hipMemcpyAsync(b->d_wlink_off, wlink_off.data(), wlink_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+        CHKB(hipMemcpyAsync(b->d_wlink_worker, wlink_worker.data(), wlink_worker.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
+    }
+    if (!b->h_sigoff) {
+        b->h_n = (size_t)n + 1 + (size_t)n / 8;
+        CHKB(hipHostMalloc(&b->h_sigoff, b->h_n * sizeof(long long), hipHostMallocMapped));
+        CHKB(hipHostGetDevicePointer((void**)&b->h_sigoff_dev, b->h_sigoff, 0));
+        for (auto& e : b->ev) CHKB(hipEventCreate(&e));
+    }
+    st_mark("mallocs+enqueue");
+    CHKB(hipStreamSynchronize(c->stage_stream));     // staging buffers above are stack-owned (only the staging stream: a running batch is not waited for)
+    st_mark("sync");
+#undef CHKB
+    // slots that have never held a batch are sized now, so that not even the first run allocates
+    for (auto& Z : c->slot)
+        if (Z.reads_cap == 0 && n > 0) { const int rg = grow_slot(c, Z, b, /*with_output=*/true); if (rg) return bail(rg); }
+    c->next_stage++;
+    *out = b;
+    return SQG_OK;
+}
+
+extern "C" int sqg_batch_stage(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t* seq_off,
+                               const int32_t* worker, sqg_batch_t** out) {
+    if (!c || !out || n < 0 || (n > 0 && (!seqs || !seq_off))) return SQG_EINVAL;
+    static const char none[1] = {0};
+    static const int64_t zero_off[1] = {0};
+    return stage_common(c, n, n > 0 ? seqs : none, n > 0 ? seq_off : zero_off, worker, nullptr, out);
+}
