@@ -34,9 +34,11 @@ struct sqg_ctx {
         uint4* d_tfix = nullptr; size_t tfix_cap = 0;
         unsigned char* d_tfix_n = nullptr; size_t tfixn_cap = 0;
         ItemDesc* d_items = nullptr; size_t items_cap = 0;          // [n_stiles] work items of the lean kernel (k_items)
-        hipEvent_t done = nullptr;                 // recorded on stream2 after the slot's last sample kernel
+        hipEvent_t done = nullptr;                 // recorded after the slot's last kernel (fix-ups included)
+        hipEvent_t sampled = nullptr;              // recorded on stream2 after the slot's sample kernels, before the fix-ups
     } slot[2];
-    hipStream_t stream2 = nullptr;                 // the sample kernels (k_samples_lean, generic, fix-ups)
+    hipStream_t stream2 = nullptr;                 // the sample kernels (k_samples_lean, generic); == stream unless SQG_OVERLAP=1
+    hipStream_t fix_stream = nullptr;              // the FP64 fix-ups of batch i (two small kernels) run next to k_events of batch i+1
     uint32_t* d_link_rows = nullptr; size_t link_rows_cap = 0;   // split chains: one row per link of the running batch
     double row_bound = 0;                          // k > 6: upper bound of any sample count held in d_rows
     bool range_mode = false;                       // range sharding (sqg_set_range_mode): every batch is cut into links and run in two phases
@@ -147,7 +149,7 @@ static uint32_t canon(long long s) {
 static int ensure(sqg_ctx* c, void** p, size_t* cap, size_t need, size_t elem) {
     if (need <= *cap) return SQG_OK;
     size_t ncap = std::max(need + need / 4, *cap + *cap / 2);     // slack: batches of similar size never re-allocate
-    if (*p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); HIPCHK(c, hipFree(*p)); *p = nullptr; *cap = 0; }
+    if (*p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); HIPCHK(c, hipStreamSynchronize(c->fix_stream)); HIPCHK(c, hipFree(*p)); *p = nullptr; *cap = 0; }
     HIPCHK(c, hipMalloc(p, ncap * elem));
     *cap = ncap;
     return SQG_OK;
@@ -166,6 +168,7 @@ static int dbg_sync(sqg_ctx* c, const char* what) {
     if (!on) return SQG_OK;
     hipError_t e = hipStreamSynchronize(c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream2);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->fix_stream);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { c->err = std::string(what) + ": " + hipGetErrorString(e); fprintf(stderr, "[sqg] %s\n", c->err.c_str()); return SQG_EDEVICE; }
     fprintf(stderr, "[sqg] %s ok\n", what);

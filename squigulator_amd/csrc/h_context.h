@@ -34,6 +34,7 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    if (ctx->fix_stream) (void)hipStreamSynchronize(ctx->fix_stream);
     (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_xcounts); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err);
     for (auto& S : ctx->slot) {
         (void)hipFree(S.d_sig); (void)hipFree(S.d_dwell); (void)hipFree(S.d_seglen); (void)hipFree(S.d_sigoff);
@@ -41,6 +42,7 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
         (void)hipFree(S.d_evrec); (void)hipFree(S.d_tile_so); (void)hipFree(S.d_slow);
         (void)hipFree(S.d_tfix); (void)hipFree(S.d_tfix_n); (void)hipFree(S.d_items);
         if (S.done) (void)hipEventDestroy(S.done);
+        if (S.sampled) (void)hipEventDestroy(S.sampled);
     }
     (void)hipFree(ctx->d_svb); (void)hipFree(ctx->d_svb_size); (void)hipFree(ctx->d_svb_off);
     (void)hipFree(ctx->d_genome); (void)hipFree(ctx->d_contig_off); (void)hipFree(ctx->d_cum);
@@ -49,6 +51,7 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     for (auto& r : ctx->pool) { (void)hipFree(r.d_block); (void)hipHostFree(r.h_sigoff); for (auto& e : r.ev) if (e) (void)hipEventDestroy(e); }
     ctx->pool.clear();
     if (ctx->stream2 && ctx->stream2 != ctx->stream) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->fix_stream) (void)hipStreamDestroy(ctx->fix_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -124,10 +127,12 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     // default keeps one stream and clean per-kernel timings).  Batches are double-buffered either way.
     if (getenv("SQG_OVERLAP")) CHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     else c->stream2 = c->stream;
+    CHK(hipStreamCreateWithFlags(&c->fix_stream, hipStreamNonBlocking));
     for (auto& S : c->slot) {
         CHK(hipMalloc(&S.d_fix_count, 4 * sizeof(unsigned int)));
         CHK(hipMemset(S.d_fix_count, 0, 4 * sizeof(unsigned int)));
         CHK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+        CHK(hipEventCreateWithFlags(&S.sampled, hipEventDisableTiming));
         CHK(hipEventRecord(S.done, c->stream2));
     }
     if (cfg->mode == SQG_MODE_CERTIFIED) {

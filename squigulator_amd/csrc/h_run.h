@@ -162,6 +162,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         }
     }
 
+    hipStream_t tail = c->stream2;                               // the stream the batch's last kernel runs on
     if (n > 0 && b->n_chains > 0) {
         P.sig = S.d_sig; P.fix = S.d_fix; P.fix_count = S.d_fix_count;
         P.fix_cap = (unsigned int)std::min<size_t>(S.fix_cap, 0xffffffffu);
@@ -194,8 +195,12 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             if ((rc = dbg_sync(c, "k_samples_lean"))) return rc;
             hipLaunchKernelGGL((k_samples<1, true>), dim3(std::min(sgrid, 4096u)), dim3(256), 0, c->stream2, P, n_tiles);
             if ((rc = dbg_sync(c, "k_samples<generic>"))) return rc;
-            hipLaunchKernelGGL(k_fixup, dim3(512), dim3(256), 0, c->stream2, P);
-            hipLaunchKernelGGL(k_fixup_tiles, dim3((unsigned)((n_stiles + 255) / 256)), dim3(256), 0, c->stream2, P, n_stiles);
+            // the FP64 fix-ups (two small, latency-bound kernels) go to their own stream: the next batch's k_events does not wait for them
+            HIPCHK(c, hipEventRecord(S.sampled, c->stream2));
+            HIPCHK(c, hipStreamWaitEvent(c->fix_stream, S.sampled, 0));
+            tail = c->fix_stream;
+            hipLaunchKernelGGL(k_fixup, dim3(512), dim3(256), 0, tail, P);
+            hipLaunchKernelGGL(k_fixup_tiles, dim3((unsigned)((n_stiles + 255) / 256)), dim3(256), 0, tail, P, n_stiles);
             if ((rc = dbg_sync(c, "k_fixup"))) return rc;
         } else {
             HIPCHK(c, hipEventRecord(b->ev[7], c->stream));
@@ -208,8 +213,8 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         HIPCHK(c, hipEventRecord(b->ev[7], c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, b->ev[7], 0));
     }
-    HIPCHK(c, hipEventRecord(b->ev[4], c->stream2));
-    HIPCHK(c, hipEventRecord(S.done, c->stream2));
+    HIPCHK(c, hipEventRecord(b->ev[4], tail));
+    HIPCHK(c, hipEventRecord(S.done, tail));
     b->ran = true;
     c->next_run++;
     return SQG_OK;
