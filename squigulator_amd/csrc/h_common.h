@@ -39,6 +39,7 @@ struct sqg_ctx {
     } slot[2];
     hipStream_t stream2 = nullptr;                 // the sample kernels (k_samples_lean, generic); == stream unless SQG_OVERLAP=1
     hipStream_t fix_stream = nullptr;              // the FP64 fix-ups of batch i (two small kernels) run next to k_events of batch i+1
+    unsigned long long* d_scan_part = nullptr; size_t scan_part_cap = 0;   // k_scan: {ticket, total} per workgroup
     uint32_t* d_link_rows = nullptr; size_t link_rows_cap = 0;   // split chains: one row per link of the running batch
     double row_bound = 0;                          // k > 6: upper bound of any sample count held in d_rows
     bool range_mode = false;                       // range sharding (sqg_set_range_mode): every batch is cut into links and run in two phases

@@ -136,7 +136,15 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         // the scan also writes the offsets through the batch's pinned host mapping (no copy between kernels)
         // (k_items, when it runs, does that part with more parallelism)
         const bool items_run = certified && c->use_kmer_streams && b->n_chains > 0 && c->dwell_hi * (double)b->n_events <= 4.0e10;
-        hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, c->stream, S.d_seglen, n, S.d_sigoff, items_run ? nullptr : b->h_sigoff_dev, c->d_err, S.d_fix_count);
+        const unsigned scan_wgs = (unsigned)((n + SCAN_WG - 1) / SCAN_WG);
+        {
+            const size_t cap0 = c->scan_part_cap;
+            if ((rc = ensure(c, (void**)&c->d_scan_part, &c->scan_part_cap, (size_t)2 * scan_wgs, sizeof(unsigned long long)))) return rc;
+            if (c->scan_part_cap != cap0)                         // tickets start at 1: a fresh array must not hold one by accident
+                HIPCHK(c, hipMemsetAsync(c->d_scan_part, 0, c->scan_part_cap * sizeof(unsigned long long), c->stream));
+        }
+        hipLaunchKernelGGL(k_scan, dim3(scan_wgs), dim3(SCAN_WG), 0, c->stream, S.d_seglen, n, S.d_sigoff, items_run ? nullptr : b->h_sigoff_dev,
+                           c->d_err, S.d_fix_count, c->d_scan_part, b->seq + 1);
         HIPCHK(c, hipGetLastError());
         if ((rc = dbg_sync(c, "k_scan"))) return rc;
     } else HIPCHK(c, hipMemsetAsync(S.d_fix_count, 0, 4 * sizeof(unsigned int), c->stream));

@@ -111,61 +111,53 @@ __global__ __launch_bounds__(256) void k_dwell(const ReadDesc* __restrict__ read
     }
 }
 
-// ---- k_scan: sig_off = exclusive scan of per-read totals (single workgroup) -----------------
-// sig_off goes to HBM for the kernels and, through the pinned host mapping, straight to the host (no D2H copy
-// between kernels): host_off is visible once the stream has been synchronised.
-#define SCAN_PER 32
-__global__ __launch_bounds__(1024) void k_scan(const unsigned long long* __restrict__ seglen, int n_reads,
-                                               long long* __restrict__ sig_off, long long* __restrict__ host_off,
-                                               unsigned int* __restrict__ err, unsigned int* __restrict__ counters) {
-    __shared__ long long wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid < 4) counters[tid] = 0;                      // fix-up list / slow-tile list counters of this batch
-    // one pass: thread t owns reads [t*per, (t+1)*per)
-    const int per = (n_reads + 1023) / 1024;
-    const int lo = min(tid * per, n_reads), hi = min(lo + per, n_reads);
-    const ulonglong2* sl = reinterpret_cast<const ulonglong2*>(seglen);
-    long long len[SCAN_PER];
+// ---- k_scan: sig_off = exclusive scan of per-read totals ------------------------------------
+// One workgroup per 1024 reads, one read per thread (coalesced 16-B loads).  A workgroup publishes the total of its
+// reads as {ticket, total} and adds up the totals of the workgroups before it, waiting for their tickets (they were
+// dispatched earlier and wait for nobody behind them); `ticket` differs from launch to launch, so the array is never
+// cleared.  sig_off goes to HBM for the kernels and, when host_off is given, through the pinned host mapping straight
+// to the host (no D2H copy between kernels): visible once the stream has been synchronised.
+#define SCAN_WG 1024
+__global__ __launch_bounds__(SCAN_WG) void k_scan(const unsigned long long* __restrict__ seglen, int n_reads,
+                                                  long long* __restrict__ sig_off, long long* __restrict__ host_off,
+                                                  unsigned int* __restrict__ err, unsigned int* __restrict__ counters,
+                                                  unsigned long long* __restrict__ part, unsigned long long ticket) {
+    __shared__ long long wsum[SCAN_WG / 64];
+    __shared__ long long before_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = blockIdx.x;
+    if (g == 0 && tid < 4) counters[tid] = 0;            // fix-up list / slow-tile list counters of this batch
+    const int i = g * SCAN_WG + tid;
     long long v = 0;
-    bool big = false;
-    if (per <= SCAN_PER) {                               // the usual case: all loads in flight together
-#pragma unroll
-        for (int j = 0; j < SCAN_PER; j++) {
-            ulonglong2 q = make_ulonglong2(0, 0);
-            if (lo + j < hi) q = sl[lo + j];
-            len[j] = (long long)(q.x + q.y);
-            big |= len[j] >= 4294967295LL;
-            v += len[j];
-        }
-    } else {
-        for (int i = lo; i < hi; i++) {
-            const ulonglong2 q = sl[i];
-            const long long l = (long long)(q.x + q.y);
-            big |= l >= 4294967295LL;
-            v += l;
-        }
+    if (i < n_reads) {
+        const ulonglong2 q = reinterpret_cast<const ulonglong2*>(seglen)[i];
+        v = (long long)(q.x + q.y);
+        if (v >= 4294967295LL) atomicOr(err, 2u);        // src/sim.c:559-562
     }
-    if (big) atomicOr(err, 2u);                          // src/sim.c:559-562
     long long x = v;
     for (int o = 1; o < 64; o <<= 1) { long long y = __shfl_up(x, o); if (lane >= o) x += y; }
     if (lane == 63) wsum[wid] = x;
     __syncthreads();
-    long long run = x - v;
-    for (int w = 0; w < wid; w++) run += wsum[w];
-    if (per <= SCAN_PER) {
-#pragma unroll
-        for (int j = 0; j < SCAN_PER; j++) {
-            if (lo + j < hi) { sig_off[lo + j] = run; if (host_off) host_off[lo + j] = run; }
-            run += len[j];
-        }
-    } else {
-        for (int i = lo; i < hi; i++) {
-            sig_off[i] = run; if (host_off) host_off[i] = run;
-            const ulonglong2 q = sl[i];
-            run += (long long)(q.x + q.y);
-        }
+    long long run = x - v, total = 0;
+    for (int w = 0; w < SCAN_WG / 64; w++) { if (w < wid) run += wsum[w]; total += wsum[w]; }
+    if (tid == 0) {
+        __hip_atomic_store(&part[2 * g + 1], (unsigned long long)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&part[2 * g], ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (tid == 1023) { sig_off[n_reads] = run; if (host_off) host_off[n_reads] = run; }   // the last thread's running total is the grand total
+    // totals of the workgroups before mine
+    long long mine = 0;
+    for (int h = tid; h < g; h += SCAN_WG) {
+        while (__hip_atomic_load(&part[2 * h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != ticket) __builtin_amdgcn_s_sleep(1);
+        mine += (long long)__hip_atomic_load(&part[2 * h + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    __syncthreads();                                     // wsum has been read by everyone
+    if (lane == 0) wsum[wid] = mine;
+    __syncthreads();
+    if (tid == 0) { long long t = 0; for (int w = 0; w < SCAN_WG / 64; w++) t += wsum[w]; before_sh = t; }
+    __syncthreads();
+    run += before_sh;
+    if (i < n_reads) { sig_off[i] = run; if (host_off) host_off[i] = run; }
+    if (i == n_reads - 1) { sig_off[n_reads] = run + v; if (host_off) host_off[n_reads] = run + v; }
 }
 
 // ---- split chains --------------------------------------------------------------------------
