@@ -52,6 +52,8 @@ struct sqg_ctx {
     std::vector<uint32_t> time_c;          // canonical time-stream state per local worker
     std::vector<long long> off_x, med_x;   // raw Schrage states (as the reference keeps them)
     unsigned long long next_stage = 0, next_run = 0, compress_seq = 0;
+    unsigned long long runs = 0;                   // batches run so far: a batch's slot is its run index & 1
+    std::set<unsigned long long> abandoned;        // staged batches that were freed without having been run
     sqg_timing_t timing = {0, 0, 0, 0, 0, 0};
     bool use_dwell_stream = true, use_kmer_streams = true;
     float delta_x = 0.f;                   // certified mode: swept |x_fast - x_exact| bound incl. margin
@@ -111,7 +113,9 @@ struct sqg_batch {
     unsigned long long compress_seq = 0;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel-phase boundaries; [7]: the event side is done
     int slot = 0;                        // which of the context's two buffer sets this batch runs in
+    unsigned long long run_idx = 0;      // how many batches had been run before this one
     bool ran = false, waited = false, lean_timed = false, dwell_timed = false;
+    bool staged = false;                 // staging completed: the batch holds a place in the run order
     bool begun = false, other_fresh = false;   // sqg_batch_run_begin has run; the other slot had never held a batch then
 };
 
@@ -145,6 +149,11 @@ static uint32_t canon(long long s) {
     s %= (long long)LCG_M;
     if (s < 0) s += LCG_M;
     return (uint32_t)s;
+}
+
+// staged batches are run in staging order; those freed without a run are stepped over
+static void skip_abandoned(sqg_ctx* c) {
+    while (!c->abandoned.empty() && *c->abandoned.begin() == c->next_run) { c->abandoned.erase(c->abandoned.begin()); c->next_run++; }
 }
 
 static int ensure(sqg_ctx* c, void** p, size_t* cap, size_t need, size_t elem) {

@@ -53,7 +53,7 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
 
 extern "C" int sqg_fetch_signal(sqg_ctx_t* c, sqg_batch_t* b, int16_t* dst) {
     if (!c || !b || !b->ran || !dst) return SQG_EINVAL;
-    if (b->seq + 2 < c->next_run) return SQG_ESEQUENCE;       // slab already reused (two batches later)
+    if (b->run_idx + 2 < c->runs) return SQG_ESEQUENCE;       // slab already reused (two batches later)
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipEventSynchronize(b->ev[4]));
     if (!b->waited) b->n_samples = b->h_sigoff[b->n];
@@ -63,7 +63,7 @@ extern "C" int sqg_fetch_signal(sqg_ctx_t* c, sqg_batch_t* b, int16_t* dst) {
 
 extern "C" int sqg_fetch_dwell(sqg_ctx_t* c, sqg_batch_t* b, int32_t* dst) {
     if (!c || !b || !b->ran || !dst) return SQG_EINVAL;
-    if (b->seq + 2 < c->next_run) return SQG_ESEQUENCE;
+    if (b->run_idx + 2 < c->runs) return SQG_ESEQUENCE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipEventSynchronize(b->ev[4]));
     if (!c->use_dwell_stream) {
@@ -93,7 +93,7 @@ extern "C" int sqg_submit(sqg_ctx_t* c, int32_t n, const char* seqs, const int64
 
 extern "C" int sqg_batch_compress(sqg_ctx_t* c, sqg_batch_t* b, sqg_svb_t* out) {
     if (!c || !b || !b->ran || !out) return SQG_EINVAL;
-    if (b->seq + 2 < c->next_run) return SQG_ESEQUENCE;       // the signals of an older batch are gone
+    if (b->run_idx + 2 < c->runs) return SQG_ESEQUENCE;       // the signals of an older batch are gone
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipEventSynchronize(b->ev[4]));
     sqg_ctx::Slot& S = c->slot[b->slot];

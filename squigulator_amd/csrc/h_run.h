@@ -5,6 +5,7 @@
 // (sqg_batch_run_end), `before` / `after` being what the other ranges of the batch draw from each stream
 static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* before, const uint32_t* after) {
     if (!c || !b) return SQG_EINVAL;
+    if (phase != 2) skip_abandoned(c);
     if (phase == 2 ? (!b->begun || b->ran) : (b->ran || b->begun || b->seq != c->next_run)) return SQG_ESEQUENCE;
     if ((before == nullptr) != (after == nullptr)) return SQG_EINVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -12,7 +13,8 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     const int n = b->n;
     const bool certified = c->cfg.mode == SQG_MODE_CERTIFIED;
     int rc;
-    b->slot = (int)(b->seq & 1);
+    if (phase != 2) b->run_idx = c->runs;
+    b->slot = (int)(b->run_idx & 1);
     sqg_ctx::Slot& S = c->slot[b->slot];
     sqg_ctx::Slot& other = c->slot[b->slot ^ 1];
     if (phase != 2) {
@@ -144,7 +146,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 HIPCHK(c, hipMemsetAsync(c->d_scan_part, 0, c->scan_part_cap * sizeof(unsigned long long), c->stream));
         }
         hipLaunchKernelGGL(k_scan, dim3(scan_wgs), dim3(SCAN_WG), 0, c->stream, S.d_seglen, n, S.d_sigoff, items_run ? nullptr : b->h_sigoff_dev,
-                           c->d_err, S.d_fix_count, c->d_scan_part, b->seq + 1);
+                           c->d_err, S.d_fix_count, c->d_scan_part, b->run_idx + 1);
         HIPCHK(c, hipGetLastError());
         if ((rc = dbg_sync(c, "k_scan"))) return rc;
     } else HIPCHK(c, hipMemsetAsync(S.d_fix_count, 0, 4 * sizeof(unsigned int), c->stream));
@@ -225,6 +227,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     HIPCHK(c, hipEventRecord(S.done, tail));
     b->ran = true;
     c->next_run++;
+    c->runs++;
     return SQG_OK;
 }
 
@@ -247,6 +250,7 @@ extern "C" int sqg_batch_run_end(sqg_ctx_t* c, sqg_batch_t* b, const uint32_t* d
 
 extern "C" int sqg_set_range_mode(sqg_ctx_t* c, int on) {
     if (!c) return SQG_EINVAL;
+    skip_abandoned(c);
     if (c->next_stage != c->next_run) return SQG_ESEQUENCE;       // staged batches pending
     c->range_mode = on != 0;
     return SQG_OK;

@@ -8,6 +8,9 @@ extern "C" void sqg_batch_free(sqg_ctx_t* ctx, sqg_batch_t* b) {
         (void)hipSetDevice(ctx->cfg.device);
         if (b->ran && b->ev[4]) (void)hipEventSynchronize(b->ev[4]);      // this batch's kernels only, not the ones queued after it
     }
+    // never run (or only begun): the batches staged after it must not wait for it.  Its share of the workers' scalar streams
+    // is spent all the same: what follows is no longer the reference's sequence.
+    if (ctx && b->staged && !b->ran) { if (b->begun && ctx->stream) (void)hipStreamSynchronize(ctx->stream); ctx->abandoned.insert(b->seq); }
     if (b->h_svboff) (void)hipHostFree(b->h_svboff);
     if (ctx && b->d_block && b->h_sigoff && b->ev[0] && ctx->pool.size() < 4) {
         sqg_ctx::Recycled r;
@@ -337,6 +340,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     for (auto& Z : c->slot)
         if (Z.reads_cap == 0 && n > 0) { const int rg = grow_slot(c, Z, b, /*with_output=*/true); if (rg) return bail(rg); }
     c->next_stage++;
+    b->staged = true;
     *out = b;
     return SQG_OK;
 }

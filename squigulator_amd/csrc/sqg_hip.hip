@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>

@@ -208,3 +208,27 @@ def test_batches_queued_back_to_back_keep_their_results():
     for h in hs:
         h.free()
     gen.close(); orac.close()
+
+
+@pytest.mark.gpu
+def test_a_staged_batch_freed_without_a_run_does_not_block_the_ones_behind_it():
+    from squigulator_amd import model, profiles
+    rng = np.random.default_rng(8)
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    mean, stdv = model.synthetic_model(6)
+    gen = api.SignalGenerator(prof, fl, 6, mean, stdv, 3, num_workers=4, mode=api.MODE_CERTIFIED)
+    reads = [bytes(rng.choice(list(b"ACGT"), 300).astype(np.uint8)) for _ in range(4)]
+    a, b, c = gen.stage(reads), gen.stage(reads), gen.stage(reads)
+    b.free()                                             # never run
+    a.run()
+    c.run()                                              # would be out of sequence if b still held its place
+    a.wait(); c.wait()
+    sa, sc = a.signal().copy(), c.signal().copy()        # a's results are still there: c ran in the other buffer set
+    assert len(sa) == a.n_samples and len(sc) == c.n_samples
+    d = gen.stage(reads).run().wait()
+    assert len(d.signal()) == d.n_samples
+    with pytest.raises(api.SqgError):
+        a.signal()                                       # two batches have run since: a's slab has been reused
+    for x in (a, c, d):
+        x.free()
+    gen.close()

@@ -147,3 +147,37 @@ def test_host_reads_with_skip_reads_match_the_oracle():
             b.free()
     for g in gens:
         g.close()
+
+
+@pytest.mark.gpu
+def test_two_phase_run_misuse_is_reported():
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    mean, stdv = model.synthetic_model(6)
+    gen = api.SignalGenerator(prof, fl, 6, mean, stdv, 1, num_workers=1, mode=api.MODE_CERTIFIED)
+    reads = [b"ACGT" * 100] * 3
+    b = gen.stage(reads)
+    with pytest.raises(api.SqgError):
+        b.run_begin()                                    # range mode is off
+    with pytest.raises(api.SqgError):
+        b.run_end()                                      # nothing begun
+    with pytest.raises(api.SqgError):
+        gen.set_range_mode(True)                         # a staged batch is pending
+    b.run().wait(); b.free()
+    gen.set_range_mode(True)
+    b = gen.stage(reads)
+    b.run_begin()
+    with pytest.raises(api.SqgError):
+        b.run_begin()                                    # twice
+    with pytest.raises(api.SqgError):
+        b.run()                                          # begun: only run_end may follow
+    with pytest.raises(api.SqgError):
+        b.run_end(1, None)                               # before without after
+    b.run_end().wait()
+    want = b.signal().copy()
+    b.free()
+    # range mode with the whole batch here == the plain run of a fresh context
+    gen2 = api.SignalGenerator(prof, fl, 6, mean, stdv, 1, num_workers=1, mode=api.MODE_CERTIFIED)
+    x = gen2.submit(reads); x.free()
+    y = gen2.submit(reads)
+    np.testing.assert_array_equal(y.signal(), want)
+    y.free(); gen2.close(); gen.close()
