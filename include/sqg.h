@@ -146,6 +146,8 @@ int  sqg_batch_wait(sqg_ctx_t *ctx, sqg_batch_t *b, sqg_result_t *res);
 /* Copy results of the most recently run batch to host memory. */
 int  sqg_fetch_signal(sqg_ctx_t *ctx, sqg_batch_t *b, int16_t *dst /* n_samples */);
 int  sqg_fetch_dwell(sqg_ctx_t *ctx, sqg_batch_t *b, int32_t *dst /* n_events, as aln->ss */);
+/* Waits for the batch's own kernels only.  A staged batch may be freed without having been run: the batches staged
+ * after it then run in order as usual, but its reads' share of the workers' streams stays spent. */
 void sqg_batch_free(sqg_ctx_t *ctx, sqg_batch_t *b);
 int  sqg_get_timing(sqg_ctx_t *ctx, sqg_timing_t *t);
 

@@ -6,7 +6,9 @@ shift || true
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-store-probe $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- $BENCH > $OUT/trace.log 2>&1
+# the stats pass runs the bench exactly as the driver does (defaults; CPU legs included): its kernel averages are the ones
+# the bench line's roofline.kernel_ms has to agree with
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python $GRAFT_REPO_ROOT/bench.py $* > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT -o pmc1 -- $BENCH > $OUT/pmc1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $OUT -o pmc2 -- $BENCH > $OUT/pmc2.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM --kernel-trace --output-format csv -d $OUT -o pmc3 -- $BENCH > $OUT/pmc3.log 2>&1
