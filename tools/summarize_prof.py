@@ -11,11 +11,43 @@ src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 shutil.copy(os.path.join(src, "trace_kernel_stats.csv"), dst + "_kernel_stats.csv")
 lines = ["# rocprofv3 summary (" + os.path.basename(src) + ")", "",
-         "command: `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-store-probe` under",
-         "`rocprofv3 --kernel-trace --stats` (durations) and three separate `--pmc` passes (counters).", "",
+         "command: `python bench.py` (the driver's default run) under `rocprofv3 --kernel-trace --stats` (durations); the counters come from",
+         "three separate `--pmc` passes of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-store-probe`.", "",
          "## kernel durations (--kernel-trace --stats)", "", "| kernel | calls | avg us | % |", "|---|---|---|---|"]
 for r in csv.DictReader(open(os.path.join(src, "trace_kernel_stats.csv"))):
     lines.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+# per-launch durations of the two big kernels: the stats average mixes warm-up launches, the timed steps and the smaller
+# parity-check batch of the CPU leg; the bench line's roofline.kernel_ms is the mean over the timed steps only
+tr = os.path.join(src, "trace_kernel_trace.csv")
+if os.path.exists(tr):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(tr)):
+        for key in ("k_samples_lean", "k_events"):
+            if key in r["Kernel_Name"]:
+                per[key].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    bench_line = None
+    log = os.path.join(src, "trace.log")
+    if os.path.exists(log):
+        import json
+        for ln in open(log):
+            if ln.startswith('{"metric"'):
+                bench_line = json.loads(ln)
+    lines += ["", "## per-launch durations (us) in launch order", ""]
+    for key, v in per.items():
+        v.sort()
+        d = [x[1] for x in v]
+        lines.append(f"* `{key}`: " + ", ".join(f"{x:.0f}" for x in d))
+        if bench_line and len(d) >= bench_line["warmup"] + bench_line["steps"]:
+            w, k = bench_line["warmup"], bench_line["steps"]
+            timed = d[w:w + k]
+            lines.append(f"  * launches {w + 1}..{w + k} are the timed steps: mean {sum(timed) / len(timed):.1f} us"
+                         + (f"; the bench line of this very run reports kernel_ms = {1e3 * bench_line['roofline']['kernel_ms']:.1f} us (hipEvents)"
+                            if key == "k_samples_lean" else ""))
+    if bench_line:
+        with open(dst + "_bench_under_rocprof.json", "w") as fh:
+            json.dump(bench_line, fh)
+        lines.append(f"* bench line of the profiled run: `{os.path.basename(dst)}_bench_under_rocprof.json` (value {bench_line['value']:.4g} {bench_line['unit']}, "
+                     f"{bench_line['ms_per_step']:.3f} ms per step; the CPU legs are slowed by the profiler)")
 lines += ["", "## PMC counters, average per dispatch (millions)", ""]
 for f in ("pmc1", "pmc2", "pmc3"):
     path = os.path.join(src, f + "_counter_collection.csv")
