@@ -111,8 +111,9 @@ struct LeanLds {
 // One wavefront per 256 consecutive events of a read (4 per lane: the dependent global round trips of the
 // set-up are paid once per ~2300 samples; the item's descriptors are wave-uniform and live in SGPRs).
 // Per step 64 consecutive samples:
-//   64-bit slice of the event-start map (v_readlane) -> mbcnt -> event -> {state, first|I, F-1/2, sdk}
-//   (one ds_read_b128) -> jump constants (ds_read_b64) -> 2 modular multiplications -> v_log/v_sqrt/v_cos ->
+//   the step's entry of the event-start table (broadcast LDS read, a step ahead) -> mbcnt -> event -> {state, first|I, F-1/2, sdk}
+//   (one ds_read_b128) -> jump constant a^(2j+1) (ds_read_b32) -> one modular multiplication; second uniform =
+//   fract(c1 * a/M) in FP64 -> v_log/v_sqrt/v_cos ->
 //   v' = fma(x, sdk, F-1/2) -> t = v' + 1.5*2^23 (round to nearest: floor of the ADC value unless it is within
 //   eps of an integer) -> acceptance test on v' - (t - 1.5*2^23) -> int16 store of the low half of bits(t) + I.
 // The loads of step i+1 are issued before the arithmetic of step i (software pipelining, two steps unrolled
