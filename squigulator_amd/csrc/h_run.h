@@ -60,13 +60,19 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     P.use_streams = c->use_kmer_streams ? 1 : 0;
     P.rna = (c->cfg.flags & SQG_RNA) ? 1 : 0;
     P.evrec = S.d_evrec; P.tile_so = S.d_tile_so; P.tile_read = b->d_tile_read; P.stile_read = b->d_stile_read;
-    constexpr int NT = SQG_EVENT_THREADS;
+    constexpr int NT = SQG_EVENT_THREADS, NT_WIDE = 1024;
+    // few chains (the reference's default -K 1000 with one worker per read): a chain is a sequence of segments, each with
+    // its barriers and LDS round trips, and there are not enough chains to hide them -- 1024 threads per chain walk it in a
+    // quarter of the steps
+    static const int wide_max = getenv("SQG_EVENTS_WIDE_MAX") ? atoi(getenv("SQG_EVENTS_WIDE_MAX")) : 1200;   // A/B knob
     auto launch_events = [&](int dw, bool hist) {
-        const dim3 g((unsigned)b->n_chains), t(NT);
-#define EVL(D, W, H) hipLaunchKernelGGL((k_events<NT, D, W, SQG_EVENT_EPT, H>), g, t, 0, c->stream, P)
-#define EVD(D, H) do { if (dw == 0) EVL(D, 0, H); else if (dw == 1) EVL(D, 1, H); else EVL(D, 2, H); } while (0)
-        if (direct) { if (hist) EVD(true, true); else EVD(true, false); }
-        else { if (hist) EVD(false, true); else EVD(false, false); }
+        const dim3 g((unsigned)b->n_chains);
+        const bool wide = !hist && b->n_chains <= wide_max;
+#define EVL(N, D, W, H) hipLaunchKernelGGL((k_events<N, D, W, SQG_EVENT_EPT, H>), g, dim3(N), 0, c->stream, P)
+#define EVD(N, D, H) do { if (dw == 0) EVL(N, D, 0, H); else if (dw == 1) EVL(N, D, 1, H); else EVL(N, D, 2, H); } while (0)
+        if (wide) { if (direct) EVD(NT_WIDE, true, false); else EVD(NT_WIDE, false, false); }
+        else if (direct) { if (hist) EVD(NT, true, true); else EVD(NT, true, false); }
+        else { if (hist) EVD(NT, false, true); else EVD(NT, false, false); }
 #undef EVD
 #undef EVL
     };

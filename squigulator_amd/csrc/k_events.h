@@ -328,7 +328,7 @@ __device__ static inline void lds_barrier() {
 // HIST: only the front half -- dwell draws, ranks, and the samples each k-mer stream is asked for, accumulated into the
 // workgroup's row (split chains, see above)
 template <int NT, bool DIRECT, int DW, int EPT, bool HIST = false>
-__global__ __launch_bounds__(NT, SQG_EVENT_WAVES) void k_events(const SigParams P) {
+__global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events(const SigParams P) {
     typedef EvLds<NT, DIRECT, EPT> Lds;
     __shared__ Lds L;
     __shared__ long long n1_sh;
