@@ -64,7 +64,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     // few chains (the reference's default -K 1000 with one worker per read): a chain is a sequence of segments, each with
     // its barriers and LDS round trips, and there are not enough chains to hide them -- 1024 threads per chain walk it in a
     // quarter of the steps
-    static const int wide_max = getenv("SQG_EVENTS_WIDE_MAX") ? atoi(getenv("SQG_EVENTS_WIDE_MAX")) : 1200;   // A/B knob
+    const int wide_max = getenv("SQG_EVENTS_WIDE_MAX") ? atoi(getenv("SQG_EVENTS_WIDE_MAX")) : 1200;   // A/B knob
     auto launch_events = [&](int dw, bool hist) {
         const dim3 g((unsigned)b->n_chains);
         const bool wide = !hist && b->n_chains <= wide_max;

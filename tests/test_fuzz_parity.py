@@ -36,7 +36,9 @@ def _case(seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(40))
-def test_random_configuration_matches_oracle(seed):
+def test_random_configuration_matches_oracle(seed, monkeypatch):
+    if seed % 2:                                         # odd seeds: the 256-thread k_events even for these small launches
+        monkeypatch.setenv("SQG_EVENTS_WIDE_MAX", "0")
     prof, flags, k, T, amp, s, batches = _case(seed)
     mean, stdv = model.synthetic_model(k, salt=seed)
     orac = orc.Oracle(prof, flags, k, mean, stdv, s, num_workers=T, amp_noise=amp)
