@@ -100,3 +100,17 @@ def test_nine_mer_sample_counts_wrap_correctly(turns, T, monkeypatch):
     prof, fl = profiles.get_profile("dna-r10-prom")
     batches = [_reads(rng, 3 * T + 4, 9, 2000) for _ in range(3)]
     _check(prof, fl, 9, T, 1234, batches)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [1, 2, 9])
+def test_very_ragged_batches(T):
+    """reads of 1 base next to reads of 2*10^5: uneven links (T < reads), a single long chain per workgroup (T = reads),
+    segment tails of every length"""
+    rng = np.random.default_rng(77)
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    lens = [200000, 5, 64, 150000, 1, 3000, 511, 512, 513]
+    batches = [[bytes(rng.choice(list(b"ACGT"), m).astype(np.uint8)) for m in rng.permutation(lens)] for _ in range(2)]
+    _check(prof, fl, 6, T, 11, batches, modes=(api.MODE_CERTIFIED,))
+    prof, fl = profiles.get_profile("dna-r10-prom")
+    _check(prof, fl, 9, T, 11, batches[:1], modes=(api.MODE_CERTIFIED,))
