@@ -183,6 +183,8 @@ int  sqg_fetch_svb(sqg_ctx_t *ctx, sqg_batch_t *b, uint8_t *dst /* n_bytes */);
 #define SQG_SAMPLE_RNA    1u   /* whole transcripts, '+' strand, src/genread.c:311-355             */
 #define SQG_SAMPLE_CDNA   2u   /* transcripts with a strand draw (--cdna)                          */
 #define SQG_SAMPLE_TRUNC  4u   /* --trans-trunc, src/genread.c:303-309                             */
+#define SQG_SAMPLE_FULL   8u   /* --full-contigs (src/sim.c:543-549): read i of the job IS contig i, '+', as loaded;
+                                  gen_read is not called, no sampler stream moves; more reads than contigs: SQG_EINVAL */
 typedef struct {
     int32_t n_contigs;
     const char *seqs;           /* contigs back to back, as loaded (no terminators)                 */

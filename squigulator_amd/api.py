@@ -71,7 +71,7 @@ class CSample(C.Structure):
                 ("rlen", C.POINTER(C.c_int32)), ("strand", C.POINTER(C.c_char)), ("seq_off", C.POINTER(C.c_int64))]
 
 
-SAMPLE_DNA, SAMPLE_RNA, SAMPLE_CDNA, SAMPLE_TRUNC = 0, 1, 2, 4
+SAMPLE_DNA, SAMPLE_RNA, SAMPLE_CDNA, SAMPLE_TRUNC, SAMPLE_FULL = 0, 1, 2, 4, 8
 
 EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_device_count",
            "sqg_batch_stage", "sqg_batch_run", "sqg_batch_wait", "sqg_fetch_signal", "sqg_fetch_dwell",

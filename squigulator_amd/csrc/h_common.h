@@ -69,6 +69,8 @@ struct sqg_ctx {
     uint32_t* d_samp = nullptr;                                 // [nw][3] sampler stream states: ref_pos, rand_strand, rand_rlen
     GenomeParams genome{};
     bool genome_loaded = false;
+    std::vector<long long> h_contig_off;                        // host copy of the contig offsets
+    long long full_next = 0;                                    // --full-contigs: the next contig to hand out (core->total_reads)
     double samp_ratio = 1.1;                                    // attempts per accepted read seen so far (long chains)
     uint8_t* d_svb = nullptr; size_t svb_cap = 0;               // svb-zd encodings of the last compressed batch
     long long* d_svb_size = nullptr; size_t svb_size_cap = 0;   // per read
@@ -107,6 +109,7 @@ struct sqg_batch {
     std::vector<long long> h_base_off;   // per read: its segment 0 in d_bases
     std::vector<int32_t> s_ref_idx, s_ref_len, s_ref_pos, s_rlen;   // sqg_batch_sample: what gen_read returned
     std::vector<char> s_strand;
+    std::vector<long long> s_src;                                   // where each sampled read starts in the resident genome
     std::vector<long long> s_seq_off, s_read_at;                    // offsets of the reads in sqg_fetch_reads / in d_bases
     long long* h_svboff = nullptr;       // pinned, device-mapped: offsets of the svb-zd encodings (sqg_batch_compress)
     long long n_svb = -1;

@@ -44,6 +44,8 @@ extern "C" int sqg_genome_load(sqg_ctx_t* c, const sqg_genome_t* g) {
     G.trans_csum = c->d_trans_csum; G.trans_idx = c->d_trans_idx;
     G.sum = total; G.grng_b = (double)(g->rlen / 2); G.n_contigs = nc; G.n_trans = g->n_trans; G.rlen = g->rlen;
     G.flags = (int)g->mode;
+    c->h_contig_off = off;
+    c->full_next = 0;
     c->genome_loaded = true;
     return SQG_OK;
 }
@@ -127,7 +129,19 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
         int max_m = 0;
         for (int q = 0; q < n_chains; q++) max_m = std::max(max_m, chain_off[(size_t)q + 1] - chain_off[(size_t)q]);
         std::vector<long long> att_used;
-        if (max_m >= 16 && !getenv("SQG_SAMPLER_SERIAL")) {
+        if (c->genome.flags & SQG_SAMPLE_FULL) {
+            // --full-contigs (src/sim.c:543-549): the reads are the contigs themselves, in order, as loaded ('N' stays 'N')
+            if (c->full_next + n > c->genome.n_contigs) { c->err = "--full-contigs: more reads asked for than there are contigs left"; cleanup(); return SQG_EINVAL; }
+            for (int i = 0; i < n; i++) {
+                const long long q = c->full_next + i;
+                SampleRec& r = rec[(size_t)i];
+                r.src = c->h_contig_off[(size_t)q]; r.ref_idx = (int)q; r.ref_pos = 0;
+                r.rlen = (int)(c->h_contig_off[(size_t)q + 1] - c->h_contig_off[(size_t)q]);
+                r.strand = '+'; r.n_N = 0; r.ref_len = r.rlen;
+            }
+            c->full_next += n;
+            CHKS(hipMemcpyAsync(d_rec, rec.data(), rec.size() * sizeof(SampleRec), hipMemcpyHostToDevice, c->stage_stream));
+        } else if (max_m >= 16 && !getenv("SQG_SAMPLER_SERIAL")) {
             // long chains: the attempts are evaluated concurrently, 25 % more than the acceptance rate seen so far asks for
             std::vector<long long> att_off((size_t)n_chains + 1, 0);
             long long max_a = 0;
@@ -191,6 +205,8 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
     n = m;
     b->s_ref_idx.resize((size_t)n); b->s_ref_len.resize((size_t)n); b->s_ref_pos.resize((size_t)n); b->s_rlen.resize((size_t)n);
     b->s_strand.resize((size_t)n + 1); b->s_seq_off.assign(seq_off.begin(), seq_off.end()); b->s_read_at.resize((size_t)n);
+    b->s_src.resize((size_t)n);
+    for (int i = 0; i < n; i++) b->s_src[(size_t)i] = rec[(size_t)i].src;
     for (int i = 0; i < n; i++) {
         const SampleRec& q = rec[(size_t)i];
         b->s_ref_idx[(size_t)i] = q.ref_idx; b->s_ref_len[(size_t)i] = q.ref_len; b->s_ref_pos[(size_t)i] = q.ref_pos;
@@ -208,7 +224,14 @@ extern "C" int sqg_fetch_reads(sqg_ctx_t* c, sqg_batch_t* b, char* dst) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     std::vector<uint8_t> all((size_t)b->n_bases_total + 1);
     if (b->n_bases_total) HIPCHK(c, hipMemcpy(all.data(), b->d_bases, (size_t)b->n_bases_total, hipMemcpyDeviceToHost));
-    for (int i = 0; i < b->n; i++)
-        memcpy(dst + b->s_seq_off[(size_t)i], all.data() + b->h_base_off[(size_t)i] + b->s_read_at[(size_t)i], (size_t)b->s_rlen[(size_t)i]);
+    const bool rna = c->cfg.flags & SQG_RNA, prefix = c->cfg.flags & SQG_PREFIX;
+    const long long extra = prefix ? (rna ? (kPolyA + (long long)strlen(kAdaptorRna)) : ((long long)strlen(kStallDna) + (long long)strlen(kAdaptorDna))) : 0;
+    for (int i = 0; i < b->n; i++) {
+        const long long len = b->s_rlen[(size_t)i];
+        if (len + extra >= c->k)
+            memcpy(dst + b->s_seq_off[(size_t)i], all.data() + b->h_base_off[(size_t)i] + b->s_read_at[(size_t)i], (size_t)len);
+        else if (len > 0)     // shorter than a k-mer (--full-contigs only): the base buffer holds the stand-in sequence of src/gensig.c:242-245
+            HIPCHK(c, hipMemcpy(dst + b->s_seq_off[(size_t)i], c->d_genome + b->s_src[(size_t)i], (size_t)len, hipMemcpyDeviceToHost));
+    }
     return SQG_OK;
 }

@@ -310,6 +310,13 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         hipLaunchKernelGGL(k_copy_reads, dim3((unsigned)n), dim3(256), 0, c->stage_stream, c->genome, d_rec, b->d_reads, b->d_bases, n,
                            rna ? 1 : 0, prefix ? 1 : 0);
         CHKB(hipGetLastError());
+        // reads shorter than k (only --full-contigs can produce them here): the reference generates 5 events of a fixed
+        // sequence instead (src/gensig.c:242-245)
+        for (int i = 0; i < n; i++) {
+            const long long len = seq_off[i + 1] - seq_off[i];
+            const long long len0 = len + (prefix ? (rna ? (kPolyA + (long long)strlen(kAdaptorRna)) : ((long long)strlen(kStallDna) + (long long)strlen(kAdaptorDna))) : 0);
+            if (len0 < k) CHKB(hipMemcpyAsync(b->d_bases + rd[(size_t)i].base_off, kShortHack, (size_t)rd[(size_t)i].len0, hipMemcpyHostToDevice, c->stage_stream));
+        }
     }
     if (n) {
         hipLaunchKernelGGL(k_fill_tiles, dim3((unsigned)n), dim3(64), 0, c->stage_stream, b->d_reads, n, lean_ev, b->d_tile_read, b->d_stile_read);

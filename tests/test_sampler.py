@@ -152,6 +152,27 @@ def test_long_chains_on_genomes_that_reject_most_attempts(seed, tmp_path):
 
 
 @pytest.mark.gpu
+def test_full_contigs_are_handed_out_in_order_and_as_loaded(tmp_path):
+    """--full-contigs (src/sim.c:543-549): read i of the job is contig i; N and lower case stay as they are; asking for
+    more reads than contigs is an error"""
+    _run("dna-r9-prom", 6, NCOV, 1, [1], rlen=10000, oflags=0x002, mode=api.SAMPLE_FULL)
+    rng = np.random.default_rng(4)
+    contigs = [bytes(rng.choice(list(b"ACGTacgtNRY"), n, p=[.2, .2, .2, .2, .04, .04, .04, .04, .02, .01, .01]).astype(np.uint8))
+               for n in (700, 5, 2600, 64, 1300, 9000, 3)]
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(f">c{i}\n{c.decode()}\n" for i, c in enumerate(contigs)))
+    _run("dna-r9-prom", 6, str(fa), 3, [3, 2, 2], rlen=10000, oflags=0x002, mode=api.SAMPLE_FULL)
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    mean, stdv = model.synthetic_model(6)
+    gen = api.SignalGenerator(prof, fl, 6, mean, stdv, 1, num_workers=2, mode=api.MODE_CERTIFIED)
+    gen.load_genome(contigs, 10000, api.SAMPLE_FULL)
+    gen.sample(5).free()
+    with pytest.raises(api.SqgError):
+        gen.sample(3)                                    # two contigs left
+    gen.close()
+
+
+@pytest.mark.gpu
 def test_sampler_shards_equal_one_context():
     """Multi-GPU sharding of the sampler: a context that owns workers [lo, hi) draws exactly the reads the
     single-context run draws for those workers (streams are per worker; no exchange)."""
