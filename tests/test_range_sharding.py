@@ -181,3 +181,15 @@ def test_two_phase_run_misuse_is_reported():
     y = gen2.submit(reads)
     np.testing.assert_array_equal(y.signal(), want)
     y.free(); gen2.close(); gen.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_random_worker_counts_rank_counts_and_batch_sizes(seed):
+    rng = np.random.default_rng(4000 + seed)
+    name, fasta, mode, sflags, rlen = [("dna-r9-prom", NCOV, api.SAMPLE_DNA, 0, 700), ("dna-r10-prom", NCOV, api.SAMPLE_DNA, 0, 500),
+                                      ("rna004-prom", SEQUIN, api.SAMPLE_RNA, profiles.SQ_PREFIX, 10000),
+                                      ("dna-r9-prom", NCOV, api.SAMPLE_DNA, profiles.SQ_PREFIX, 400)][seed % 4]
+    T, G = int(rng.integers(1, 5)), int(rng.integers(2, 5))
+    batches = [int(rng.integers(1, 24)) for _ in range(3)]
+    _run(name, fasta, T, G, batches, rlen, sflags=sflags, mode=mode, seed=int(rng.integers(1, 1 << 20)))
