@@ -169,8 +169,8 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     }
     {
         const sqg_profile_t& q = cfg->profile;
-        const double a = std::floor(q.dwell_mean + 6.5546 * std::fabs(q.dwell_std) + 0.5);
-        const double z = std::floor(std::fabs(q.dwell_mean - 6.5546 * std::fabs(q.dwell_std)) + 0.5) + 1.0;
+        const double a = std::floor(q.dwell_mean + 6.5556 * std::fabs(q.dwell_std) + 0.5);
+        const double z = std::floor(std::fabs(q.dwell_mean - 6.5556 * std::fabs(q.dwell_std)) + 0.5) + 1.0;
         c->dwell_hi = c->use_dwell_stream ? std::max(std::max(a, z), 1.0) + 1.0 : (double)(int)q.dwell_mean;
         // lean-kernel work item = 64*epl events: the largest epl whose items stay below LEAN_MAX_SAMPLES samples
         // (mean + 6 sigma of the item total; the rare longer item is left to the generic kernel)

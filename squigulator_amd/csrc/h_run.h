@@ -58,6 +58,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     P.chain_order = b->d_chain_order; P.delta_x = c->delta_x; P.thr_all = c->thr_all;
     P.k = c->k; P.num_kmer = c->num_kmer; P.const_sps = (int)p.dwell_mean;
     P.use_streams = c->use_kmer_streams ? 1 : 0;
+    P.dwell_unbounded = c->dwell_hi > 65535.0 ? 1 : 0;
     P.rna = (c->cfg.flags & SQG_RNA) ? 1 : 0;
     P.evrec = S.d_evrec; P.tile_so = S.d_tile_so; P.tile_read = b->d_tile_read; P.stile_read = b->d_stile_read;
     constexpr int NT = SQG_EVENT_THREADS, NT_WIDE = 1024;
@@ -156,7 +157,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         HIPCHK(c, hipGetLastError());
         if ((rc = dbg_sync(c, "k_scan"))) return rc;
     } else HIPCHK(c, hipMemsetAsync(S.d_fix_count, 0, 4 * sizeof(unsigned int), c->stream));
-    // Output size is data-dependent.  A hard bound exists (|z| <= sqrt(2 ln(2^31-1)) = 6.5546 for any
+    // Output size is data-dependent.  A hard bound exists (|z| <= sqrt(2 ln(2^31-1)) = 6.5556 for any
     // draw), so the slab is sized by it and the launches continue without a host round trip; only
     // if that bound is unreasonable (huge dwell spread) is the scan read back first.
     if (n == 0) b->h_sigoff[0] = 0;

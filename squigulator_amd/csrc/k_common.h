@@ -177,6 +177,7 @@ struct SigParams {
     float thr_all;               // 1/2 - (largest eps over all k-mers): acceptance threshold of the lean kernel
     int k, num_kmer;
     int const_sps;               // (int)dwell_mean, used when dwell == null
+    int dwell_unbounded;         // the hard bound of a dwell draw (|z| <= 6.5556) exceeds 65535: k_events checks every draw
     int use_streams;             // 0 in --ideal / --ideal-amp (src/gensig.c:265-269)
     int rna;                     // reverse the signal (src/gensig.c:348-354)
     int shift_len;               // RNA+prefix: 79*(int)dwell_mean samples get -shift (src/genread.c:79-86)

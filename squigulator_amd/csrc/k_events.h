@@ -441,8 +441,8 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
                         if (fabsf(g - fl) < 0.5f - dw_eps && c1 <= LCG_M - (1u << NEAR_ONE_BITS)) { v = (int)__float_as_uint(t) - 0x4b400000; decided = true; }
                     }
                     if (!decided) v = dwell_exact(c1, P.dstd, P.dmean);      // src/gensig.c:255
-                    v = v < 1 ? -v + 1 : v;                                  // src/gensig.c:256
-                    if (v > 65535) { atomicOr(P.err, 1u); v = 65535; }
+                    v = max(v, 1 - v);                                       // src/gensig.c:256: sps < 1 ? -sps + 1 : sps
+                    if (P.dwell_unbounded && v > 65535) { atomicOr(P.err, 1u); v = 65535; }   // else: no draw can get there
                     sps[q] = v;
                     P.dwell_out[rd.ev_off + e] = (uint16_t)v;
                 }
