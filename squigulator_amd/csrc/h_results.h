@@ -32,12 +32,7 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
         if (c->cfg.mode == SQG_MODE_CERTIFIED) {
             unsigned int cnt[4] = {0, 0, 0, 0};
             HIPCHK(c, hipMemcpy(cnt, S.d_fix_count, sizeof cnt, hipMemcpyDeviceToHost));
-            nfix = cnt[0];                                  // global list ...
-            if (c->use_kmer_streams && b->n_stiles > 0) {   // ... plus the per-tile slots of the lean kernel
-                std::vector<unsigned char> tn((size_t)b->n_stiles);
-                HIPCHK(c, hipMemcpy(tn.data(), S.d_tfix_n, tn.size(), hipMemcpyDeviceToHost));
-                for (unsigned char v : tn) nfix += v;
-            }
+            nfix = cnt[0] + cnt[2];                         // global list + the per-item slots of the lean kernel (counted by k_fixup_tiles)
         }
         c->timing.dwell_ms = d; c->timing.samples_ms = s; c->timing.total_ms = t; c->timing.fallback_samples = nfix;
         b->waited = true;

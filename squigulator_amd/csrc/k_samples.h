@@ -480,6 +480,7 @@ __global__ __launch_bounds__(256) void k_fixup_tiles(const SigParams P, const in
     const int incl = wave_incl_scan_dpp(n);
     const int total = __builtin_amdgcn_readlane(incl, 63);
     if (total == 0) return;
+    if (lane == 0) atomicAdd(P.fix_count + 2, (unsigned int)total);   // statistics: samples parked per item (sqg_get_timing)
     for (int q = 0; q < n; q++) work[wid][incl - n + q] = (uint16_t)((lane << 4) | q);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     for (int w = lane; w < total; w += 64) {
