@@ -68,6 +68,7 @@ struct sqg_ctx {
     float* d_trans_csum = nullptr; int* d_trans_idx = nullptr;
     uint32_t* d_samp = nullptr;                                 // [nw][3] sampler stream states: ref_pos, rand_strand, rand_rlen
     GenomeParams genome{};
+    uint8_t* d_samp_scratch = nullptr; size_t samp_scratch_cap = 0;   // sqg_batch_sample: records, chain lists, attempt slots
     bool genome_loaded = false;
     std::vector<long long> h_contig_off;                        // host copy of the contig offsets
     long long full_next = 0;                                    // --full-contigs: the next contig to hand out (core->total_reads)

@@ -111,23 +111,43 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
     std::vector<int> fill(chain_off.begin(), chain_off.end() - 1), chain_reads((size_t)n);
     for (int i = 0; i < n; i++) chain_reads[(size_t)fill[(size_t)chain_of[(size_t)wk[(size_t)i]]]++] = i;
 
-    SampleRec* d_rec = nullptr;
-    int *d_co = nullptr, *d_cr = nullptr, *d_cw = nullptr;
-    SampleRec* d_try = nullptr; unsigned char* d_ok = nullptr; long long* d_ao = nullptr;
+    // device scratch of the sampler: one grow-only allocation of the context, carved per call (every call ends with the
+    // staging stream drained, so nothing of the previous call is still in use)
+    int max_m = 0;
+    for (int q = 0; q < n_chains; q++) max_m = std::max(max_m, chain_off[(size_t)q + 1] - chain_off[(size_t)q]);
+    const bool concurrent = n > 0 && !(c->genome.flags & SQG_SAMPLE_FULL) && max_m >= 16 && !getenv("SQG_SAMPLER_SERIAL");
+    std::vector<long long> att_off((size_t)n_chains + 1, 0);
+    long long max_a = 0;
+    if (concurrent)    // long chains: the attempts are evaluated concurrently, 25 % more than the acceptance rate seen so far asks for
+        for (int q = 0; q < n_chains; q++) {
+            const long long m = chain_off[(size_t)q + 1] - chain_off[(size_t)q];
+            const long long a = (long long)std::ceil((double)m * c->samp_ratio * 1.25) + 64;
+            att_off[(size_t)q + 1] = att_off[(size_t)q] + a; max_a = std::max(max_a, a);
+        }
+    const size_t na = (size_t)att_off.back();
+    size_t top = 0;
+    auto room = [&](size_t bytes) { const size_t o = top; top += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t o_rec = room(std::max<size_t>(1, (size_t)n) * sizeof(SampleRec)), o_co = room(chain_off.size() * sizeof(int)),
+                 o_cr = room(std::max<size_t>(1, chain_reads.size()) * sizeof(int)), o_cw = room(std::max<size_t>(1, chain_worker.size()) * sizeof(int)),
+                 o_try = room(na * sizeof(SampleRec)), o_ok = room(na), o_ao = room((att_off.size() + (size_t)n_chains) * sizeof(long long));
+    if (top > c->samp_scratch_cap) {
+        (void)hipStreamSynchronize(c->stage_stream);
+        (void)hipFree(c->d_samp_scratch); c->d_samp_scratch = nullptr; c->samp_scratch_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_samp_scratch, top + top / 4));
+        c->samp_scratch_cap = top + top / 4;
+    }
+    uint8_t* const sb = c->d_samp_scratch;
+    SampleRec* d_rec = (SampleRec*)(sb + o_rec);
+    int *d_co = (int*)(sb + o_co), *d_cr = (int*)(sb + o_cr), *d_cw = (int*)(sb + o_cw);
+    SampleRec* d_try = (SampleRec*)(sb + o_try); unsigned char* d_ok = sb + o_ok; long long* d_ao = (long long*)(sb + o_ao);
     std::vector<SampleRec> rec((size_t)n);
     int rc = SQG_OK;
-    auto cleanup = [&]() { (void)hipFree(d_rec); (void)hipFree(d_co); (void)hipFree(d_cr); (void)hipFree(d_cw); (void)hipFree(d_try); (void)hipFree(d_ok); (void)hipFree(d_ao); };
+    auto cleanup = [&]() {};
 #define CHKS(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE; } } while (0)
-    CHKS(hipMalloc(&d_rec, std::max<size_t>(1, (size_t)n) * sizeof(SampleRec)));
     if (n > 0) {
-        CHKS(hipMalloc(&d_co, chain_off.size() * sizeof(int)));
-        CHKS(hipMalloc(&d_cr, chain_reads.size() * sizeof(int)));
-        CHKS(hipMalloc(&d_cw, chain_worker.size() * sizeof(int)));
         CHKS(hipMemcpyAsync(d_co, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
         CHKS(hipMemcpyAsync(d_cr, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
         CHKS(hipMemcpyAsync(d_cw, chain_worker.data(), chain_worker.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
-        int max_m = 0;
-        for (int q = 0; q < n_chains; q++) max_m = std::max(max_m, chain_off[(size_t)q + 1] - chain_off[(size_t)q]);
         std::vector<long long> att_used;
         if (c->genome.flags & SQG_SAMPLE_FULL) {
             // --full-contigs (src/sim.c:543-549): the reads are the contigs themselves, in order, as loaded ('N' stays 'N')
@@ -141,19 +161,7 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
             }
             c->full_next += n;
             CHKS(hipMemcpyAsync(d_rec, rec.data(), rec.size() * sizeof(SampleRec), hipMemcpyHostToDevice, c->stage_stream));
-        } else if (max_m >= 16 && !getenv("SQG_SAMPLER_SERIAL")) {
-            // long chains: the attempts are evaluated concurrently, 25 % more than the acceptance rate seen so far asks for
-            std::vector<long long> att_off((size_t)n_chains + 1, 0);
-            long long max_a = 0;
-            for (int q = 0; q < n_chains; q++) {
-                const long long m = chain_off[(size_t)q + 1] - chain_off[(size_t)q];
-                const long long a = (long long)std::ceil((double)m * c->samp_ratio * 1.25) + 64;
-                att_off[(size_t)q + 1] = att_off[(size_t)q] + a; max_a = std::max(max_a, a);
-            }
-            const size_t na = (size_t)att_off.back();
-            CHKS(hipMalloc(&d_try, na * sizeof(SampleRec)));
-            CHKS(hipMalloc(&d_ok, na));
-            CHKS(hipMalloc(&d_ao, (att_off.size() + (size_t)n_chains) * sizeof(long long)));
+        } else if (concurrent) {
             long long* d_used = d_ao + att_off.size();
             CHKS(hipMemcpyAsync(d_ao, att_off.data(), att_off.size() * sizeof(long long), hipMemcpyHostToDevice, c->stage_stream));
             hipLaunchKernelGGL(k_sample_try, dim3((unsigned)((max_a + 3) / 4), (unsigned)n_chains), dim3(256), 0, c->stage_stream, c->genome, c->d_samp,
