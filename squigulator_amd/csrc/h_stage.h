@@ -239,7 +239,9 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
             }
     };
     {
-        const int nth = (n_wchains >= 1024) ? (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        // (starting a thread costs about as much as the draws of 300 reads)
+        const int want = n_wchains >= 16384 ? 8 : n_wchains >= 6144 ? 4 : n_wchains >= 3072 ? 2 : 1;
+        const int nth = (int)std::min<unsigned>((unsigned)want, std::max(1u, std::thread::hardware_concurrency()));
         if (nth <= 1) chain_range(0, n_wchains);
         else {
             std::vector<std::thread> th;
