@@ -45,7 +45,8 @@ struct sqg_ctx {
     bool range_mode = false;                       // range sharding (sqg_set_range_mode): every batch is cut into links and run in two phases
     uint32_t* d_xcounts = nullptr; size_t xcounts_cap = 0;       // [nw][num_kmer] samples the running batch draws per stream (sqg_batch_run_begin)
     // device block, pinned offsets and events of freed batches, kept for the next sqg_batch_stage / sqg_batch_sample
-    struct Recycled { uint8_t* d_block; size_t block_bytes; long long* h_sigoff; long long* h_sigoff_dev; size_t h_n; hipEvent_t ev[8]; };
+    struct Recycled { uint8_t* d_block; size_t block_bytes; long long* h_sigoff; long long* h_sigoff_dev; size_t h_n; hipEvent_t ev[8];
+                      uint8_t* h_meta; size_t h_meta_bytes; hipEvent_t ev_staged; };
     std::vector<Recycled> pool;
     hipStream_t stage_stream = nullptr;            // uploads and the staging kernels (k_sample, k_copy_reads, k_fill_tiles): a host
                                                    // can stage batch i+1 while batch i runs
@@ -116,6 +117,8 @@ struct sqg_batch {
     long long n_svb = -1;
     unsigned long long compress_seq = 0;
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel-phase boundaries; [7]: the event side is done
+    uint8_t* h_meta = nullptr; size_t h_meta_bytes = 0;   // pinned: the host-built arrays of the batch (descriptors, chain lists), uploaded in one copy
+    hipEvent_t ev_staged = nullptr;      // recorded on the staging stream after the batch's last staging operation
     int slot = 0;                        // which of the context's two buffer sets this batch runs in
     unsigned long long run_idx = 0;      // how many batches had been run before this one
     bool ran = false, waited = false, lean_timed = false, dwell_timed = false;

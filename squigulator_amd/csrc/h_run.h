@@ -20,6 +20,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     if (phase != 2) {
         // this slot's buffers were last used by the sample kernels of batch seq-2 (stream2)
         HIPCHK(c, hipStreamWaitEvent(c->stream, S.done, 0));
+        if (b->ev_staged) HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_staged, 0));     // the batch's uploads and staging kernels
         auto grow = [&](sqg_ctx::Slot& Z) -> int { return grow_slot(c, Z, b, /*with_output=*/false); };
         b->other_fresh = other.reads_cap == 0 && n > 0;
         if ((rc = grow(S))) return rc;

@@ -230,6 +230,7 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
 extern "C" int sqg_fetch_reads(sqg_ctx_t* c, sqg_batch_t* b, char* dst) {
     if (!c || !b || !dst || b->s_seq_off.empty()) return SQG_EINVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (b->ev_staged) HIPCHK(c, hipEventSynchronize(b->ev_staged));     // the base buffer is filled on the staging stream
     std::vector<uint8_t> all((size_t)b->n_bases_total + 1);
     if (b->n_bases_total) HIPCHK(c, hipMemcpy(all.data(), b->d_bases, (size_t)b->n_bases_total, hipMemcpyDeviceToHost));
     const bool rna = c->cfg.flags & SQG_RNA, prefix = c->cfg.flags & SQG_PREFIX;

@@ -11,16 +11,20 @@ extern "C" void sqg_batch_free(sqg_ctx_t* ctx, sqg_batch_t* b) {
     // never run (or only begun): the batches staged after it must not wait for it.  Its share of the workers' scalar streams
     // is spent all the same: what follows is no longer the reference's sequence.
     if (ctx && b->staged && !b->ran) { if (b->begun && ctx->stream) (void)hipStreamSynchronize(ctx->stream); ctx->abandoned.insert(b->seq); }
+    if (ctx && !b->ran && ctx->stage_stream) (void)hipStreamSynchronize(ctx->stage_stream);   // its uploads may still be in flight
     if (b->h_svboff) (void)hipHostFree(b->h_svboff);
     if (ctx && b->d_block && b->h_sigoff && b->ev[0] && ctx->pool.size() < 4) {
         sqg_ctx::Recycled r;
         r.d_block = b->d_block; r.block_bytes = b->block_bytes; r.h_sigoff = b->h_sigoff; r.h_sigoff_dev = b->h_sigoff_dev; r.h_n = b->h_n;
         for (int i = 0; i < 8; i++) r.ev[i] = b->ev[i];
+        r.h_meta = b->h_meta; r.h_meta_bytes = b->h_meta_bytes; r.ev_staged = b->ev_staged;
         ctx->pool.push_back(r);
     } else {
         (void)hipFree(b->d_block);
         if (b->h_sigoff) (void)hipHostFree(b->h_sigoff);
+        if (b->h_meta) (void)hipHostFree(b->h_meta);
         for (auto& e : b->ev) if (e) (void)hipEventDestroy(e);
+        if (b->ev_staged) (void)hipEventDestroy(b->ev_staged);
     }
     delete b;
 }
@@ -271,21 +275,27 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     st_mark("chains+streams+blocks");
     auto bail = [&](int code) { sqg_batch_free(c, b); return code; };
 #define CHKB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE); } } while (0)
+    size_t meta_bytes = 0, mo_reads = 0, mo_blk = 0, mo_coff = 0, mo_crd = 0, mo_ord = 0, mo_wlo = 0, mo_wlw = 0;
     {   // one device allocation per batch, carved into the batch's arrays (256-byte aligned)
         size_t off = 0;
         auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-        const size_t o_bases = carve((size_t)nb + 16), o_reads = carve(std::max<size_t>(1, rd.size()) * sizeof(ReadDesc)),
+        // the host-built arrays first and back to back: they go up in one copy from the batch's pinned mirror
+        const size_t o_reads = carve(std::max<size_t>(1, rd.size()) * sizeof(ReadDesc)),
                      o_blk = carve(blk_read.size() * sizeof(int)), o_coff = carve(chain_off.size() * sizeof(int)),
                      o_crd = carve(std::max<size_t>(1, chain_reads.size()) * sizeof(int)),
-                     o_st = carve((size_t)std::max<long long>(nst, 1) * sizeof(int)), o_t = carve((size_t)std::max<long long>(ntile, 1) * sizeof(int)),
                      o_ord = carve(std::max<size_t>(1, chain_order.size()) * sizeof(int)),
                      o_wlo = carve(wlink_off.size() * sizeof(int)), o_wlw = carve(std::max<size_t>(1, wlink_worker.size()) * sizeof(int));
+        meta_bytes = off;
+        const size_t o_bases = carve((size_t)nb + 16),
+                     o_st = carve((size_t)std::max<long long>(nst, 1) * sizeof(int)), o_t = carve((size_t)std::max<long long>(ntile, 1) * sizeof(int));
+        mo_reads = o_reads; mo_blk = o_blk; mo_coff = o_coff; mo_crd = o_crd; mo_ord = o_ord; mo_wlo = o_wlo; mo_wlw = o_wlw;
         // a freed batch's block, pinned offsets and events are reused when they are large enough
         for (size_t pi = 0; pi < c->pool.size(); pi++) {
             sqg_ctx::Recycled& r = c->pool[pi];
-            if (r.block_bytes >= off && r.h_n >= (size_t)n + 1) {
+            if (r.block_bytes >= off && r.h_n >= (size_t)n + 1 && r.h_meta_bytes >= meta_bytes) {
                 b->d_block = r.d_block; b->block_bytes = r.block_bytes; b->h_sigoff = r.h_sigoff; b->h_sigoff_dev = r.h_sigoff_dev; b->h_n = r.h_n;
                 for (int i = 0; i < 8; i++) b->ev[i] = r.ev[i];
+                b->h_meta = r.h_meta; b->h_meta_bytes = r.h_meta_bytes; b->ev_staged = r.ev_staged;
                 c->pool.erase(c->pool.begin() + (long)pi);
                 break;
             }
@@ -293,11 +303,14 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         if (!b->d_block) {
             if (c->pool.size() >= 4) {                      // nothing fits: make room
                 sqg_ctx::Recycled& r = c->pool.front();
-                (void)hipFree(r.d_block); (void)hipHostFree(r.h_sigoff); for (auto& e : r.ev) if (e) (void)hipEventDestroy(e);
+                (void)hipFree(r.d_block); (void)hipHostFree(r.h_sigoff); (void)hipHostFree(r.h_meta); for (auto& e : r.ev) if (e) (void)hipEventDestroy(e);
+                if (r.ev_staged) (void)hipEventDestroy(r.ev_staged);
                 c->pool.erase(c->pool.begin());
             }
             b->block_bytes = off + off / 8;                 // slack: the next batches are about this size
             CHKB(hipMalloc(&b->d_block, b->block_bytes));
+            b->h_meta_bytes = meta_bytes + meta_bytes / 8;
+            CHKB(hipHostMalloc(&b->h_meta, b->h_meta_bytes, hipHostMallocDefault));
         }
         uint8_t* base = b->d_block;
         b->d_bases = base + o_bases; b->d_reads = (ReadDesc*)(base + o_reads); b->d_blk_read = (int*)(base + o_blk);
@@ -305,9 +318,21 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         b->d_tile_read = (int*)(base + o_t); b->d_chain_order = (int*)(base + o_ord);
         b->d_wlink_off = (int*)(base + o_wlo); b->d_wlink_worker = (int*)(base + o_wlw);
     }
+    {   // the host-built arrays -> pinned mirror -> one asynchronous copy
+        uint8_t* m = b->h_meta;
+        if (n) memcpy(m + mo_reads, rd.data(), rd.size() * sizeof(ReadDesc));
+        memcpy(m + mo_blk, blk_read.data(), blk_read.size() * sizeof(int));
+        memcpy(m + mo_coff, chain_off.data(), chain_off.size() * sizeof(int));
+        if (n) memcpy(m + mo_crd, chain_reads.data(), chain_reads.size() * sizeof(int));
+        if (b->n_chains) memcpy(m + mo_ord, chain_order.data(), chain_order.size() * sizeof(int));
+        if (b->split) {
+            memcpy(m + mo_wlo, wlink_off.data(), wlink_off.size() * sizeof(int));
+            memcpy(m + mo_wlw, wlink_worker.data(), wlink_worker.size() * sizeof(int));
+        }
+        CHKB(hipMemcpyAsync(b->d_block, m, meta_bytes, hipMemcpyHostToDevice, c->stage_stream));
+    }
     if (seqs) CHKB(hipMemcpyAsync(b->d_bases, hb.data(), hb.size(), hipMemcpyHostToDevice, c->stage_stream));
     else CHKB(hipMemsetAsync(b->d_bases + nb, 'A', 16, c->stage_stream));
-    if (n) CHKB(hipMemcpyAsync(b->d_reads, rd.data(), rd.size() * sizeof(ReadDesc), hipMemcpyHostToDevice, c->stage_stream));
     if (!seqs && n) {                                      // the reads come from the resident genome
         hipLaunchKernelGGL(k_copy_reads, dim3((unsigned)n), dim3(256), 0, c->stage_stream, c->genome, d_rec, b->d_reads, b->d_bases, n,
                            rna ? 1 : 0, prefix ? 1 : 0);
@@ -327,22 +352,18 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     b->n_bases_total = nb;
     b->h_base_off.resize((size_t)n);
     for (int i = 0; i < n; i++) b->h_base_off[(size_t)i] = rd[(size_t)i].base_off;
-    CHKB(hipMemcpyAsync(b->d_blk_read, blk_read.data(), blk_read.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
-    CHKB(hipMemcpyAsync(b->d_chain_off, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
-    if (n) CHKB(hipMemcpyAsync(b->d_chain_reads, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
-    if (b->n_chains) CHKB(hipMemcpyAsync(b->d_chain_order, chain_order.data(), chain_order.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
-    if (b->split) {
-        CHKB(hipMemcpyAsync(b->d_wlink_off, wlink_off.data(), wlink_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
-        CHKB(hipMemcpyAsync(b->d_wlink_worker, wlink_worker.data(), wlink_worker.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
-    }
     if (!b->h_sigoff) {
         b->h_n = (size_t)n + 1 + (size_t)n / 8;
         CHKB(hipHostMalloc(&b->h_sigoff, b->h_n * sizeof(long long), hipHostMallocMapped));
         CHKB(hipHostGetDevicePointer((void**)&b->h_sigoff_dev, b->h_sigoff, 0));
         for (auto& e : b->ev) CHKB(hipEventCreate(&e));
+        CHKB(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming));
     }
+    CHKB(hipEventRecord(b->ev_staged, c->stage_stream));   // sqg_batch_run waits for it on its own stream
     st_mark("mallocs+enqueue");
-    CHKB(hipStreamSynchronize(c->stage_stream));     // staging buffers above are stack-owned (only the staging stream: a running batch is not waited for)
+    // the read bytes of sqg_batch_stage come from the caller's (pageable) buffer through a stack-owned copy: wait for that
+    // upload.  Everything else sits in memory the batch owns, and the staging stream is left running.
+    if (seqs) CHKB(hipStreamSynchronize(c->stage_stream));
     st_mark("sync");
 #undef CHKB
     // slots that have never held a batch are sized now, so that not even the first run allocates
