@@ -62,3 +62,17 @@ def test_worker_sharding_is_a_partition():
         assert seen == list(range(T))
     idx, wk = shard.shard_batch(10, 4, 1, 2)
     assert list(idx) == [6, 7, 8, 9] and list(wk) == [2, 2, 2, 3]
+
+
+def test_read_ranges_partition_every_batch():
+    """range sharding: the ranks' ranges are contiguous, disjoint, in rank order and cover the batch (also when there
+    are fewer reads than ranks)"""
+    from squigulator_amd import shard
+    for n in (0, 1, 2, 7, 8, 9, 1000, 32768):
+        for world in (1, 2, 3, 8):
+            cuts = [shard.read_range(r, world, n) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+            assert all(lo <= hi for lo, hi in cuts)
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
