@@ -144,8 +144,6 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     HIPCHK(c, hipEventRecord(b->ev[3], c->stream));
     if (n > 0) {
         // the scan also writes the offsets through the batch's pinned host mapping (no copy between kernels)
-        // (k_items, when it runs, does that part with more parallelism)
-        const bool items_run = certified && c->use_kmer_streams && b->n_chains > 0 && c->dwell_hi * (double)b->n_events <= 4.0e10;
         const unsigned scan_wgs = (unsigned)((n + SCAN_WG - 1) / SCAN_WG);
         {
             const size_t cap0 = c->scan_part_cap;
@@ -153,7 +151,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             if (c->scan_part_cap != cap0)                         // tickets start at 1: a fresh array must not hold one by accident
                 HIPCHK(c, hipMemsetAsync(c->d_scan_part, 0, c->scan_part_cap * sizeof(unsigned long long), c->stream));
         }
-        hipLaunchKernelGGL(k_scan, dim3(scan_wgs), dim3(SCAN_WG), 0, c->stream, S.d_seglen, n, S.d_sigoff, items_run ? nullptr : b->h_sigoff_dev,
+        hipLaunchKernelGGL(k_scan, dim3(scan_wgs), dim3(SCAN_WG), 0, c->stream, S.d_seglen, n, S.d_sigoff, b->h_sigoff_dev,
                            c->d_err, S.d_fix_count, c->d_scan_part, b->run_idx + 1);
         HIPCHK(c, hipGetLastError());
         if ((rc = dbg_sync(c, "k_scan"))) return rc;
@@ -200,7 +198,10 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             unsigned lgrid = (unsigned)((n_stiles + 3) / 4);
             static const int lean_grid_cap = getenv("SQG_LEAN_GRID") ? atoi(getenv("SQG_LEAN_GRID")) : 0;   // A/B knob
             if (lean_grid_cap > 0) lgrid = std::min(lgrid, (unsigned)lean_grid_cap);
-            hipLaunchKernelGGL(k_items, dim3((unsigned)((std::max(n_stiles, n + 1) + 255) / 256)), dim3(256), 0, c->stream, P, n_stiles, n, b->h_sigoff_dev);
+            // work items of 256 events (4 per lane) look their descriptor up themselves, on the scalar unit; with shorter
+            // items (profiles with long dwells) the look-up chain per item is worth a kernel of its own
+            if (c->lean_epl < 4) hipLaunchKernelGGL(k_items, dim3((unsigned)((n_stiles + 255) / 256)), dim3(256), 0, c->stream, P, n_stiles, n, nullptr);
+            else P.items = nullptr;
             HIPCHK(c, hipEventRecord(b->ev[7], c->stream));              // event side done: the sample kernels may start ...
             HIPCHK(c, hipStreamWaitEvent(c->stream2, b->ev[7], 0));      // ... on their own stream, next to the next batch's k_events
             HIPCHK(c, hipEventRecord(b->ev[5], c->stream2));

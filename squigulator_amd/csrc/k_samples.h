@@ -44,12 +44,13 @@ __device__ static inline void push_fix_one(const SigParams& P, long long at, uin
 #define FIX_SLOTS 8                        // parked undecided samples per super tile (expected ~0.5); overflow -> global list
 #define LEAN_MAX_SAMPLES 4096              // samples per work item the 64x64-bit start map covers
 
-// k_items: one thread per 256-event super tile.  Collapses the dependent look-ups of the lean kernel's set-up
+// k_items: one thread per super tile, for profiles whose items are short (LEAN_EPL < 4; with 4 events per lane the lean
+// kernel does this itself on the scalar unit).  Collapses the dependent look-ups of the lean kernel's set-up
 // (tile -> read -> tile_so / sig_off / seglen) into one record per item and decides which items the lean
 // kernel takes; the others are queued (as 64-event tiles) for k_samples<MODE, GENERIC>.
 __global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_stiles, const int n_reads, long long* __restrict__ host_off) {
     const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g <= n_reads) host_off[g] = P.sig_off[g];                      // read offsets to the host through the pinned mapping
+    if (host_off && g <= n_reads) host_off[g] = P.sig_off[g];          // (the scan writes the host's copy of the offsets itself)
     if (g >= n_stiles) return;
     const int r = P.stile_read[g];
     const ReadDesc rd = P.reads[r];
@@ -91,6 +92,21 @@ __global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_st
     P.tfix_n[g] = 0;
 }
 
+// load through the constant address space: for a wave-uniform address this is a scalar load (the arrays read this way
+// were written by earlier kernels of the stream)
+template <typename T>
+__device__ static inline T sload(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "dword granularity");
+    const __attribute__((address_space(4))) uint32_t* src =
+        reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(p));
+    uint32_t w[sizeof(T) / 4];
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(T) / 4); q++) w[q] = src[q];
+    T v;
+    __builtin_memcpy(&v, w, sizeof v);
+    return v;
+}
+
 template <int EPL>
 struct LeanWaveLds {
     uint4 rec[64 * EPL];                // {c_ev, (4*first sample) << 16 | I (16 bits), F - 1/2, sdk}
@@ -130,16 +146,52 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
     const char* mult_b = reinterpret_cast<const char*>(L.mult);
 
     for (int g = blockIdx.x * 4 + wid; g < n_stiles; g += gridDim.x * 4) {
-        // the item's descriptor is wave-uniform: scalar load (the constant address space forces s_load; k_items wrote it
-        // before this kernel started)
+        // the item's descriptor -- what the read, its 64-event tiles and the scanned read offsets say about this item -- is
+        // wave-uniform: the whole look-up chain runs on the scalar unit (sload: constant-address-space loads)
         ItemDesc it;
-        {
-            const __attribute__((address_space(4))) uint32_t* src =
-                reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(P.items + g));
-            uint32_t w[sizeof(ItemDesc) / 4];
-#pragma unroll
-            for (int q = 0; q < (int)(sizeof(ItemDesc) / 4); q++) w[q] = src[q];
-            __builtin_memcpy(&it, w, sizeof it);
+        if constexpr (LEAN_EPL < 4) {                                   // short items (1-2 events per lane): k_items prepared the descriptors
+            it = sload(P.items + g);
+            if (it.n_ev == 0) continue;                                // not taken, or empty
+        } else {
+            const int r = sload(P.stile_read + g);
+            const ReadDesc rd = sload(P.reads + r);
+            constexpr int LEAN_EV = 64 * LEAN_EPL;
+            const int lt = g - rd.stile_off;                           // item within the read
+            const int ne_read = rd.ne0 + rd.ne1;
+            const int n_ev = min(LEAN_EV, ne_read - lt * LEAN_EV);
+            const long long sig_base = sload(P.sig_off + r);
+            const uint32_t read_len = (uint32_t)(sload(P.sig_off + r + 1) - sig_base);
+            const uint32_t base_pos = sload(P.tile_so + rd.tile_off + lt * LEAN_EPL);
+            const uint32_t next_pos = (lt + 1) * LEAN_EV < ne_read ? sload(P.tile_so + rd.tile_off + (lt + 1) * LEAN_EPL) : read_len;
+            const int n_samples = (int)(next_pos - base_pos);
+            const bool take = rd.fast != 0 && n_samples <= LEAN_MAX_SAMPLES && n_samples > 0;
+            if (!take) {                                               // leave these (up to LEAN_EPL) 64-event tiles to the generic kernel
+                if (lane == 0) {
+                    const int nt = (n_ev + 63) >> 6;
+                    const unsigned int q = atomicAdd(P.slow_count, (unsigned int)nt);
+                    for (int i = 0; i < nt; i++) P.slow_tiles[q + i] = rd.tile_off + lt * LEAN_EPL + i;
+                    P.tfix_n[g] = 0;
+                }
+                continue;
+            }
+            int shift_lo = 0, shift_hi = 0;
+            if (RNA && P.shift_len > 0) {                              // RNA adaptor level-shift window (src/genread.c:79-86)
+                const long long n1 = (long long)sload(P.seglen + 2 * r);
+                if ((long long)base_pos + n_samples > n1 - P.shift_len && (long long)base_pos < n1) {
+                    shift_lo = (int)max(n1 - P.shift_len - (long long)base_pos, 0LL);
+                    shift_hi = (int)min(n1 - (long long)base_pos, (long long)n_samples);
+                }
+            }
+            it.ev_first = rd.ev_off + (long long)lt * LEAN_EV;
+            it.sig_base = sig_base;
+            it.offset = rd.offset;
+            it.n_ev = n_ev;
+            it.n_samples = n_samples;
+            it.at0 = RNA ? read_len - 1u - base_pos : base_pos;
+            it.ev_read0 = lt * LEAN_EV;
+            it.read = r;
+            it.shift_lo = shift_lo; it.shift_hi = shift_hi;
+            it.pad = 0;
         }
         const int ne = it.n_ev;                                         // events of this item
         if (ne == 0) continue;                                         // not taken, or empty
@@ -295,7 +347,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         #undef LEAN_STORE_COND
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         const int nfix = W.nfix;
-        if (nfix && lane == 0) P.tfix_n[g] = (unsigned char)min(nfix, FIX_SLOTS);
+        if ((LEAN_EPL == 4 || nfix) && lane == 0) P.tfix_n[g] = (unsigned char)min(nfix, FIX_SLOTS);   // (k_items cleared it for the short items)
     }
 }
 
