@@ -127,7 +127,11 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     // default keeps one stream and clean per-kernel timings).  Batches are double-buffered either way.
     if (getenv("SQG_OVERLAP")) CHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     else c->stream2 = c->stream;
-    CHK(hipStreamCreateWithFlags(&c->fix_stream, hipStreamNonBlocking));
+    {   // lowest priority: the fix-ups fill the gaps of the next batch's k_events, they must not take its slots
+        int prio_lo = 0, prio_hi = 0;
+        CHK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+        CHK(hipStreamCreateWithPriority(&c->fix_stream, hipStreamNonBlocking, prio_lo));
+    }
     for (auto& S : c->slot) {
         CHK(hipMalloc(&S.d_fix_count, 4 * sizeof(unsigned int)));
         CHK(hipMemset(S.d_fix_count, 0, 4 * sizeof(unsigned int)));
