@@ -123,8 +123,8 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     CHK(hipMemset(c->d_err, 0, sizeof(unsigned int)));
     CHK(hipStreamCreateWithFlags(&c->stage_stream, hipStreamNonBlocking));
     // SQG_OVERLAP=1: the sample kernels get their own stream, so that the event kernels of the next batch run next to
-    // them (measured +2 % throughput on the bench workload; it stretches every kernel's duration, which is why the
-    // default keeps one stream and clean per-kernel timings).  Batches are double-buffered either way.
+    // them.  Both are VALU-bound: measured +2 % with earlier kernels, -2..4 % with the current ones, and it stretches every
+    // kernel's duration -- the default keeps one stream and clean per-kernel timings.  Batches are double-buffered either way.
     if (getenv("SQG_OVERLAP")) CHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     else c->stream2 = c->stream;
     {   // lowest priority: the fix-ups fill the gaps of the next batch's k_events, they must not take its slots
