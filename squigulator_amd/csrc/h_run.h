@@ -212,12 +212,13 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             HIPCHK(c, hipEventRecord(b->ev[6], c->stream2));
             b->lean_timed = true;
             if ((rc = dbg_sync(c, "k_samples_lean"))) return rc;
-            hipLaunchKernelGGL((k_samples<1, true>), dim3(std::min(sgrid, 4096u)), dim3(256), 0, c->stream2, P, n_tiles);
-            if ((rc = dbg_sync(c, "k_samples<generic>"))) return rc;
-            // the FP64 fix-ups (two small, latency-bound kernels) go to their own stream: the next batch's k_events does not wait for them
+            // what is left -- the items the lean kernel did not take (usually none) and the FP64 fix-ups, small latency-bound
+            // kernels -- goes to a stream of its own: the next batch's k_events does not wait for it
             HIPCHK(c, hipEventRecord(S.sampled, c->stream2));
             HIPCHK(c, hipStreamWaitEvent(c->fix_stream, S.sampled, 0));
             tail = c->fix_stream;
+            hipLaunchKernelGGL((k_samples<1, true>), dim3(std::min(sgrid, 4096u)), dim3(256), 0, tail, P, n_tiles);
+            if ((rc = dbg_sync(c, "k_samples<generic>"))) return rc;
             hipLaunchKernelGGL(k_fixup, dim3(512), dim3(256), 0, tail, P);
             hipLaunchKernelGGL(k_fixup_tiles, dim3((unsigned)((n_stiles + 255) / 256)), dim3(256), 0, tail, P, n_stiles);
             if ((rc = dbg_sync(c, "k_fixup"))) return rc;
