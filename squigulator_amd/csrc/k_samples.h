@@ -132,8 +132,8 @@ struct LeanLds {
 //   fract(c1 * a/M) in FP64 -> v_log/v_sqrt/v_cos ->
 //   v' = fma(x, sdk, F-1/2) -> t = v' + 1.5*2^23 (round to nearest: floor of the ADC value unless it is within
 //   eps of an integer) -> acceptance test on v' - (t - 1.5*2^23) -> int16 store of the low half of bits(t) + I.
-// The loads of step i+1 are issued before the arithmetic of step i (software pipelining, two steps unrolled
-// so that the pipeline registers do not have to be copied).
+// The loads of step i+1 are issued before the arithmetic of step i (software pipelining; four steps unrolled: the
+// pipeline registers alternate instead of being copied, and the position registers advance once per four steps).
 template <bool RNA, int LEAN_EPL>
 __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const int n_stiles) {
     __shared__ LeanLds<LEAN_EPL> L;
@@ -274,9 +274,9 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         #define LEAN_EVOF(tq_) (int)__builtin_amdgcn_mbcnt_hi((tq_).y, __builtin_amdgcn_mbcnt_lo((tq_).x, (tq_).z))
         // one step: issue the loads of step c_+1 into (RN, MN, EN) and the table entry of step c_+2 into TQN, then the arithmetic
         // of step c_ from (RA, MU, EV).  TQ: the table entry of step c_+1, loaded one step ago.
-        // DI: 0 / 1 = first / second step of a pair; idx4, voff and tbp advance once per pair, the second step's +64 samples
-        // ride in the immediate offsets of its LDS reads and its store.
-        #define LEAN_STEP(SH, TAIL, c_, DI, RA, MU, EV, RN, MN, EN, TQ, TQN) {                                       \
+        // DI: position of the step in its group of ST (4, or 2 for the remainder); idx4, voff and tbp advance once per group,
+        // the other steps' +64*DI samples ride in the immediate offsets of their LDS reads and stores.
+        #define LEAN_STEP(SH, TAIL, c_, DI, ST, RA, MU, EV, RN, MN, EN, TQ, TQN) {                                       \
             EN = LEAN_EVOF(TQ);                                                                                   \
             RN = W.rec[EN];                                                                                       \
             TQN = tbp[2 + (DI)];                                                                                  \
@@ -303,8 +303,8 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
                 if (slot + 1 == n0 + __popcll(am)) W.nfix = slot + 1;          /* the last of them publishes the new count */ \
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                            \
             }                                                                                                     \
-            if (DI) { idx4 += 512u; voff = RNA ? voff - 256u : voff + 256u; tbp += 2; }                           \
-            MN = *reinterpret_cast<const uint32_t*>(mult_b + ((DI) ? 0 : 256) + (idx4 - (RN.y >> 16))); }
+            if ((DI) == (ST) - 1) { idx4 += 256u * (ST); voff = RNA ? voff - 128u * (ST) : voff + 128u * (ST); tbp += (ST); } \
+            MN = *reinterpret_cast<const uint32_t*>(mult_b + ((DI) == (ST) - 1 ? 0 : 256 * ((DI) + 1)) + (idx4 - (RN.y >> 16))); }
 
         /* ablation builds (tools/ab_variants.sh; results are wrong): -DSQG_ABL_NOARITH, -DSQG_ABL_NOSTORE, -DSQG_ABL_NOLOOP */
 #if defined(SQG_ABL_NOSTORE)
@@ -329,16 +329,23 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         int c = 0;
         // the (few) items that overlap the RNA level-shift window run the variant that tests every sample against it
         #define LEAN_LOOP(SH)                                                                                    \
-            for (; c + 2 <= nfull; c += 2) {                                                                      \
-                LEAN_STEP(SH, false, c, 0, ra, ma, eva, rb, mb, evb, tqa, tqb)                                    \
-                LEAN_STEP(SH, false, c + 1, 1, rb, mb, evb, ra, ma, eva, tqb, tqa)                                \
+            for (; c + 4 <= nfull; c += 4) {                                                                      \
+                LEAN_STEP(SH, false, c, 0, 4, ra, ma, eva, rb, mb, evb, tqa, tqb)                                 \
+                LEAN_STEP(SH, false, c + 1, 1, 4, rb, mb, evb, ra, ma, eva, tqb, tqa)                             \
+                LEAN_STEP(SH, false, c + 2, 2, 4, ra, ma, eva, rb, mb, evb, tqa, tqb)                             \
+                LEAN_STEP(SH, false, c + 3, 3, 4, rb, mb, evb, ra, ma, eva, tqb, tqa)                             \
+            }                                                                                                     \
+            if (c + 2 <= nfull) {                                                                                 \
+                LEAN_STEP(SH, false, c, 0, 2, ra, ma, eva, rb, mb, evb, tqa, tqb)                                 \
+                LEAN_STEP(SH, false, c + 1, 1, 2, rb, mb, evb, ra, ma, eva, tqb, tqa)                             \
+                c += 2;                                                                                           \
             }                                                                                                     \
             if (c < nfull) {                                                                                      \
-                LEAN_STEP(SH, false, c, 0, ra, ma, eva, rb, mb, evb, tqa, tqb)                                    \
+                LEAN_STEP(SH, false, c, 0, 2, ra, ma, eva, rb, mb, evb, tqa, tqb)                                 \
                 ra = rb; ma = mb; eva = evb; tqa = tqb; c++;                                                      \
                 idx4 += 256u; voff = RNA ? voff - 128u : voff + 128u; tbp += 1;                                   \
             }                                                                                                     \
-            if (rem) LEAN_STEP(SH, true, c, 0, ra, ma, eva, rb, mb, evb, tqa, tqb)
+            if (rem) LEAN_STEP(SH, true, c, 0, 2, ra, ma, eva, rb, mb, evb, tqa, tqb)
         if (RNA && it.shift_hi > it.shift_lo) { LEAN_LOOP(true) } else { LEAN_LOOP(false) }
         #undef LEAN_LOOP
         #undef LEAN_STEP
