@@ -260,6 +260,10 @@ def main():
                          "GPUs, no data-path collective.  With a value (e.g. 1: the reference's reproducible regime) every "
                          "GPU owns all T workers and generates a range of each batch's reads; the per-stream sample counts "
                          "are all-gathered over RCCL once per batch (range sharding, include/sqg.h)")
+    ap.add_argument("--workers-per-gpu", type=int, default=0,
+                    help="W > 0: the job has T = N*W virtual workers, W per GPU (sharded by worker, no data-path collective), and "
+                         "every batch of N*K reads is split over them as the reference's static partition does "
+                         "(src/thread.c:80-99): `-t N*W -K N*K`.  W = 1 on one GPU is the reference's reproducible `-t 1`")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for one rank per GPU; gloo only to exercise the N>1 control flow on a "
                          "box with fewer GPUs than ranks (ranks then share GPUs)")
@@ -307,7 +311,10 @@ def main():
     range_mode = args.job_workers > 0
     if range_mode and args.host_sampler:
         raise SystemExit("--job-workers needs the device sampler")
-    T = args.job_workers if range_mode else K * world
+    W = args.workers_per_gpu
+    if W and (range_mode or K % W):
+        raise SystemExit("--workers-per-gpu: not with --job-workers, and it must divide --batch-reads")
+    T = args.job_workers if range_mode else (W * world if W else K * world)
     w_lo, w_hi = (0, T) if range_mode else shard.worker_range(rank, world, T)   # default: contiguous block of K virtual workers
     gen = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=T, device=local_rank,
                               mode=api.MODE_EXACT if args.mode == "exact" else api.MODE_CERTIFIED,
@@ -323,7 +330,8 @@ def main():
         contigs = [load_genome(GENOME)]
     genome = contigs[0]
     rng = np.random.default_rng(42 + rank)
-    workers = np.arange(w_lo, w_hi, dtype=np.int32)
+    # worker of this GPU's read i: one each (T = K), or the static partition of the job's N*K-read batch over T = N*W workers
+    workers = np.arange(w_lo, w_hi, dtype=np.int32) if not W else (w_lo + np.arange(K, dtype=np.int32) // (K // W)).astype(np.int32)
 
     nsteps = args.warmup + args.steps
     batches = []
@@ -413,6 +421,8 @@ def main():
                 "workload": f"{wl_desc}; -x {args.profile} --seed 42 -r {args.rlen}, "
                             + (f"-t {T} -K {K * world} (range sharding: every GPU owns all {T} worker(s) and generates {K} reads of each "
                                f"batch; one all-gather of {4 * n_rows} B per batch), {args.steps} batches" if range_mode else
+                               f"-t {T} -K {K * world} ({W} worker(s) per GPU, sharded by worker; static partition of each batch, "
+                               f"{K} reads per GPU), {args.steps} batches" if W else
                                f"-t {T} -K {T} (T=K virtual workers, {K} per GPU), {args.steps} batches"),
                 "reads_per_step_per_gpu": K, "kmer_size": k, "mode": args.mode,
                 "reads": "numpy draws of gen_read's distribution (host)" if args.host_sampler

@@ -19,7 +19,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsqg_hip.so")
 SOURCES = [os.path.join(CSRC, "sqg_hip.hip")]
 HEADERS = [os.path.join(os.path.dirname(HERE), "include", "sqg.h")] + \
-          [os.path.join(CSRC, h) for h in ("sqg_kernels.h", "k_common.h", "k_events.h", "k_samples.h", "k_sampler.h", "k_svb.h",
+          [os.path.join(CSRC, h) for h in ("sqg_kernels.h", "k_common.h", "k_events.h", "k_part.h", "k_samples.h", "k_sampler.h", "k_svb.h",
                                            "h_common.h", "h_context.h", "h_stage.h", "h_sampler.h", "h_run.h", "h_results.h")]
 ARCH = "gfx950"
 

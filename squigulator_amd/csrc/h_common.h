@@ -41,6 +41,12 @@ struct sqg_ctx {
     hipStream_t fix_stream = nullptr;              // the FP64 fix-ups of batch i (two small kernels) run next to k_events of batch i+1
     unsigned long long* d_scan_part = nullptr; size_t scan_part_cap = 0;   // k_scan: {ticket, total} per workgroup
     uint32_t* d_link_rows = nullptr; size_t link_rows_cap = 0;   // split chains: one row per link of the running batch
+    // k > 6, split chains (k_part.h), buffers of the running batch
+    uint32_t* d_part = nullptr; size_t part_cap = 0;             // [n_events] bucketed events
+    uint32_t* d_part_prior = nullptr; size_t part_prior_cap = 0; // [n_events] samples before each bucketed event
+    uint32_t* d_pcnt = nullptr; size_t pcnt_cap = 0;             // [n_links][n_part]
+    uint32_t* d_slice = nullptr; size_t slice_cap = 0;           // [2][n_groups][n_part] slice bounds
+    uint32_t* d_phist = nullptr; size_t phist_cap = 0;           // [n_groups][4^k]
     double row_bound = 0;                          // k > 6: upper bound of any sample count held in d_rows
     bool range_mode = false;                       // range sharding (sqg_set_range_mode): every batch is cut into links and run in two phases
     uint32_t* d_xcounts = nullptr; size_t xcounts_cap = 0;       // [nw][num_kmer] samples the running batch draws per stream (sqg_batch_run_begin)
@@ -102,6 +108,11 @@ struct sqg_batch {
     int* d_wlink_off = nullptr;          // [n_wchains+1] links of each worker chain
     int* d_wlink_worker = nullptr;       // [n_wchains]
     long long max_wchain_ev = 0;         // events of the longest worker chain
+    bool part = false;                   // k > 6, split: the hand-out runs over bucketed events (k_part.h)
+    int n_groups = 0;                    // groups of consecutive links (k_part.h)
+    int* d_link_group = nullptr;         // [n_chains] group of each link
+    int* d_wgroup_off = nullptr;         // [n_wchains+1] groups of each worker chain
+    uint32_t* d_cbase = nullptr;         // [n_wchains] first slot of each worker chain's region in the bucketed event array
     int* d_tile_read = nullptr;
     int* d_stile_read = nullptr;
     long long n_tiles = 0, n_stiles = 0;

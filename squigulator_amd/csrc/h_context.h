@@ -35,6 +35,7 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->fix_stream) (void)hipStreamSynchronize(ctx->fix_stream);
+    (void)hipFree(ctx->d_part); (void)hipFree(ctx->d_part_prior); (void)hipFree(ctx->d_pcnt); (void)hipFree(ctx->d_slice); (void)hipFree(ctx->d_phist);
     (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_scan_part); (void)hipFree(ctx->d_xcounts); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_samp_scratch); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err);
     for (auto& S : ctx->slot) {
         (void)hipFree(S.d_sig); (void)hipFree(S.d_dwell); (void)hipFree(S.d_seglen); (void)hipFree(S.d_sigoff);

@@ -17,7 +17,7 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
 #endif
         if (e) {
             HIPCHK(c, hipMemset(c->d_err, 0, sizeof e));
-            c->err = "device reported: " + std::string((e & 1) ? "dwell>65535 " : "") + ((e & 2) ? "read>=UINT32_MAX samples " : "") + ((e & 4) ? "internal length mismatch " : "") + ((e & 8) ? "FP64 fix-up list overflow" : "");
+            c->err = "device reported: " + std::string((e & 1) ? "dwell>65535 " : "") + ((e & 2) ? "read>=UINT32_MAX samples " : "") + ((e & 4) ? "internal length mismatch " : "") + ((e & 8) ? "FP64 fix-up list overflow " : "") + ((e & 32) ? "one k-mer stream asked for >= 2^32 samples by one batch" : "");
             return (e & 12) ? SQG_EDEVICE : SQG_EOVERFLOW;
         }
         float d = 0, s = 0, t = 0, ee = 0;

@@ -36,7 +36,10 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         // the rows count samples in 32 bits; only the count mod (M-1)/2 matters (range mode: the other ranges' counts are not
         // known here, so the rows are reduced before every batch)
         const double bnd = (double)b->max_wchain_ev * c->dwell_hi;
-        if (c->range_mode || c->row_bound + bnd >= 4294967295.0) {
+        if (b->part && !c->range_mode) {
+            // k_part_scan reduces the rows itself and reports a stream that is asked for >= 2^32 samples by one batch
+            c->row_bound = std::min((double)LCG_ORD2 + bnd, 4294967295.0) - bnd;
+        } else if (c->range_mode || c->row_bound + bnd >= 4294967295.0) {
             const size_t nrow = (size_t)c->nw * (size_t)c->num_kmer;
             hipLaunchKernelGGL(k_rows_normalize, dim3((unsigned)((nrow + 255) / 256)), dim3(256), 0, c->stream, c->d_rows, nrow);
             HIPCHK(c, hipGetLastError());
@@ -44,12 +47,21 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         }
         c->row_bound += bnd;
     }
-    if (phase != 2 && b->split && (rc = ensure(c, (void**)&c->d_link_rows, &c->link_rows_cap, (size_t)b->n_chains * (size_t)c->num_kmer, sizeof(uint32_t)))) return rc;
+    if (phase != 2 && b->split && !b->part && (rc = ensure(c, (void**)&c->d_link_rows, &c->link_rows_cap, (size_t)b->n_chains * (size_t)c->num_kmer, sizeof(uint32_t)))) return rc;
+    const int n_part = c->num_kmer >> PART_SUB_BITS;
+    if (phase != 2 && b->part) {
+        if ((rc = ensure(c, (void**)&c->d_part, &c->part_cap, (size_t)b->n_events + 64, sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(c, (void**)&c->d_part_prior, &c->part_prior_cap, (size_t)b->n_events + 64, sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(c, (void**)&c->d_pcnt, &c->pcnt_cap, (size_t)b->n_chains * (size_t)n_part, sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(c, (void**)&c->d_slice, &c->slice_cap, (size_t)2 * b->n_groups * (size_t)n_part, sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(c, (void**)&c->d_phist, &c->phist_cap, (size_t)b->n_groups * (size_t)c->num_kmer, sizeof(uint32_t)))) return rc;
+    }
     const size_t n_rows = (size_t)c->nw * (size_t)c->num_kmer;
     if (phase == 1 && (rc = ensure(c, (void**)&c->d_xcounts, &c->xcounts_cap, n_rows, sizeof(uint32_t)))) return rc;
     SigParams P;
     memset(&P, 0, sizeof P);
-    P.link_rows = b->split ? c->d_link_rows : nullptr;
+    P.link_rows = (b->split && !b->part) ? c->d_link_rows : nullptr;
+    P.part = c->d_part; P.part_prior = c->d_part_prior; P.pcnt = c->d_pcnt; P.n_part = n_part;
     P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
     P.dwell = c->use_dwell_stream ? S.d_dwell : nullptr; P.dwell_out = S.d_dwell; P.seglen_out = S.d_seglen;
     P.dmean = p.dwell_mean; P.dstd = p.dwell_std;
@@ -70,11 +82,12 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     auto launch_events = [&](int dw, bool hist) {
         const dim3 g((unsigned)b->n_chains);
         const bool wide = !hist && b->n_chains <= wide_max;
-#define EVL(N, D, W, H) hipLaunchKernelGGL((k_events<N, D, W, SQG_EVENT_EPT, H>), g, dim3(N), 0, c->stream, P)
-#define EVD(N, D, H) do { if (dw == 0) EVL(N, D, 0, H); else if (dw == 1) EVL(N, D, 1, H); else EVL(N, D, 2, H); } while (0)
-        if (wide) { if (direct) EVD(NT_WIDE, true, false); else EVD(NT_WIDE, false, false); }
-        else if (direct) { if (hist) EVD(NT, true, true); else EVD(NT, true, false); }
-        else { if (hist) EVD(NT, false, true); else EVD(NT, false, false); }
+#define EVL(N, D, W, H, PT) hipLaunchKernelGGL((k_events<N, D, W, SQG_EVENT_EPT, H, PT>), g, dim3(N), 0, c->stream, P)
+#define EVD(N, D, H, PT) do { if (dw == 0) EVL(N, D, 0, H, PT); else if (dw == 1) EVL(N, D, 1, H, PT); else EVL(N, D, 2, H, PT); } while (0)
+        if (b->part) { if (hist) EVD(NT, false, true, true); else EVD(NT, false, false, true); }
+        else if (wide) { if (direct) EVD(NT_WIDE, true, false, false); else EVD(NT_WIDE, false, false, false); }
+        else if (direct) { if (hist) EVD(NT, true, true, false); else EVD(NT, true, false, false); }
+        else { if (hist) EVD(NT, false, true, false); else EVD(NT, false, false, false); }
 #undef EVD
 #undef EVL
     };
@@ -104,7 +117,40 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     if (n > 0 && b->n_chains > 0) {
         const int dw = inline_dwell ? (certified && c->dwell_hi < 1.0e6 ? 1 : 2) : 0;
         const dim3 pg((unsigned)((c->num_kmer + 63) / 64), (unsigned)b->n_wchains);
-        if (b->split && phase != 2) {
+        const dim3 sg((unsigned)((c->num_kmer + 255) / 256), (unsigned)b->n_wchains);
+        const unsigned pgrid = (unsigned)b->n_groups * (unsigned)n_part;
+        uint32_t* const slice_lo = c->d_slice;
+        uint32_t* const slice_hi = c->d_slice ? c->d_slice + (size_t)b->n_groups * n_part : nullptr;
+        if (b->part) {
+            // k > 6, split chains: the hand-out over events bucketed by the top bits of the rank (k_part.h)
+            if (phase != 2) {
+                launch_events(dw, true);                          // dwell draws; events per (link, partition)
+                hipLaunchKernelGGL(k_part_offsets, dim3((unsigned)b->n_wchains), dim3(1024), 0, c->stream, c->d_pcnt, n_part, b->d_wlink_off,
+                                   b->d_link_group, b->d_cbase, slice_lo, slice_hi);
+                HIPCHK(c, hipGetLastError());
+                if ((rc = dbg_sync(c, "k_events<count>/k_part_offsets"))) return rc;
+                launch_events(0, false);                          // every event to its slot (the dwell is in memory now)
+                hipLaunchKernelGGL(k_part_hist, dim3(pgrid), dim3(256), 0, c->stream, c->d_part, slice_lo, slice_hi, c->d_phist);
+                HIPCHK(c, hipGetLastError());
+                if ((rc = dbg_sync(c, "k_events<scatter>/k_part_hist"))) return rc;
+                if (phase == 1) {                                 // range sharding: what this range draws per stream, for the exchange
+                    HIPCHK(c, hipMemsetAsync(c->d_xcounts, 0, n_rows * sizeof(uint32_t), c->stream));
+                    hipLaunchKernelGGL(k_part_totals, sg, dim3(256), 0, c->stream, c->d_phist, c->num_kmer, b->d_wgroup_off, b->d_wlink_worker, c->d_xcounts);
+                    HIPCHK(c, hipGetLastError());
+                }
+            }
+            if (phase != 1) {
+                hipLaunchKernelGGL(k_part_scan, sg, dim3(256), 0, c->stream, c->d_phist, c->d_rows, c->num_kmer, b->d_wgroup_off, b->d_wlink_worker, before, c->d_err);
+                if (before) {                                     // every worker's row moves past the whole batch, all ranges
+                    const dim3 ag((unsigned)((n_rows + 255) / 256));
+                    hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
+                }
+                hipLaunchKernelGGL(k_part_hand, dim3(pgrid), dim3(256), 0, c->stream, c->d_part, c->d_part_prior, slice_lo, slice_hi, c->d_phist);
+                hipLaunchKernelGGL(k_part_home, dim3((unsigned)((b->n_tiles + 3) / 4)), dim3(256), 0, c->stream, P, (int)b->n_tiles);
+                HIPCHK(c, hipGetLastError());
+                if ((rc = dbg_sync(c, "k_part_scan/hand/home"))) return rc;
+            }
+        } else if (b->split && phase != 2) {
             // links: samples per (link, k-mer) with the dwell draws ...
             if (!direct) HIPCHK(c, hipMemsetAsync(c->d_link_rows, 0, (size_t)b->n_chains * (size_t)c->num_kmer * sizeof(uint32_t), c->stream));
             launch_events(dw, true);
@@ -115,7 +161,8 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 HIPCHK(c, hipGetLastError());
             }
         }
-        if (b->split && phase != 1) {
+        if (b->part) {
+        } else if (b->split && phase != 1) {
             // ... then each link's view of its worker's streams
             if (direct) hipLaunchKernelGGL(k_link_prefix<true>, pg, dim3(1024), 0, c->stream, P, b->d_wlink_off, b->d_wlink_worker, before);
             else hipLaunchKernelGGL(k_link_prefix<false>, pg, dim3(1024), 0, c->stream, P, b->d_wlink_off, b->d_wlink_worker, before);

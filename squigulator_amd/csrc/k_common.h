@@ -182,5 +182,15 @@ struct SigParams {
     int rna;                     // reverse the signal (src/gensig.c:348-354)
     int shift_len;               // RNA+prefix: 79*(int)dwell_mean samples get -shift (src/genread.c:79-86)
     int shift;                   // (int16)(30*dig/range)
+    // k > 6, few workers (k_part.h): a worker chain's events bucketed by the top bits of the k-mer rank
+    uint32_t* part;              // [n_events], a chain's region partition-major, chain order inside a partition:
+                                 // (dwell << 16) | low PART_SUB_BITS of the rank
+    uint32_t* part_prior;        // [n_events] same slots (k_part_hand): samples the event's stream has produced before it
+    uint32_t* pcnt;              // [n_links][n_part] events per (link, partition); k_part_offsets turns it into the first slot
+    int n_part;                  // partitions = num_kmer >> PART_SUB_BITS
 };
+
+#define PART_SUB_BITS 12         // a partition's sub-row: 4096 streams, 16 KiB of LDS (the size of a whole 6-mer row)
+#define PART_SUB (1 << PART_SUB_BITS)
+#define PART_MAX 64              // partitions of a 9-mer table
 

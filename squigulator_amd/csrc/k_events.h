@@ -302,16 +302,21 @@ __device__ static inline int wave_incl_scan(int v, int lane) {
 
 // DIRECT (k <= 6): one bin per k-mer rank, no keys, no probing; otherwise an open-addressing hash of 2*SEG bins.
 // A segment is SEG = NT*EPT consecutive events of a read, EPT consecutive events per thread.
-template <int NT, bool DIRECT, int EPT>
+template <int NT, bool DIRECT, int EPT, bool PART = false>
 struct EvLds {
     static constexpr int SEG = NT * EPT;
-    uint32_t keys[DIRECT ? 1 : 2 * SEG];     // hash bins: k-mer rank
-    uint32_t head[DIRECT ? 1 : 2 * SEG];     // hash bin -> most recently inserted event of the segment (EV_NIL: none)
+    uint32_t keys[(DIRECT || PART) ? 1 : 2 * SEG];     // hash bins: k-mer rank
+    uint32_t head[(DIRECT || PART) ? 1 : 2 * SEG];     // hash bin -> most recently inserted event of the segment (EV_NIL: none)
     uint32_t row[DIRECT ? 4096 : 1];         // DIRECT: the worker's stream states, resident for the whole chain; while a segment
                                              // is being handed out, ROW_BUSY | (most recently inserted event of the bin)
-    uint32_t st[SEG];                        // DIRECT: the state the bin's first exchanger swapped out of row[]; else: the
+    uint32_t st[PART ? 1 : SEG];             // DIRECT: the state the bin's first exchanger swapped out of row[]; else: the
                                              // bin's state at the start of the segment, published by its first event
-    uint32_t nxt[SEG];          // per event: (dwell << 16) | next event in the same bin
+    uint32_t nxt[PART ? 1 : SEG];            // per event: (dwell << 16) | next event in the same bin
+    // PART (k > 6, split chains; k_part.h): the events are bucketed by the top bits of their rank, stably
+    uint4 pmask[PART ? (NT / 64) * PART_MAX : 1];   // per (wavefront, partition): which lanes hold an event of the partition,
+                                                    // {first event of the lane: lanes 0-31, 32-63; second event: 0-31, 32-63}
+    uint32_t prun[PART ? PART_MAX : 1];      // per partition: events of the link so far (counting pass), or the slot in
+                                             // SigParams.part of the link's next event of the partition (scatter pass)
     uint32_t jump[EV_JUMP_N];   // a^(2j), j < EV_JUMP_N
     uint8_t codes[SEG + EV_HALO + 4];  // 2-bit base codes of the segment
     uint8_t lut[256];           // base -> 2-bit code (src/seq.h:14-27)
@@ -327,9 +332,14 @@ __device__ static inline void lds_barrier() {
 // out-of-line FP64 fallback; 2 = drawn here in FP64 (src/gensig.c:254-257)
 // HIST: only the front half -- dwell draws, ranks, and the samples each k-mer stream is asked for, accumulated into the
 // workgroup's row (split chains, see above)
-template <int NT, bool DIRECT, int DW, int EPT, bool HIST = false>
+// PART (k > 6, with HIST or after it): the stream hand-out is left to k_part_hist / k_part_scan / k_part_hand, which walk the
+// events bucketed by the top bits of their rank (k_part.h).  With HIST: events per (link, partition) -> P.pcnt.  Without:
+// every event is written to its slot in P.part -- (link, partition)'s first slot from P.pcnt, then stable in event order
+// -- and its evrec holds {slot, rank} for k_part_home.
+template <int NT, bool DIRECT, int DW, int EPT, bool HIST = false, bool PART = false>
 __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events(const SigParams P) {
-    typedef EvLds<NT, DIRECT, EPT> Lds;
+    static_assert(!PART || (!DIRECT && EPT == 2), "PART: k > 6, two events per thread");
+    typedef EvLds<NT, DIRECT, EPT, PART> Lds;
     __shared__ Lds L;
     __shared__ long long n1_sh;
     constexpr int NW = NT / 64, SEG = NT * EPT, HT = 2 * SEG, TL = 64 / EPT;   // TL: lanes per 64-event tile
@@ -347,6 +357,10 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
     const uint32_t seed_w = (uint32_t)(((unsigned long long)P.seed_base +
                                         (unsigned long long)(P.rows ? P.reads[P.chain_reads[c_lo]].worker : 0) * P.seed_step) % LCG_M);
     if (DIRECT && P.use_streams) for (int i = tid; i < P.num_kmer; i += NT) L.row[i] = HIST ? 0u : row[i];
+    if (PART) {
+        if (tid < PART_MAX) L.prun[tid] = (HIST || tid >= P.n_part) ? 0u : P.pcnt[(size_t)chain * P.n_part + tid];
+        for (int i = tid; i < (NT / 64) * PART_MAX; i += NT) L.pmask[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     const uint32_t a2nt = DW ? lcg_jump2(P.pw, (uint32_t)SEG) : 0u;      // time-stream jump over one segment
     const uint32_t a2jn = DW ? lcg_jump2(P.pw, (uint32_t)EV_JUMP_N) : 0u; // ... and over EV_JUMP_N events
     const float dw_sf = (float)P.dstd, dw_mf = (float)P.dmean;
@@ -456,7 +470,7 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
             for (int q = 0; q < EPT; q++) lane_total += sps[q];
             const int incl = wave_incl_scan_dpp(lane_total);
             if (lane == 63) L.wsum[wid] = incl;
-            if (!DIRECT && !HIST && P.use_streams) for (int i = tid; i < HT; i += NT) { L.keys[i] = BIN_EMPTY; L.head[i] = EV_NIL; }
+            if (!DIRECT && !HIST && !PART && P.use_streams) for (int i = tid; i < HT; i += NT) { L.keys[i] = BIN_EMPTY; L.head[i] = EV_NIL; }
             lds_barrier();                                                                    // (1)
             int woff = 0, seg_total = 0;
             for (int w = 0; w < NW; w++) { const int x = L.wsum[w]; if (w < wid) woff += x; seg_total += x; }
@@ -486,7 +500,10 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
                 }
                 h[q] = DIRECT ? rank[q] : (rank[q] * 2654435761u) >> (32 - (31 - __builtin_clz(HT)));
                 if (HIST) {
-                    if (P.use_streams && EV_IN(e)) { if (DIRECT) atomicAdd(&L.row[rank[q]], (uint32_t)sps[q]); else atomicAdd(&row[rank[q]], (uint32_t)sps[q]); }
+                    if (PART) { if (EV_IN(e)) atomicAdd(&L.prun[rank[q] >> PART_SUB_BITS], 1u); }
+                    else if (P.use_streams && EV_IN(e)) { if (DIRECT) atomicAdd(&L.row[rank[q]], (uint32_t)sps[q]); else atomicAdd(&row[rank[q]], (uint32_t)sps[q]); }
+                } else if (PART) {
+                    if (EV_IN(e)) atomicOr(reinterpret_cast<unsigned int*>(&L.pmask[wid * PART_MAX + (rank[q] >> PART_SUB_BITS)]) + 2 * q + (lane >> 5), 1u << (lane & 31));
                 } else if (P.use_streams && EV_IN(e)) {
                     const uint32_t id = (uint32_t)(tid * EPT + q);    // event within the segment, in event order
                     if (DIRECT) {
@@ -517,7 +534,7 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
                 lds_barrier();                                        // codes / wsum are rewritten by the next segment
                 return;
             }
-            if (DIRECT) lds_barrier(); else __syncthreads();                                  // (2) global rows: + earlier row stores have landed
+            if (DIRECT || PART) lds_barrier(); else __syncthreads();                          // (2) global rows: + earlier row stores have landed
             prefetch_next(s0);                                        // lands while this segment waits for its states
             // first sample of every 64-event tile (TL lanes) within the read
             if ((lane & (TL - 1)) == 0 && EV_IN(e0)) P.tile_so[rd.tile_off + (e0 >> 6)] = done + (uint32_t)lane_excl;
@@ -531,7 +548,32 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
                     c_ev[q] = 0;
                 }
             }
-            if (P.use_streams) {
+            if (PART) {
+                // my slot: the link's events of my partition so far + those of earlier wavefronts, of lower lanes, of my lane
+#pragma unroll
+                for (int q = 0; q < EPT; q++) {
+                    if (EV_IN(e0 + q)) {
+                        const uint32_t p = rank[q] >> PART_SUB_BITS;
+                        const uint4 m = L.pmask[wid * PART_MAX + p];
+                        uint32_t before = __builtin_amdgcn_mbcnt_hi(m.y, __builtin_amdgcn_mbcnt_lo(m.x, 0u));
+                        before = __builtin_amdgcn_mbcnt_hi(m.w, __builtin_amdgcn_mbcnt_lo(m.z, before));
+                        if (q == 1 && (rank[0] >> PART_SUB_BITS) == p) before++;          // (event e0 exists when e0 + 1 does)
+                        for (int w = 0; w < wid; w++) {
+                            const uint4 o = L.pmask[w * PART_MAX + p];
+                            before += (uint32_t)(__builtin_popcount(o.x) + __builtin_popcount(o.y) + __builtin_popcount(o.z) + __builtin_popcount(o.w));
+                        }
+                        const uint32_t slot = L.prun[p] + before;
+                        P.part[slot] = (rank[q] & (PART_SUB - 1)) | ((uint32_t)sps[q] << 16);
+                        c_ev[q] = slot;
+                    }
+                }
+                lds_barrier();                                                                  // (3) every slot taken before the counts move
+                {   // thread (wavefront w, lane p): the partition's counts move past the segment, the masks are cleared
+                    const uint4 m = L.pmask[tid];
+                    const uint32_t n = (uint32_t)(__builtin_popcount(m.x) + __builtin_popcount(m.y) + __builtin_popcount(m.z) + __builtin_popcount(m.w));
+                    if (n) { atomicAdd(&L.prun[lane], n); L.pmask[tid] = make_uint4(0u, 0u, 0u, 0u); }
+                }
+            } else if (P.use_streams) {
                 // dwell drawn from my k-mer's stream by earlier events of this segment, by all of them,
                 // and whether I am the last one (who stores the advanced state)
                 // the bin's FIRST event (prior == 0) stores the advanced state, so that every event has exactly one
@@ -608,5 +650,6 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
         __syncthreads();
     }
     if (DIRECT && P.use_streams) for (int i = tid; i < P.num_kmer; i += NT) row[i] = L.row[i];
+    if (PART && HIST && tid < P.n_part) P.pcnt[(size_t)chain * P.n_part + tid] = L.prun[tid];
 }
 

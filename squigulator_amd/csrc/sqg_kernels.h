@@ -5,6 +5,7 @@
 //   k_dwell       per-event dwell draw from the worker's time stream   (src/gensig.c:254-257)
 //   k_scan        read lengths -> output offsets
 //   k_events      per worker chain: ranks, in-order hand-out of the k-mer streams
+//   k_part_*      k > 6, few workers: the stream hand-out over events bucketed by the top bits of the rank (k_part.h)
 //   k_samples     per 64-event tile: the samples                       (src/gensig.c:226-356)
 //   k_fixup       FP64 recomputation of the samples the certified fp32 path could not decide
 //   k_certify     exhaustive error sweep of the fp32 normal-deviate path over all 2^31-2 states
@@ -27,6 +28,7 @@
 
 #include "k_common.h"
 #include "k_events.h"
+#include "k_part.h"
 #include "k_samples.h"
 #include "k_sampler.h"
 #include "k_svb.h"
