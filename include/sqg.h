@@ -204,6 +204,9 @@ typedef struct {                /* what gen_read returned, per read (host arrays
     const int64_t *seq_off;     /* [n_reads+1] offsets of the reads in the sqg_fetch_reads() array  */
 } sqg_sample_t;
 int  sqg_genome_load(sqg_ctx_t *ctx, const sqg_genome_t *g);
+/* the same with g->seqs in DEVICE memory (a reference already resident in HBM -- e.g. decompressed or synthesised there --
+ * is copied device to device; everything else in *g is host memory as above) */
+int  sqg_genome_load_device(sqg_ctx_t *ctx, const sqg_genome_t *g);
 int  sqg_batch_sample(sqg_ctx_t *ctx, int32_t n_reads, const int32_t *worker, sqg_batch_t **out, sqg_sample_t *info);
 /* the sampled reads as gen_read returned them (after N substitution and revcomp), for the FASTA/SAM writers */
 int  sqg_fetch_reads(sqg_ctx_t *ctx, sqg_batch_t *b, char *dst /* seq_off[n_reads] bytes */);

@@ -61,7 +61,7 @@ class CSvb(C.Structure):
 
 
 class CGenome(C.Structure):
-    _fields_ = [("n_contigs", C.c_int32), ("seqs", C.c_char_p), ("contig_off", C.POINTER(C.c_int64)),
+    _fields_ = [("n_contigs", C.c_int32), ("seqs", C.c_void_p), ("contig_off", C.POINTER(C.c_int64)),
                 ("rlen", C.c_int32), ("mode", C.c_uint32), ("n_trans", C.c_int32),
                 ("trans_csum", C.POINTER(C.c_float)), ("trans_idx", C.POINTER(C.c_int32))]
 
@@ -78,7 +78,7 @@ EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_d
            "sqg_batch_free", "sqg_get_timing", "sqg_submit", "sqg_worker_of", "sqg_probe_store_bandwidth",
            "sqg_batch_compress", "sqg_fetch_svb", "sqg_genome_load", "sqg_batch_sample", "sqg_fetch_reads",
            "sqg_host_alloc", "sqg_host_free", "sqg_set_range_mode", "sqg_skip_reads", "sqg_batch_sample_range",
-           "sqg_batch_run_begin", "sqg_batch_run_end")
+           "sqg_batch_run_begin", "sqg_batch_run_end", "sqg_genome_load_device")
 
 _lib = None
 
@@ -129,6 +129,8 @@ def load_library(path: str | None = None):
     L.sqg_fetch_svb.argtypes = [vp, vp, vp]
     L.sqg_genome_load.restype = C.c_int
     L.sqg_genome_load.argtypes = [vp, C.POINTER(CGenome)]
+    L.sqg_genome_load_device.restype = C.c_int
+    L.sqg_genome_load_device.argtypes = [vp, C.POINTER(CGenome)]
     L.sqg_batch_sample.restype = C.c_int
     L.sqg_batch_sample.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(vp), C.POINTER(CSample)]
     L.sqg_fetch_reads.restype = C.c_int
@@ -300,7 +302,7 @@ class SignalGenerator:
         blob = b"".join(contigs)
         off = np.zeros(len(contigs) + 1, np.int64)
         off[1:] = np.cumsum([len(x) for x in contigs])
-        g = CGenome(len(contigs), blob, off.ctypes.data_as(C.POINTER(C.c_int64)), rlen, mode, 0, None, None)
+        g = CGenome(len(contigs), C.cast(C.c_char_p(blob), C.c_void_p), off.ctypes.data_as(C.POINTER(C.c_int64)), rlen, mode, 0, None, None)
         if trans is not None:
             csum = np.ascontiguousarray(trans[0], np.float32)
             idx = np.ascontiguousarray(trans[1], np.int32)
@@ -308,6 +310,14 @@ class SignalGenerator:
             g.trans_csum = csum.ctypes.data_as(C.POINTER(C.c_float))
             g.trans_idx = idx.ctypes.data_as(C.POINTER(C.c_int32))
         self._chk(self.L.sqg_genome_load(self.ctx, C.byref(g)), "sqg_genome_load")
+
+    def load_genome_device(self, d_seqs: int, contig_lens, rlen: int, mode: int = SAMPLE_DNA):
+        """The same for a reference that already sits in device memory: d_seqs is the device address of the concatenated
+        contigs (e.g. torch_tensor.data_ptr()); it is copied, the caller may free it afterwards."""
+        off = np.zeros(len(contig_lens) + 1, np.int64)
+        off[1:] = np.cumsum(np.asarray(contig_lens, np.int64))
+        g = CGenome(len(contig_lens), C.c_void_p(d_seqs), off.ctypes.data_as(C.POINTER(C.c_int64)), rlen, mode, 0, None, None)
+        self._chk(self.L.sqg_genome_load_device(self.ctx, C.byref(g)), "sqg_genome_load_device")
 
     def set_range_mode(self, on: bool = True):
         """range sharding (include/sqg.h): this context owns all workers and generates a range of each batch's reads"""

@@ -34,6 +34,8 @@ struct sqg_ctx {
         uint4* d_tfix = nullptr; size_t tfix_cap = 0;
         unsigned char* d_tfix_n = nullptr; size_t tfixn_cap = 0;
         ItemDesc* d_items = nullptr; size_t items_cap = 0;          // [n_stiles] work items of the lean kernel (k_items)
+        uint32_t* d_part_state = nullptr; size_t part_state_cap = 0;   // [n_events] k > 6, split chains (k_part.h): stream state at each
+                                                                    // bucketed event; read by the sample kernels like evrec
         hipEvent_t done = nullptr;                 // recorded after the slot's last kernel (fix-ups included)
         hipEvent_t sampled = nullptr;              // recorded on stream2 after the slot's sample kernels, before the fix-ups
     } slot[2];
@@ -43,7 +45,6 @@ struct sqg_ctx {
     uint32_t* d_link_rows = nullptr; size_t link_rows_cap = 0;   // split chains: one row per link of the running batch
     // k > 6, split chains (k_part.h), buffers of the running batch
     uint32_t* d_part = nullptr; size_t part_cap = 0;             // [n_events] bucketed events
-    uint32_t* d_part_prior = nullptr; size_t part_prior_cap = 0; // [n_events] samples before each bucketed event
     uint32_t* d_pcnt = nullptr; size_t pcnt_cap = 0;             // [n_links][n_part]
     uint32_t* d_slice = nullptr; size_t slice_cap = 0;           // [2][n_groups][n_part] slice bounds
     uint32_t* d_phist = nullptr; size_t phist_cap = 0;           // [n_groups][4^k]

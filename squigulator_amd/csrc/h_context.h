@@ -35,13 +35,13 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->fix_stream) (void)hipStreamSynchronize(ctx->fix_stream);
-    (void)hipFree(ctx->d_part); (void)hipFree(ctx->d_part_prior); (void)hipFree(ctx->d_pcnt); (void)hipFree(ctx->d_slice); (void)hipFree(ctx->d_phist);
+    (void)hipFree(ctx->d_part); (void)hipFree(ctx->d_pcnt); (void)hipFree(ctx->d_slice); (void)hipFree(ctx->d_phist);
     (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_scan_part); (void)hipFree(ctx->d_xcounts); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_samp_scratch); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err);
     for (auto& S : ctx->slot) {
         (void)hipFree(S.d_sig); (void)hipFree(S.d_dwell); (void)hipFree(S.d_seglen); (void)hipFree(S.d_sigoff);
         (void)hipFree(S.d_fix); (void)hipFree(S.d_fix_count);
         (void)hipFree(S.d_evrec); (void)hipFree(S.d_tile_so); (void)hipFree(S.d_slow);
-        (void)hipFree(S.d_tfix); (void)hipFree(S.d_tfix_n); (void)hipFree(S.d_items);
+        (void)hipFree(S.d_tfix); (void)hipFree(S.d_tfix_n); (void)hipFree(S.d_items); (void)hipFree(S.d_part_state);
         if (S.done) (void)hipEventDestroy(S.done);
         if (S.sampled) (void)hipEventDestroy(S.sampled);
     }

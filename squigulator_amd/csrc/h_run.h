@@ -50,8 +50,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     if (phase != 2 && b->split && !b->part && (rc = ensure(c, (void**)&c->d_link_rows, &c->link_rows_cap, (size_t)b->n_chains * (size_t)c->num_kmer, sizeof(uint32_t)))) return rc;
     const int n_part = c->num_kmer >> PART_SUB_BITS;
     if (phase != 2 && b->part) {
-        if ((rc = ensure(c, (void**)&c->d_part, &c->part_cap, (size_t)b->n_events + 64, sizeof(uint32_t)))) return rc;
-        if ((rc = ensure(c, (void**)&c->d_part_prior, &c->part_prior_cap, (size_t)b->n_events + 64, sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(c, (void**)&c->d_part, &c->part_cap, (size_t)b->n_events + PART_SLACK, sizeof(uint32_t)))) return rc;
         if ((rc = ensure(c, (void**)&c->d_pcnt, &c->pcnt_cap, (size_t)b->n_chains * (size_t)n_part, sizeof(uint32_t)))) return rc;
         if ((rc = ensure(c, (void**)&c->d_slice, &c->slice_cap, (size_t)2 * b->n_groups * (size_t)n_part, sizeof(uint32_t)))) return rc;
         if ((rc = ensure(c, (void**)&c->d_phist, &c->phist_cap, (size_t)b->n_groups * (size_t)c->num_kmer, sizeof(uint32_t)))) return rc;
@@ -61,7 +60,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     SigParams P;
     memset(&P, 0, sizeof P);
     P.link_rows = (b->split && !b->part) ? c->d_link_rows : nullptr;
-    P.part = c->d_part; P.part_prior = c->d_part_prior; P.pcnt = c->d_pcnt; P.n_part = n_part;
+    P.part = c->d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = c->d_pcnt; P.n_part = n_part;
     P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
     P.dwell = c->use_dwell_stream ? S.d_dwell : nullptr; P.dwell_out = S.d_dwell; P.seglen_out = S.d_seglen;
     P.dmean = p.dwell_mean; P.dstd = p.dwell_std;
@@ -140,15 +139,15 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 }
             }
             if (phase != 1) {
-                hipLaunchKernelGGL(k_part_scan, sg, dim3(256), 0, c->stream, c->d_phist, c->d_rows, c->num_kmer, b->d_wgroup_off, b->d_wlink_worker, before, c->d_err);
+                hipLaunchKernelGGL(k_part_scan, sg, dim3(256), 0, c->stream, c->d_phist, c->d_rows, c->num_kmer, b->d_wgroup_off, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, c->d_err);
                 if (before) {                                     // every worker's row moves past the whole batch, all ranges
                     const dim3 ag((unsigned)((n_rows + 255) / 256));
                     hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
                 }
-                hipLaunchKernelGGL(k_part_hand, dim3(pgrid), dim3(256), 0, c->stream, c->d_part, c->d_part_prior, slice_lo, slice_hi, c->d_phist);
-                hipLaunchKernelGGL(k_part_home, dim3((unsigned)((b->n_tiles + 3) / 4)), dim3(256), 0, c->stream, P, (int)b->n_tiles);
+                if (c->dwell_hi >= (double)PART_JT) hipLaunchKernelGGL(k_part_hand<true>, dim3(pgrid), dim3(64), 0, c->stream, c->d_part, S.d_part_state, slice_lo, slice_hi, c->d_phist, c->d_pow, (uint32_t)b->n_events);
+                else hipLaunchKernelGGL(k_part_hand<false>, dim3(pgrid), dim3(64), 0, c->stream, c->d_part, S.d_part_state, slice_lo, slice_hi, c->d_phist, c->d_pow, (uint32_t)b->n_events);
                 HIPCHK(c, hipGetLastError());
-                if ((rc = dbg_sync(c, "k_part_scan/hand/home"))) return rc;
+                if ((rc = dbg_sync(c, "k_part_scan/k_part_hand"))) return rc;
             }
         } else if (b->split && phase != 2) {
             // links: samples per (link, k-mer) with the dwell draws ...

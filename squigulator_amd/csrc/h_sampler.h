@@ -3,7 +3,7 @@
 #pragma once
 
 // ---- resident genome + device-side read sampler ("next" row of SURVEY.md section 8f) ----
-extern "C" int sqg_genome_load(sqg_ctx_t* c, const sqg_genome_t* g) {
+static int genome_load_impl(sqg_ctx_t* c, const sqg_genome_t* g, const bool on_device) {
     if (!c || !g || g->n_contigs <= 0 || !g->seqs || !g->contig_off || g->rlen <= 0) return SQG_EINVAL;
     if (g->n_trans < 0 || (g->n_trans > 0 && (!g->trans_csum || !g->trans_idx))) return SQG_EINVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -21,7 +21,7 @@ extern "C" int sqg_genome_load(sqg_ctx_t* c, const sqg_genome_t* g) {
     (void)hipFree(c->d_trans_csum); (void)hipFree(c->d_trans_idx); (void)hipFree(c->d_samp);
     c->d_genome = nullptr; c->d_contig_off = nullptr; c->d_cum = nullptr; c->d_trans_csum = nullptr; c->d_trans_idx = nullptr; c->d_samp = nullptr;
     HIPCHK(c, hipMalloc(&c->d_genome, (size_t)total + 16));
-    HIPCHK(c, hipMemcpy(c->d_genome, g->seqs + g->contig_off[0], (size_t)total, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_genome, g->seqs + g->contig_off[0], (size_t)total, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
     HIPCHK(c, hipMemset(c->d_genome + total, 0, 16));
     HIPCHK(c, hipMalloc(&c->d_contig_off, off.size() * sizeof(long long)));
     HIPCHK(c, hipMemcpy(c->d_contig_off, off.data(), off.size() * sizeof(long long), hipMemcpyHostToDevice));
@@ -49,6 +49,9 @@ extern "C" int sqg_genome_load(sqg_ctx_t* c, const sqg_genome_t* g) {
     c->genome_loaded = true;
     return SQG_OK;
 }
+
+extern "C" int sqg_genome_load(sqg_ctx_t* c, const sqg_genome_t* g) { return genome_load_impl(c, g, false); }
+extern "C" int sqg_genome_load_device(sqg_ctx_t* c, const sqg_genome_t* g) { return genome_load_impl(c, g, true); }
 
 // events of a read of `len` bases once the prefix is attached (src/gensig.c:242-245, src/genread.c:87-123)
 static long long read_events(const sqg_ctx* c, long long len) {

@@ -185,7 +185,8 @@ struct SigParams {
     // k > 6, few workers (k_part.h): a worker chain's events bucketed by the top bits of the k-mer rank
     uint32_t* part;              // [n_events], a chain's region partition-major, chain order inside a partition:
                                  // (dwell << 16) | low PART_SUB_BITS of the rank
-    uint32_t* part_prior;        // [n_events] same slots (k_part_hand): samples the event's stream has produced before it
+    uint32_t* part_state;        // [n_events] same slots (k_part_hand): the stream's state at the event's first draw; non-null tells
+                                 // the sample kernels that evrec.x is a slot, not a state
     uint32_t* pcnt;              // [n_links][n_part] events per (link, partition); k_part_offsets turns it into the first slot
     int n_part;                  // partitions = num_kmer >> PART_SUB_BITS
 };

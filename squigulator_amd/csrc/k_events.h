@@ -317,6 +317,9 @@ struct EvLds {
                                                     // {first event of the lane: lanes 0-31, 32-63; second event: 0-31, 32-63}
     uint32_t prun[PART ? PART_MAX : 1];      // per partition: events of the link so far (counting pass), or the slot in
                                              // SigParams.part of the link's next event of the partition (scatter pass)
+    uint2 pbase[PART ? (NT / 64) * PART_MAX : 1];   // per (wavefront, partition), scatter pass: {slot, position in the segment's
+                                                    // partition-sorted order} of the wavefront's first event of the partition
+    uint2 sorted[PART ? SEG : 1];            // the segment's events in partition-sorted order: {slot, record}
     uint32_t jump[EV_JUMP_N];   // a^(2j), j < EV_JUMP_N
     uint8_t codes[SEG + EV_HALO + 4];  // 2-bit base codes of the segment
     uint8_t lut[256];           // base -> 2-bit code (src/seq.h:14-27)
@@ -549,25 +552,45 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
                 }
             }
             if (PART) {
-                // my slot: the link's events of my partition so far + those of earlier wavefronts, of lower lanes, of my lane
+                // every wavefront, lane p: the partition's events of the segment per wavefront -> where this wavefront's events of
+                // the partition go: slots (link-wide, L.prun) and positions in the segment's partition-sorted order
+                {
+                    uint32_t mine_before = 0, all = 0;
+#pragma unroll
+                    for (int w = 0; w < NW; w++) {
+                        const uint4 o = L.pmask[w * PART_MAX + lane];
+                        const uint32_t n = (uint32_t)(__builtin_popcount(o.x) + __builtin_popcount(o.y) + __builtin_popcount(o.z) + __builtin_popcount(o.w));
+                        if (w < wid) mine_before += n;
+                        all += n;
+                    }
+                    const uint32_t excl = (uint32_t)wave_incl_scan_dpp((int)all) - all;
+                    L.pbase[wid * PART_MAX + lane] = make_uint2(L.prun[lane] + mine_before, excl + mine_before);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                }
 #pragma unroll
                 for (int q = 0; q < EPT; q++) {
                     if (EV_IN(e0 + q)) {
                         const uint32_t p = rank[q] >> PART_SUB_BITS;
                         const uint4 m = L.pmask[wid * PART_MAX + p];
-                        uint32_t before = __builtin_amdgcn_mbcnt_hi(m.y, __builtin_amdgcn_mbcnt_lo(m.x, 0u));
+                        uint32_t before = __builtin_amdgcn_mbcnt_hi(m.y, __builtin_amdgcn_mbcnt_lo(m.x, 0u));   // lower lanes
                         before = __builtin_amdgcn_mbcnt_hi(m.w, __builtin_amdgcn_mbcnt_lo(m.z, before));
                         if (q == 1 && (rank[0] >> PART_SUB_BITS) == p) before++;          // (event e0 exists when e0 + 1 does)
-                        for (int w = 0; w < wid; w++) {
-                            const uint4 o = L.pmask[w * PART_MAX + p];
-                            before += (uint32_t)(__builtin_popcount(o.x) + __builtin_popcount(o.y) + __builtin_popcount(o.z) + __builtin_popcount(o.w));
-                        }
-                        const uint32_t slot = L.prun[p] + before;
-                        P.part[slot] = (rank[q] & (PART_SUB - 1)) | ((uint32_t)sps[q] << 16);
+                        const uint2 pb = L.pbase[wid * PART_MAX + p];
+                        const uint32_t slot = pb.x + before;
+                        L.sorted[pb.y + before] = make_uint2(slot, (rank[q] & (PART_SUB - 1)) | ((uint32_t)sps[q] << 16));
                         c_ev[q] = slot;
                     }
                 }
                 lds_barrier();                                                                  // (3) every slot taken before the counts move
+                // the records go out in sorted order: a partition's run of the segment is contiguous in memory
+                {
+                    const int n_seg = FULL ? SEG : min(SEG, ne - s0);
+#pragma unroll
+                    for (int q = 0; q < EPT; q++) {
+                        const int j = q * NT + tid;
+                        if (j < n_seg) { const uint2 v = L.sorted[j]; P.part[v.x] = v.y; }
+                    }
+                }
                 {   // thread (wavefront w, lane p): the partition's counts move past the segment, the masks are cleared
                     const uint4 m = L.pmask[tid];
                     const uint32_t n = (uint32_t)(__builtin_popcount(m.x) + __builtin_popcount(m.y) + __builtin_popcount(m.z) + __builtin_popcount(m.w));

@@ -13,12 +13,12 @@
 //   k_events<PART>        per link: every event to its slot, {dwell, low 12 bits of the rank}; evrec = {slot, rank}
 //   k_part_hist           per (group, partition): samples per stream over the slice                  -> phist
 //   k_part_scan           per (worker chain, rank): exclusive scan over the chain's groups on top of the worker's row:
-//                         phist = the sub-row as the group finds it; the worker's row moves past the batch
-//   k_part_hand           per (group, partition): the slice in order against the sub-row in LDS: prior[slot] = samples the
-//                         event's stream has produced before it
-//   k_part_home           per 64-event tile: evrec.x = seed(worker, rank) * a^(2 * prior[slot])
+//                         phist = the streams' STATES as the group finds them; the worker's row moves past the batch
+//   k_part_hand           per (group, partition): the slice in order against the sub-row in LDS: state[slot] = the stream's
+//                         state at the event's first draw; the sub-row advances by a^(2 * dwell)
+//   k_samples*            evrec.x is the slot: the sample kernels fetch state[slot]
 //
-// Everything between the two k_events passes and k_part_home streams through memory sequentially (4 B per event and pass);
+// Everything between the two k_events passes and the sample kernels streams through memory sequentially (4 B per event and pass);
 // the scatter and the gather move runs of a (512-event segment, partition), which consecutive segments of a link extend.
 #pragma once
 
@@ -81,20 +81,28 @@ __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* __restrict__ 
 
 // One thread per (worker chain, rank): exclusive scan of phist over the chain's groups, starting from the worker's row
 // (sample counts, reduced mod (M-1)/2: only that matters for a^(2n)) plus, with range sharding, what the ranges before this
-// one draw (`before`; the row itself is then left to k_rows_advance).  grid (num_kmer / 256, worker chains).
+// one draw (`before`; the row itself is then left to k_rows_advance).  What a group gets is the stream's STATE as the
+// group finds it: seed(worker, rank) * a^(2 * samples before), the seed being (seed_base + worker*seed_step + rank) mod M
+// (src/sim.c:249) -- from there on k_part_hand advances states, one modular multiplication per event, as the 6-mer path does.
+// grid (num_kmer / 256, worker chains).
 __global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ phist, uint32_t* __restrict__ rows, const int num_kmer,
                                                    const int* __restrict__ wgroup_off, const int* __restrict__ wlink_worker,
-                                                   const uint32_t* __restrict__ before, unsigned int* __restrict__ err) {
+                                                   const uint32_t* __restrict__ before, const uint32_t* __restrict__ pw,
+                                                   const uint32_t seed_base, const uint32_t seed_step, unsigned int* __restrict__ err) {
     const int q = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
     if (j >= num_kmer) return;
-    const size_t wj = (size_t)wlink_worker[q] * num_kmer + j;
+    const int w = wlink_worker[q];
+    const size_t wj = (size_t)w * num_kmer + j;
+    const unsigned long long sv = ((unsigned long long)seed_base + (unsigned long long)w * seed_step) % LCG_M + (unsigned long long)j;
+    const uint32_t seed = (uint32_t)(sv >= LCG_M ? sv - LCG_M : sv);
     unsigned long long run = rows[wj] % LCG_ORD2;
     if (before) run += before[wj];
     const int g0 = wgroup_off[q], g1 = wgroup_off[q + 1];
     for (int g = g0; g < g1; g++) {
         uint32_t* cell = phist + (size_t)g * num_kmer + j;
         const uint32_t cnt = *cell;
-        *cell = (uint32_t)run;
+        const uint32_t n = (uint32_t)run;                         // (an overflow is reported below; the batch fails)
+        *cell = n ? lcg_mul(seed, lcg_jump2(pw, n)) : seed;
         run += cnt;
     }
     if (run > 0xffffffffull) atomicOr(err, 32u);                  // one stream asked for >= 2^32 samples by one batch
@@ -111,60 +119,74 @@ __global__ __launch_bounds__(256) void k_part_totals(const uint32_t* __restrict_
     counts[(size_t)wlink_worker[q] * num_kmer + j] = sum;
 }
 
-// grid: groups x partitions, 256 threads.  The slice is walked in order, 64 events per step and wavefront; wavefront v hands
-// out the streams whose sub-rank has v in its top two bits (every wavefront reads the whole slice: 4 B per event from L2).
-// In-order hand-out inside a step: the lanes of a stream queue on a tag (atomic min of the lane number, so the earliest event
-// wins the round), the winner reads and advances the sub-row, the others go another round (rarely: 16 events over 1024 streams).
-#define PART_TAGS 256
-__global__ __launch_bounds__(256) void k_part_hand(const uint32_t* __restrict__ part, uint32_t* __restrict__ prior_out,
-                                                   const uint32_t* __restrict__ slice_lo, const uint32_t* __restrict__ slice_hi,
-                                                   const uint32_t* __restrict__ phist) {
+// grid: groups x partitions, ONE wavefront each (the sub-row of stream states, 16 KiB, is the workgroup's LDS: every lane
+// busy, no sharing).  The slice is walked in order, 256 events per step (event b + 64q + lane is the lane's q-th); the next
+// step's loads are issued before this step's hand-out.
+// In-order hand-out inside a step: every event queues on its stream's tag with its position in the step (atomic min, so
+// the earliest event of a stream wins the round); winners hold distinct tags, hence distinct streams: each takes its
+// stream's state and advances it by its dwell (a^(2 * dwell) from LDS), the others go another round (the longest queue of
+// 256 events over 1024 tags is 2-4).  LDS operations of one wavefront execute in program order, which is all the ordering the
+// protocol needs.
+// BIGD: dwells of PART_JT samples and more exist (their multiplier comes from the global jump tables)
+#define PART_TAGS 1024
+#define PART_JT 256
+#define PART_SLACK 1024          // entries behind the bucketed events: read ahead by the last step of a slice, and the dump of its idle lanes' stores
+template <bool BIGD>
+__global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out,
+                                                  const uint32_t* __restrict__ slice_lo, const uint32_t* __restrict__ slice_hi,
+                                                  const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pw, const uint32_t dump) {
     __shared__ uint32_t row[PART_SUB];
-    __shared__ uint32_t tags[4][PART_TAGS];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const uint32_t* src = phist + (size_t)blockIdx.x * PART_SUB;
-    for (int i = tid; i < PART_SUB; i += 256) row[i] = src[i];
-    for (int i = tid; i < 4 * PART_TAGS; i += 256) (&tags[0][0])[i] = 0xffffffffu;
-    __syncthreads();
+    __shared__ uint32_t tg[PART_TAGS];
+    __shared__ uint32_t jt[PART_JT];                              // a^(2j)
+    const int lane = threadIdx.x;
+    const uint4* src = reinterpret_cast<const uint4*>(phist + (size_t)blockIdx.x * PART_SUB);
+    for (int i = lane; i < PART_SUB / 4; i += 64) reinterpret_cast<uint4*>(row)[i] = src[i];
+    for (int i = lane; i < PART_TAGS; i += 64) tg[i] = 0xffffffffu;
+    for (int i = lane; i < PART_JT; i += 64) jt[i] = pw[2 * POW_N + i];
     const uint32_t lo = slice_lo[blockIdx.x], hi = slice_hi[blockIdx.x];
-    uint32_t* tg = tags[wid];
-    for (uint32_t b = lo; b < hi; b += 64) {
-        const uint32_t i = b + lane;
-        const uint32_t rec = i < hi ? part[i] : 0u;
-        const uint32_t sub = rec & (PART_SUB - 1), d = rec >> 16;
-        bool pending = i < hi && (int)(sub >> (PART_SUB_BITS - 2)) == wid;
-        const uint32_t h = sub & (PART_TAGS - 1);
-        while (__builtin_amdgcn_ballot_w64(pending)) {
-            if (pending) atomicMin(&tg[h], (uint32_t)lane);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            if (pending && __hip_atomic_load(&tg[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT) == (uint32_t)lane) {
-                const uint32_t prior = row[sub];
-                row[sub] = prior + d;
-                prior_out[i] = prior;                               // (not in place: the other wavefronts still read part[i])
-                __hip_atomic_store(&tg[h], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                pending = false;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    uint32_t cur[4], nxt[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 4; q++) cur[q] = part[lo + 64 * q + lane];   // (unconditional: the arrays have PART_SLACK entries behind the last slice)
+    __syncthreads();
+    for (uint32_t b = lo; b < hi; b += 256) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) nxt[q] = part[b + 256 + 64 * q + lane];
+        uint32_t sub[4], h[4], mul[4], st[4], pri[4];
+        bool pend[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t rec = cur[q], d = rec >> 16;
+            sub[q] = rec & (PART_SUB - 1);
+            h[q] = sub[q] & (PART_TAGS - 1);
+            pri[q] = (uint32_t)(64 * q + lane);
+            pend[q] = b + 64 * q + lane < hi;
+            mul[q] = jt[d & (PART_JT - 1)];
+            if (BIGD && d >= PART_JT) mul[q] = lcg_jump2(pw, d);
+            st[q] = 0u;
         }
+        do {
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (pend[q]) atomicMin(&tg[h[q]], pri[q]);
+            uint32_t t[4], s0[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                t[q] = __hip_atomic_load(&tg[h[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                s0[q] = __hip_atomic_load(&row[sub[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (pend[q] && t[q] == pri[q]) {
+                    __hip_atomic_store(&row[sub[q]], lcg_mul(s0[q], mul[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    __hip_atomic_store(&tg[h[q]], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    st[q] = s0[q];
+                    pend[q] = false;
+                }
+            }
+        } while (__builtin_amdgcn_ballot_w64(pend[0] | pend[1] | pend[2] | pend[3]));
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t i = b + 64 * q + lane; state_out[i < hi ? i : dump + lane] = st[q]; }   // (straight-line code: the
+                                                              // wait for the next step's records then leaves these stores in flight)
+#pragma unroll
+        for (int q = 0; q < 4; q++) cur[q] = nxt[q];
     }
-}
-
-// one wavefront per 64-event tile: evrec.x (the event's slot, left by k_events<PART>) -> the stream state at the event's first
-// draw, seed(worker, rank) * a^(2 * samples before), the seed being (seed_w + rank) mod M (src/sim.c:249)
-__global__ __launch_bounds__(256) void k_part_home(const SigParams P, const int n_tiles) {
-    const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= n_tiles) return;
-    const int r = P.tile_read[g];
-    const ReadDesc rd = P.reads[r];
-    const int e = (g - rd.tile_off) * 64 + lane;
-    if (e >= rd.ne0 + rd.ne1) return;
-    uint2* er = P.evrec + rd.ev_off + e;
-    const uint2 v = *er;
-    const uint32_t prior = P.part_prior[v.x];
-    const uint32_t seed_w = (uint32_t)(((unsigned long long)P.seed_base + (unsigned long long)rd.worker * P.seed_step) % LCG_M);
-    const unsigned long long sv = (unsigned long long)seed_w + v.y;
-    uint32_t c = (uint32_t)(sv >= LCG_M ? sv - LCG_M : sv);
-    if (prior) c = lcg_mul(c, lcg_jump2(P.pw, prior));
-    er->x = c;
 }

@@ -226,6 +226,10 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         float2 md[LEAN_EPL];
 #pragma unroll
         for (int q = 0; q < LEAN_EPL; q++) md[q] = (e0 + q < ne) ? P.model[er[q].y] : make_float2(0.f, 0.f);
+        if (P.part_state) {                                            // (wave-uniform) k > 6, bucketed hand-out (k_part.h): slot -> state
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) if (e0 + q < ne) er[q].x = P.part_state[er[q].x];
+        }
         int lane_total = 0;
 #pragma unroll
         for (int q = 0; q < LEAN_EPL; q++) lane_total += sps[q];
@@ -384,6 +388,7 @@ __global__ __launch_bounds__(256) void k_samples(const SigParams P, const int n_
         if (valid) {
             er = P.evrec[rd.ev_off + e];
             sps = P.dwell ? (int)P.dwell[rd.ev_off + e] : P.const_sps;
+            if (P.part_state) er.x = P.part_state[er.x];                // k > 6, bucketed hand-out (k_part.h): slot -> state
         }
         const float2 md = valid ? P.model[er.y] : make_float2(0.f, 0.f);
         const int incl = wave_incl_scan(sps, lane);
