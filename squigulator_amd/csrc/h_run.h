@@ -51,7 +51,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     const int n_part = c->num_kmer >> PART_SUB_BITS;
     if (phase != 2 && b->part) {
         if ((rc = ensure(c, (void**)&c->d_part, &c->part_cap, (size_t)b->n_events + PART_SLACK, sizeof(uint32_t)))) return rc;
-        if ((rc = ensure(c, (void**)&c->d_pcnt, &c->pcnt_cap, (size_t)b->n_chains * (size_t)n_part, sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(c, (void**)&c->d_pcnt, &c->pcnt_cap, (size_t)2 * b->n_chains * (size_t)n_part, sizeof(uint32_t)))) return rc;   // counts, offsets
         if ((rc = ensure(c, (void**)&c->d_slice, &c->slice_cap, (size_t)2 * b->n_groups * (size_t)n_part, sizeof(uint32_t)))) return rc;
         if ((rc = ensure(c, (void**)&c->d_phist, &c->phist_cap, (size_t)b->n_groups * (size_t)c->num_kmer, sizeof(uint32_t)))) return rc;
     }
@@ -60,7 +60,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     SigParams P;
     memset(&P, 0, sizeof P);
     P.link_rows = (b->split && !b->part) ? c->d_link_rows : nullptr;
-    P.part = c->d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = c->d_pcnt; P.n_part = n_part;
+    P.part = c->d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = c->d_pcnt; P.poff = c->d_pcnt ? c->d_pcnt + (size_t)b->n_chains * n_part : nullptr; P.n_part = n_part;
     P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
     P.dwell = c->use_dwell_stream ? S.d_dwell : nullptr; P.dwell_out = S.d_dwell; P.seglen_out = S.d_seglen;
     P.dmean = p.dwell_mean; P.dstd = p.dwell_std;
@@ -124,8 +124,8 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             // k > 6, split chains: the hand-out over events bucketed by the top bits of the rank (k_part.h)
             if (phase != 2) {
                 launch_events(dw, true);                          // dwell draws; events per (link, partition)
-                hipLaunchKernelGGL(k_part_offsets, dim3((unsigned)b->n_wchains), dim3(1024), 0, c->stream, c->d_pcnt, n_part, b->d_wlink_off,
-                                   b->d_link_group, b->d_cbase, slice_lo, slice_hi);
+                hipLaunchKernelGGL(k_part_offsets, dim3((unsigned)n_part, (unsigned)b->n_wchains), dim3(1024), 0, c->stream, c->d_pcnt,
+                                   c->d_pcnt + (size_t)b->n_chains * n_part, n_part, b->d_wlink_off, b->d_link_group, b->d_cbase, slice_lo, slice_hi);
                 HIPCHK(c, hipGetLastError());
                 if ((rc = dbg_sync(c, "k_events<count>/k_part_offsets"))) return rc;
                 launch_events(0, false);                          // every event to its slot (the dwell is in memory now)

@@ -175,8 +175,9 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         const bool want = c->range_mode ? n > 0 : forced >= 0 ? (forced > 0 && multi) : (multi && n_wchains < 1024 && nev >= 65536);
         if (c->use_kmer_streams && want) {
             const size_t row_bytes = (size_t)c->num_kmer * sizeof(uint32_t);
-            long long target = forced > 0 ? forced : 2048;
-            target = std::min<long long>(target, std::max<long long>(8, (long long)(((size_t)1 << 30) / row_bytes)));
+            const bool part_ok = k > 6 && nev < 4294967000LL && !getenv("SQG_NO_PART");     // bucketed hand-out (below): no per-link rows
+            long long target = forced > 0 ? forced : part_ok ? 4096 : 2048;
+            if (!part_ok) target = std::min<long long>(target, std::max<long long>(8, (long long)(((size_t)1 << 30) / row_bytes)));
             std::vector<int> link_off(1, 0);
             for (int q = 0; q < n_wchains; q++) {
                 const int lo = wchain_off[(size_t)q], hi = wchain_off[(size_t)q + 1];
@@ -209,7 +210,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     // the per-link rows of round 1, for A/B runs).
     std::vector<int> link_group, wgroup_off(1, 0);
     std::vector<uint32_t> cbase;
-    if (b->split && k > 6 && nev < 4294967000LL && !getenv("SQG_NO_PART")) {
+    if (b->split && k > 6 && nev < 4294967000LL && !getenv("SQG_NO_PART")) {                  // (= part_ok above)
         const int n_part = c->num_kmer >> PART_SUB_BITS;
         const char* genv = getenv("SQG_PART_GROUPS");
         const long long tg = genv ? std::max(1, atoi(genv)) : std::max(1, 4096 / n_part);

@@ -187,7 +187,8 @@ struct SigParams {
                                  // (dwell << 16) | low PART_SUB_BITS of the rank
     uint32_t* part_state;        // [n_events] same slots (k_part_hand): the stream's state at the event's first draw; non-null tells
                                  // the sample kernels that evrec.x is a slot, not a state
-    uint32_t* pcnt;              // [n_links][n_part] events per (link, partition); k_part_offsets turns it into the first slot
+    uint32_t* pcnt;              // [n_links][n_part] events per (link, partition)
+    const uint32_t* poff;        // [n_links][n_part] first slot in part[] of the link's events of the partition (k_part_offsets)
     int n_part;                  // partitions = num_kmer >> PART_SUB_BITS
 };
 

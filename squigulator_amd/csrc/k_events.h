@@ -337,7 +337,7 @@ __device__ static inline void lds_barrier() {
 // workgroup's row (split chains, see above)
 // PART (k > 6, with HIST or after it): the stream hand-out is left to k_part_hist / k_part_scan / k_part_hand, which walk the
 // events bucketed by the top bits of their rank (k_part.h).  With HIST: events per (link, partition) -> P.pcnt.  Without:
-// every event is written to its slot in P.part -- (link, partition)'s first slot from P.pcnt, then stable in event order
+// every event is written to its slot in P.part -- (link, partition)'s first slot from P.poff, then stable in event order
 // -- and its evrec holds {slot, rank} for k_part_home.
 template <int NT, bool DIRECT, int DW, int EPT, bool HIST = false, bool PART = false>
 __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events(const SigParams P) {
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
                                         (unsigned long long)(P.rows ? P.reads[P.chain_reads[c_lo]].worker : 0) * P.seed_step) % LCG_M);
     if (DIRECT && P.use_streams) for (int i = tid; i < P.num_kmer; i += NT) L.row[i] = HIST ? 0u : row[i];
     if (PART) {
-        if (tid < PART_MAX) L.prun[tid] = (HIST || tid >= P.n_part) ? 0u : P.pcnt[(size_t)chain * P.n_part + tid];
+        if (tid < PART_MAX) L.prun[tid] = (HIST || tid >= P.n_part) ? 0u : P.poff[(size_t)chain * P.n_part + tid];
         for (int i = tid; i < (NT / 64) * PART_MAX; i += NT) L.pmask[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     const uint32_t a2nt = DW ? lcg_jump2(P.pw, (uint32_t)SEG) : 0u;      // time-stream jump over one segment

@@ -8,7 +8,7 @@
 // rank >> 12, 64 of them for 9-mers), stably, and each bucket is walked against its own 4096-entry sub-row in LDS:
 //
 //   k_events<HIST, PART>  per link: dwell draws, ranks, events per (link, partition)                  -> pcnt
-//   k_part_offsets        per worker chain: pcnt -> first slot of every (link, partition) in part[], and the slices
+//   k_part_offsets        per (worker chain, partition): pcnt -> first slot of every (link, partition) in part[], and the slices
 //                         [lo, hi) of part[] that belong to each (group of links, partition)
 //   k_events<PART>        per link: every event to its slot, {dwell, low 12 bits of the rank}; evrec = {slot, rank}
 //   k_part_hist           per (group, partition): samples per stream over the slice                  -> phist
@@ -22,42 +22,42 @@
 // the scatter and the gather move runs of a (512-event segment, partition), which consecutive segments of a link extend.
 #pragma once
 
-// grid: worker chains; 1024 threads = n_part partitions x (1024 / n_part) runs of consecutive links.
+// grid (partitions, worker chains), 1024 threads, each with a run of consecutive links of the chain.
 //   wlink_off[q]..wlink_off[q+1]   the links of worker chain q, in chain order
 //   link_group[l]                  the group a link belongs to (consecutive links of a chain, ascending)
-//   cbase[q]                       first slot of the chain's region in part[]
-__global__ __launch_bounds__(1024) void k_part_offsets(uint32_t* __restrict__ pcnt, const int n_part, const int* __restrict__ wlink_off,
-                                                       const int* __restrict__ link_group, const uint32_t* __restrict__ cbase,
+//   cbase[q]                       first slot of the chain's region in part[]; the region is partition-major
+// poff[l][p] <- first slot of link l's events of partition p; slice_lo/hi[g][p] <- the slots of group g's events of partition p
+__global__ __launch_bounds__(1024) void k_part_offsets(const uint32_t* __restrict__ pcnt, uint32_t* __restrict__ poff, const int n_part,
+                                                       const int* __restrict__ wlink_off, const int* __restrict__ link_group,
+                                                       const uint32_t* __restrict__ cbase,
                                                        uint32_t* __restrict__ slice_lo, uint32_t* __restrict__ slice_hi) {
-    __shared__ uint32_t sums[1024];
-    __shared__ uint32_t pstart[PART_MAX + 1], ptot[PART_MAX];
-    const int q = blockIdx.x, tid = threadIdx.x;
-    const int p = tid % n_part, sg = tid / n_part, nsg = 1024 / n_part;
+    __shared__ uint32_t wsum[16], wlow[16];
+    const int p = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l0 = wlink_off[q], l1 = wlink_off[q + 1];
-    const int per = (l1 - l0 + nsg - 1) / nsg, la = min(l0 + sg * per, l1), lb = min(la + per, l1);
-    uint32_t sum = 0;
-    for (int l = la; l < lb; l++) sum += pcnt[(size_t)l * n_part + p];
-    sums[tid] = sum;
-    __syncthreads();
-    if (tid < n_part) { uint32_t t = 0; for (int s = 0; s < nsg; s++) t += sums[s * n_part + tid]; ptot[tid] = t; }
-    __syncthreads();
-    if (tid == 0) {                                               // the chain's region: partition-major
-        uint32_t run = cbase[q];
-        for (int pp = 0; pp < n_part; pp++) { pstart[pp] = run; run += ptot[pp]; }
-        pstart[n_part] = run;
+    const int per = (l1 - l0 + 1023) / 1024, la = min(l0 + tid * per, l1), lb = min(la + per, l1);
+    uint32_t own = 0, lower = 0;                                  // my links' events of partition p / of the partitions below p
+    for (int l = la; l < lb; l++) {
+        const uint32_t* row = pcnt + (size_t)l * n_part;
+        own += row[p];
+        for (int pp = 0; pp < p; pp++) lower += row[pp];
     }
+    uint32_t incl = (uint32_t)wave_incl_scan_dpp((int)own);
+    for (int o = 32; o > 0; o >>= 1) lower += __shfl_xor(lower, o);
+    if (lane == 63) wsum[wid] = incl;
+    if (lane == 0) wlow[wid] = lower;
     __syncthreads();
-    uint32_t at = pstart[p];
-    for (int s = 0; s < sg; s++) at += sums[s * n_part + p];
+    uint32_t start = cbase[q], before = 0, total = 0;             // start: first slot of (chain, partition)
+    for (int w = 0; w < 16; w++) { start += wlow[w]; if (w < wid) before += wsum[w]; total += wsum[w]; }
+    uint32_t at = start + before + incl - own;
     for (int l = la; l < lb; l++) {
         const uint32_t cnt = pcnt[(size_t)l * n_part + p];
-        pcnt[(size_t)l * n_part + p] = at;
+        poff[(size_t)l * n_part + p] = at;
         const int g = link_group[l];
         if (l == l0 || link_group[l - 1] != g) {                  // the link opens a group
             slice_lo[(size_t)g * n_part + p] = at;
             if (l != l0) slice_hi[(size_t)(g - 1) * n_part + p] = at;
         }
-        if (l == l1 - 1) slice_hi[(size_t)g * n_part + p] = pstart[p + 1];
+        if (l == l1 - 1) slice_hi[(size_t)g * n_part + p] = start + total;
         at += cnt;
     }
 }
@@ -70,9 +70,12 @@ __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* __restrict__ 
     for (int i = tid; i < PART_SUB; i += 256) row[i] = 0u;
     __syncthreads();
     const uint32_t lo = slice_lo[blockIdx.x], hi = slice_hi[blockIdx.x];
-    for (uint32_t i = lo + tid; i < hi; i += 256) {
-        const uint32_t rec = part[i];
-        atomicAdd(&row[rec & (PART_SUB - 1)], rec >> 16);
+    for (uint32_t b = lo; b < hi; b += 1024) {
+        uint32_t rec[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) rec[q] = part[b + 256 * q + tid];        // (unconditional: PART_SLACK entries behind the last slice)
+#pragma unroll
+        for (int q = 0; q < 4; q++) if (b + 256 * q + tid < hi) atomicAdd(&row[rec[q] & (PART_SUB - 1)], rec[q] >> 16);
     }
     __syncthreads();
     uint32_t* dst = phist + (size_t)blockIdx.x * PART_SUB;       // [g][p][sub] = [g][rank]
@@ -119,74 +122,103 @@ __global__ __launch_bounds__(256) void k_part_totals(const uint32_t* __restrict_
     counts[(size_t)wlink_worker[q] * num_kmer + j] = sum;
 }
 
-// grid: groups x partitions, ONE wavefront each (the sub-row of stream states, 16 KiB, is the workgroup's LDS: every lane
-// busy, no sharing).  The slice is walked in order, 256 events per step (event b + 64q + lane is the lane's q-th); the next
-// step's loads are issued before this step's hand-out.
-// In-order hand-out inside a step: every event queues on its stream's tag with its position in the step (atomic min, so
-// the earliest event of a stream wins the round); winners hold distinct tags, hence distinct streams: each takes its
-// stream's state and advances it by its dwell (a^(2 * dwell) from LDS), the others go another round (the longest queue of
-// 256 events over 1024 tags is 2-4).  LDS operations of one wavefront execute in program order, which is all the ordering the
-// protocol needs.
+// grid: groups x partitions, ONE wavefront each (the sub-row of stream states, 16 KiB, is the workgroup's LDS: no sharing,
+// every lane busy).  The slice is walked in order in steps of 1024 events: the step's 16 loads per lane are in flight while the
+// step before is handed out, its 16 stores go out together at the end (on gfx950 a wavefront that waits for a load also waits
+// for its own earlier stores: they are kept few and far from the loads).  A step is handed out in four phases of 256 events
+// (event 64q + lane of the phase is the lane's q-th).
+// In-order hand-out of a phase.  First try, plain LDS traffic only: every event writes its position in the phase to its
+// stream's tag and reads it back; the events that do not find themselves write "contended" over the tag; an event that still
+// finds itself after that is alone on its stream in this phase: it takes the stream's state and advances it by its dwell
+// (a^(2 * dwell) from LDS).  The events of contended streams (6 % of them: 256 events over 4096 streams) queue on a small
+// hashed tag array with an atomic min of their position, so that the earliest wins the round, until none is left.
+// LDS operations of one wavefront execute in program order, which is all the ordering the protocol needs.
 // BIGD: dwells of PART_JT samples and more exist (their multiplier comes from the global jump tables)
-#define PART_TAGS 1024
+#define PART_ATAGS 256
 #define PART_JT 256
-#define PART_SLACK 1024          // entries behind the bucketed events: read ahead by the last step of a slice, and the dump of its idle lanes' stores
+#define PART_STEP 1024
+#define PART_SLACK (2 * PART_STEP)   // entries behind the bucketed events: read ahead by the last step of a slice, and the dump of idle lanes' stores
 template <bool BIGD>
 __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out,
                                                   const uint32_t* __restrict__ slice_lo, const uint32_t* __restrict__ slice_hi,
                                                   const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pw, const uint32_t dump) {
     __shared__ uint32_t row[PART_SUB];
-    __shared__ uint32_t tg[PART_TAGS];
+    __shared__ uint16_t tg[PART_SUB];                             // position in the phase of the (last) event that took the tag; 0x100: contended
+    __shared__ uint32_t atg[PART_ATAGS];
     __shared__ uint32_t jt[PART_JT];                              // a^(2j)
+    constexpr int NR = PART_STEP / 64;                            // records per lane and step
     const int lane = threadIdx.x;
     const uint4* src = reinterpret_cast<const uint4*>(phist + (size_t)blockIdx.x * PART_SUB);
     for (int i = lane; i < PART_SUB / 4; i += 64) reinterpret_cast<uint4*>(row)[i] = src[i];
-    for (int i = lane; i < PART_TAGS; i += 64) tg[i] = 0xffffffffu;
+    for (int i = lane; i < PART_ATAGS; i += 64) atg[i] = 0xffffffffu;
     for (int i = lane; i < PART_JT; i += 64) jt[i] = pw[2 * POW_N + i];
     const uint32_t lo = slice_lo[blockIdx.x], hi = slice_hi[blockIdx.x];
-    uint32_t cur[4], nxt[4] = {0u, 0u, 0u, 0u};
+    uint32_t cur[NR], nxt[NR];
 #pragma unroll
-    for (int q = 0; q < 4; q++) cur[q] = part[lo + 64 * q + lane];   // (unconditional: the arrays have PART_SLACK entries behind the last slice)
+    for (int r = 0; r < NR; r++) cur[r] = part[lo + 64 * r + lane];   // (unconditional: PART_SLACK entries behind the last slice)
     __syncthreads();
-    for (uint32_t b = lo; b < hi; b += 256) {
+    for (uint32_t b = lo; b < hi; b += PART_STEP) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) nxt[q] = part[b + 256 + 64 * q + lane];
-        uint32_t sub[4], h[4], mul[4], st[4], pri[4];
-        bool pend[4];
+        for (int r = 0; r < NR; r++) nxt[r] = part[b + PART_STEP + 64 * r + lane];
+        uint32_t out[NR];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t rec = cur[q], d = rec >> 16;
-            sub[q] = rec & (PART_SUB - 1);
-            h[q] = sub[q] & (PART_TAGS - 1);
-            pri[q] = (uint32_t)(64 * q + lane);
-            pend[q] = b + 64 * q + lane < hi;
-            mul[q] = jt[d & (PART_JT - 1)];
-            if (BIGD && d >= PART_JT) mul[q] = lcg_jump2(pw, d);
-            st[q] = 0u;
-        }
-        do {
-#pragma unroll
-            for (int q = 0; q < 4; q++) if (pend[q]) atomicMin(&tg[h[q]], pri[q]);
-            uint32_t t[4], s0[4];
+        for (int ph = 0; ph < NR / 4; ph++) {
+            uint32_t sub[4], mul[4], st[4];
+            uint16_t pri[4];
+            bool pend[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                t[q] = __hip_atomic_load(&tg[h[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                s0[q] = __hip_atomic_load(&row[sub[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                const uint32_t rec = cur[4 * ph + q], d = rec >> 16;
+                sub[q] = rec & (PART_SUB - 1);
+                pri[q] = (uint16_t)(64 * q + lane);
+                pend[q] = b + 256 * ph + 64 * q + lane < hi;
+                mul[q] = jt[d & (PART_JT - 1)];
+                if (BIGD && d >= PART_JT) mul[q] = lcg_jump2(pw, d);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (pend[q]) __hip_atomic_store(&tg[sub[q]], pri[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            uint16_t t[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) t[q] = __hip_atomic_load(&tg[sub[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (pend[q] && t[q] != pri[q]) __hip_atomic_store(&tg[sub[q]], (uint16_t)0x100, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                t[q] = __hip_atomic_load(&tg[sub[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                st[q] = __hip_atomic_load(&row[sub[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                if (pend[q] && t[q] == pri[q]) {
-                    __hip_atomic_store(&row[sub[q]], lcg_mul(s0[q], mul[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    __hip_atomic_store(&tg[h[q]], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    st[q] = s0[q];
+                if (pend[q] && t[q] == pri[q]) {                   // alone on the stream in this phase
+                    __hip_atomic_store(&row[sub[q]], lcg_mul(st[q], mul[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                     pend[q] = false;
                 }
             }
-        } while (__builtin_amdgcn_ballot_w64(pend[0] | pend[1] | pend[2] | pend[3]));
+            while (__builtin_amdgcn_ballot_w64(pend[0] | pend[1] | pend[2] | pend[3])) {     // contended streams, in order
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const uint32_t i = b + 64 * q + lane; state_out[i < hi ? i : dump + lane] = st[q]; }   // (straight-line code: the
-                                                              // wait for the next step's records then leaves these stores in flight)
+                for (int q = 0; q < 4; q++) if (pend[q]) atomicMin(&atg[sub[q] & (PART_ATAGS - 1)], (uint32_t)pri[q]);
+                uint32_t ta[4], s0[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) cur[q] = nxt[q];
+                for (int q = 0; q < 4; q++) {
+                    ta[q] = __hip_atomic_load(&atg[sub[q] & (PART_ATAGS - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    s0[q] = __hip_atomic_load(&row[sub[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (pend[q] && ta[q] == (uint32_t)pri[q]) {
+                        __hip_atomic_store(&row[sub[q]], lcg_mul(s0[q], mul[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        __hip_atomic_store(&atg[sub[q] & (PART_ATAGS - 1)], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        st[q] = s0[q];
+                        pend[q] = false;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) out[4 * ph + q] = st[q];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) { const uint32_t i = b + 64 * r + lane; state_out[i < hi ? i : dump + lane] = out[r]; }
+#pragma unroll
+        for (int r = 0; r < NR; r++) cur[r] = nxt[r];
     }
 }

@@ -12,6 +12,6 @@ for f in glob.glob("$OUT/**/q_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"][:50]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
-    if any(t in k for t in ("k_events", "k_samples_lean")):
+    if any(t in k for t in ("k_events", "k_samples_lean", "k_part")):
         print(k, {c: "%.4g" % (sum(v) / len(v)) for c, v in d.items()})
 PY
