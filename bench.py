@@ -1,31 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- simulated raw samples/s of the per-read signal path on N MI355X.
 
-Workload (BASELINE.json configs[1]): nCoV-2019 reference, -x dna-r9-prom (R9 6-mer pore model),
-reads of gamma-distributed length (-r 10000) cut from the 29 903-nt genome, --seed 42.  One "step" is
-one batch (one process_db()) of --batch-reads reads in the T=K regime: read i of a batch runs on
-virtual worker i.  Steps x batch-reads reads in total; the default 12 x 32768 = 4 x the config's n=100000.
-The reads are the ones the reference itself would draw: gen_read (src/genread.c) with `--seed 42 -t T -K T`
-on the genome kept in HBM, sampled by the library's device-side sampler at staging time (--host-sampler:
-numpy draws of the same distribution, uploaded).  Inputs (sequences, per-read descriptors) are resident in
-HBM before the timed region starts.
+Headline workload (BASELINE.json configs[2], the configuration the metric is quoted on): a synthetic hg38-scale
+genome -- 24 contigs with hg38's chromosome lengths (3.09 Gb, i.i.d. ACGT, telomere / acrocentric / heterochromatin-like
+N runs: hg38 itself is not available offline) kept in HBM -- `-x dna-r10-prom` (R10 9-mer pore model),
+`-r 10000 --seed 42`, reads drawn by the library's device-side gen_read (src/genread.c).  One "step" is one batch
+(one process_db()) of --batch-reads reads per GPU.  Regime: ONE virtual worker per GPU (`-t N -K N*batch`, the
+reference's static partition, src/thread.c:80-99); on one GPU that is the reference's reproducible `-t 1`.  A worker's
+reads of a batch form one chain; the library cuts it into links and, for 9-mers, hands the k-mer streams out over events
+bucketed by the top bits of the rank (squigulator_amd/csrc/k_part.h).  Inputs (sequences, descriptors) are resident in HBM
+before the timed region starts; the K timed steps are queued back to back.
 
-N>1: one process per GPU (torch.distributed, backend nccl = RCCL).  The job's T = N*K virtual workers
-are sharded contiguously over ranks; each rank stages and runs only its own workers' reads (no
-steady-state collective; one broadcast of the pore model at start-up) => weak scaling.
+Other workloads (--workload): ncov-r9 (configs[1], T=K regime), sequin-rna004 (configs[4]), synth-r10 (a small genome).
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (k_samples_lean) against HBM:
-achieved = algorithmic bytes (2*N_samples + N_bases + 24*N_reads per launch) / its
-average launch duration measured with hipEvents on the library's stream.  `cpu_baseline` is the
-oracle (a C restatement of the reference's path, oracle/) timed on this box's host cores on a bounded
-sample of the same workload.
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL).  Started without WORLD_SIZE, `--gpus N` launches the N
+ranks itself (python -m torch.distributed.run on 127.0.0.1).  The job's T virtual workers are sharded contiguously over
+the ranks; each rank stages and runs only its own workers' reads (no steady-state collective; one broadcast of the pore
+model at start-up) => weak scaling.  --job-workers T: range sharding instead (every rank owns all T workers and
+generates a range of each batch; one all-gather of per-stream sample counts per batch).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (k_samples_lean) against HBM: achieved =
+algorithmic bytes (2*N_samples + N_bases + 24*N_reads per launch) / its average launch duration measured
+with hipEvents on the library's stream; `step_frac` is the same bytes over the whole step.  `cpu_baseline` is the
+reference's own gensig.c/genread.c (oracle/_ref/ref_harness) timed on this box's host cores, one `-t 1` process per
+physical core, read loop only (kind "reference"); the oracle restatement (kind "port") when that binary is absent.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -37,39 +45,16 @@ from squigulator_amd import api, model, profiles, shard  # noqa: E402
 
 HBM_PEAK_BYTES_PER_S = 8.0e12   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 GENOME = os.path.join(ROOT, "tests", "golden", "inputs", "nCoV-2019.reference.fasta")
+SEQUINS = os.path.join(ROOT, "tests", "golden", "inputs", "rnasequin_sequences_2.4.fa")
 
-
-def load_genome(path):
-    seq = []
-    with open(path) as f:
-        for line in f:
-            if not line.startswith(">"):
-                seq.append(line.strip())
-    return "".join(seq).encode()
-
-
-_COMP = bytes.maketrans(b"ACGTacgt", b"TGCATGCA")
-
-
-def sample_reads(genome: bytes, n: int, rlen: int, rng: np.random.Generator):
-    """Reads with the reference sampler's distribution (src/genread.c:243-281): length ~ Erlang-2 with
-    scale rlen/2, start uniform over the genome, clipped at the contig end, >=200 nt, random strand."""
-    out = []
-    G = len(genome)
-    while len(out) < n:
-        m = n - len(out)
-        lens = rng.gamma(2.0, rlen / 2, size=m).astype(np.int64)
-        pos = rng.integers(0, G, size=m)
-        strand = rng.integers(0, 2, size=m)
-        for L, p, s in zip(lens, pos, strand):
-            r = genome[p:p + L]
-            if len(r) < 200:
-                continue
-            out.append(r if s else r.translate(_COMP)[::-1])
-    return out[:n]
-
-
-HG38_CHR_MB = [248, 242, 198, 190, 182, 171, 159, 145, 138, 134, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51, 156, 57]
+# GRCh38 primary assembly, chr1..22, X, Y
+HG38_LEN = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+            135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167,
+            46709983, 50818468, 156040895, 57227415]
+# N runs besides 10 kb at both ends of every contig: (contig, start as a fraction of its length, length as a fraction) --
+# the acrocentric short arms, the large heterochromatin gaps of chr1/9/16 and of chrY: 4.9 % of the genome, as in hg38
+HG38_NRUNS = [(12, 0.0, 0.14), (13, 0.0, 0.15), (14, 0.0, 0.167), (20, 0.0, 0.107), (21, 0.0, 0.207),
+              (0, 0.49, 0.072), (8, 0.31, 0.13), (15, 0.40, 0.10), (23, 0.47, 0.52)]
 
 
 def load_contigs(path):
@@ -87,39 +72,88 @@ def load_contigs(path):
     return out
 
 
-def synthetic_genome(total_mb: float, seed: int = 1):
-    """hg38 is not available offline: 24 contigs with hg38's chromosome proportions, i.i.d. uniform ACGT
-    from a fixed seed, a few N runs (telomere/centromere-like) to exercise the sampler's rejection rule."""
+def genome_layout(total_mb: float | None):
+    """contig lengths (hg38's, or scaled to total_mb) and the N runs as (absolute start, length)"""
+    scale = 1.0 if total_mb is None else total_mb * 1e6 / sum(HG38_LEN)
+    lens = [max(int(n * scale), 5000) for n in HG38_LEN]
+    off = np.concatenate([[0], np.cumsum(lens)])
+    tel = max(int(10000 * min(scale * 30, 1.0)), 50)
+    runs = []
+    for c, n in enumerate(lens):
+        runs.append((int(off[c]), min(tel, n // 20)))
+        runs.append((int(off[c]) + n - min(tel, n // 20), min(tel, n // 20)))
+    for c, s, l in HG38_NRUNS:
+        runs.append((int(off[c]) + int(s * lens[c]), int(l * lens[c])))
+    return lens, runs
+
+
+def synthetic_genome_host(total_mb: float, seed: int = 1):
+    """the same layout on the host (numpy), for the CPU legs and the tests: list of contigs (bytes)"""
+    lens, runs = genome_layout(total_mb)
     rng = np.random.default_rng(seed)
-    lut = np.frombuffer(b"ACGT", np.uint8)
-    scale = total_mb * 1e6 / (sum(HG38_CHR_MB) * 1e6)
-    contigs = []
-    for mb in HG38_CHR_MB:
-        n = max(int(mb * 1e6 * scale), 5000)
-        a = lut[rng.integers(0, 4, n, dtype=np.uint8)]
-        a[:min(1000, n // 50)] = ord("N")
-        mid = n // 3
-        a[mid:mid + min(3000, n // 20)] = ord("N")
-        contigs.append(a.tobytes())
-    return contigs
+    a = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, sum(lens), dtype=np.uint8)]
+    for s, l in runs:
+        a[s:s + l] = ord("N")
+    off = np.concatenate([[0], np.cumsum(lens)])
+    return [a[off[i]:off[i + 1]].tobytes() for i in range(len(lens))]
+
+
+def synthetic_genome_device(total_mb: float | None, device, seed: int = 1):
+    """the synthetic genome made in HBM (torch is the allocator here): (uint8 tensor of the concatenated contigs, lengths)"""
+    import torch
+    lens, runs = genome_layout(total_mb)
+    total = sum(lens)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    seq = torch.empty(total, dtype=torch.uint8, device=device)
+    step = 1 << 28
+    for s in range(0, total, step):
+        c = torch.randint(0, 4, (min(step, total - s),), dtype=torch.uint8, device=device, generator=g)
+        # 0,1,2,3 -> 'A','C','G','T' = 65,67,71,84
+        seq[s:s + len(c)] = 65 + 2 * c + 2 * (c >= 2).to(torch.uint8) + 11 * (c == 3).to(torch.uint8)
+    for s, l in runs:
+        seq[s:s + l] = ord("N")
+    return seq, lens
+
+
+_COMP = bytes.maketrans(b"ACGTacgt", b"TGCATGCA")
+
+
+def sample_reads_host(contigs, n: int, rlen: int, rng: np.random.Generator):
+    """Reads with the reference sampler's distribution (src/genread.c:243-281) drawn with numpy: length ~ Erlang-2 with
+    scale rlen/2, start uniform over the genome, clipped at the contig end, >= 200 nt, <= 10 % N, random strand."""
+    out = []
+    cum = np.cumsum([len(c) for c in contigs])
+    while len(out) < n:
+        m = n - len(out)
+        lens = rng.gamma(2.0, rlen / 2, size=m).astype(np.int64)
+        pos = rng.integers(0, cum[-1], size=m)
+        strand = rng.integers(0, 2, size=m)
+        for L, p, s in zip(lens, pos, strand):
+            ci = int(np.searchsorted(cum, p, side="right"))
+            q = int(p - (cum[ci - 1] if ci else 0))
+            r = contigs[ci][q:q + int(L)]
+            if len(r) < 200 or r.count(b"N") * 10 > len(r):
+                continue
+            r = r.replace(b"N", b"A")
+            out.append(r if s else r.translate(_COMP)[::-1])
+    return out[:n]
 
 
 WORKLOADS = {
-    # name: (profile, extra flags, sampler mode, description)
-    "ncov-r9": ("dna-r9-prom", 0, "dna", "nCoV-2019.reference.fasta -x dna-r9-prom (BASELINE.json configs[1])"),
-    "synth-r10": ("dna-r10-prom", 0, "dna", "synthetic hg38-proportioned genome -x dna-r10-prom (configs[2]/[3]; hg38 itself is not available offline)"),
-    "sequin-rna004": ("rna004-prom", profiles.SQ_PREFIX, "rna", "rnasequin_sequences_2.4.fa -x rna004-prom --prefix=yes, whole transcripts (configs[4])"),
+    # name: (profile, extra flags, sampler mode, workers per GPU (0: one per read), reads per step per GPU, description)
+    "hg38-r10": ("dna-r10-prom", 0, "dna", 1, 8192,
+                 "synthetic hg38-scale genome (24 contigs, hg38's chromosome lengths, 3.09 Gb) -x dna-r10-prom (BASELINE.json configs[2]; "
+                 "configs[3] at N=8)"),
+    "ncov-r9": ("dna-r9-prom", 0, "dna", 0, 32768, "nCoV-2019.reference.fasta -x dna-r9-prom (BASELINE.json configs[1])"),
+    "synth-r10": ("dna-r10-prom", 0, "dna", 1, 8192, "small synthetic hg38-proportioned genome (--genome-mb) -x dna-r10-prom"),
+    "sequin-rna004": ("rna004-prom", profiles.SQ_PREFIX, "rna", 0, 32768,
+                      "rnasequin_sequences_2.4.fa -x rna004-prom --prefix=yes, whole transcripts (configs[4])"),
 }
 
 
-def pack(reads):
-    off = np.zeros(len(reads) + 1, np.int64)
-    off[1:] = np.cumsum([len(r) for r in reads])
-    return b"".join(reads), off
-
-
-def pmc_traffic(profile, batch_reads, rlen, mode):
-    """HBM bytes per k_samples launch from the rocprofv3 PMC passes of the same command
+def pmc_traffic(workload_key):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of the same command
     (tools/prof_pmc.sh -> profiles/traffic_latest.json); None when no profile of this workload exists.
     The counters cannot be read from inside the process being timed, so the bench quotes the committed
     measurement of the identical configuration."""
@@ -127,156 +161,213 @@ def pmc_traffic(profile, batch_reads, rlen, mode):
     try:
         with open(path) as f:
             doc = json.load(f)
-        if doc.get("workload_key") == f"{profile}|batch_reads={batch_reads}|rlen={rlen}|mode={mode}":
+        if doc.get("workload_key") == workload_key:
             return float(doc["kernels"]["k_samples_lean"]["hbm_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass
     return None
 
 
-def cpu_baseline(prof, flags, k, mean, stdv, genome, rlen, target_cpu_seconds=20.0, check_mode=None):
-    """Oracle (oracle/libsqg_oracle.so) on the host cores, T=K regime, bounded sample.  With check_mode the same
-    reads also go through the HIP path and every int16 is compared (the oracle as the checker): `parity`."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import ctypes
-    import orc
-    cores = os.cpu_count() or 1
-    # the oracle (like the reference) mallocs a >128 KiB signal buffer per read; with hundreds of threads glibc's
-    # default mmap threshold turns that into mmap/munmap storms.  Keep those allocations on the heap so the
-    # baseline measures generation, not the kernel's mmap lock.
+def host_info():
+    """(CPU model, physical cores, hardware threads)"""
+    name, phys = "unknown", set()
     try:
-        libc = ctypes.CDLL("libc.so.6")
-        libc.mallopt(-3, 1 << 30)      # M_MMAP_THRESHOLD
-        libc.mallopt(-1, 1 << 30)      # M_TRIM_THRESHOLD
+        with open("/proc/cpuinfo") as f:
+            pid = cid = None
+            for line in f:
+                if line.startswith("model name") and name == "unknown":
+                    name = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    pid = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    cid = line.split(":")[1].strip()
+                elif not line.strip():
+                    if pid is not None and cid is not None:
+                        phys.add((pid, cid))
+                    pid = cid = None
     except OSError:
         pass
-    rng = np.random.default_rng(1234)
-    # calibrate the single-core rate on a few reads, then size the timed sample for ~target_cpu_seconds
-    # of CPU work in total (and at least 4 reads per core so every core has work)
-    probe = sample_reads(genome, 8, rlen, rng)
-    o = orc.Oracle(prof, flags, k, mean, stdv, 42, num_workers=len(probe))
-    t0 = time.perf_counter()
-    res = o.run_batch_seqs(probe, want_ss=False, nthreads=1)
-    dt = time.perf_counter() - t0
-    o.close()
-    ns = sum(len(r.sig) for r in res)
-    rate1 = ns / dt                                   # one core, samples/s
-    mean_len = ns / len(probe)
-    n = int(min(max(target_cpu_seconds * rate1 / mean_len, 4 * cores), 20000))
-    reads = sample_reads(genome, n, rlen, rng)
-    o = orc.Oracle(prof, flags, k, mean, stdv, 42, num_workers=n)
-    t0 = time.perf_counter()
-    res = o.run_batch_seqs(reads, want_ss=False, nthreads=cores)
-    dt = time.perf_counter() - t0
-    o.close()
-    ns = sum(len(r.sig) for r in res)
-    out = {"value": ns / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-           "sample": f"{n} reads / {ns} samples of the same workload, generation only (no BLOW5 encode), "
-                     f"-t {n} -K {n} on {cores} host threads, {dt:.2f} s wall"}
-    if check_mode is not None:
-        # the very same reads, seed and workers through the C ABI: bit-for-bit comparison of the whole sample
-        gen = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=n, mode=check_mode)
-        b = gen.submit(reads)
-        sig = b.signal()
-        bad = 0
-        for i, r in enumerate(res):
-            got = sig[b.sig_off[i]:b.sig_off[i + 1]]
-            if len(got) != len(r.sig) or not np.array_equal(got, r.sig):
-                bad += 1
-        out["parity"] = {"reads": n, "samples": int(ns), "reads_differing": bad, "equal": bad == 0 and int(b.n_samples) == int(ns)}
-        b.free(); gen.close()
-    return out
+    threads = os.cpu_count() or 1
+    return name, (len(phys) or threads), threads
 
 
-def cpu_reference(prof, flags, k, mean, stdv, nproc, reads_per_proc=24, rlen=10000):
-    """The REFERENCE's own gensig.c/genread.c (oracle/_ref/ref_harness, compiled in the build container from the
-    upstream sources where they lie) timed on the host cores: `nproc` independent single-threaded processes
-    (-t1, different seeds), aggregate samples/s.  Includes the reference's read sampling and the harness's
-    binary dump; returns None when the binary did not travel."""
-    import subprocess
-    import tempfile
+def cpu_allowance():
+    """CPUs this process may actually use: (scheduler affinity, cgroup quota in CPUs or None).  A container that shows every
+    core of the host but is throttled to a few would make an N-process baseline look N/few times slower per core."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                t = f.read().split()
+            if path.endswith("cpu.max"):
+                if t and t[0] != "max":
+                    quota = float(t[0]) / float(t[1])
+            else:
+                q = float(t[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                        quota = q / float(g.read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return aff, quota
+
+
+def cpu_reference(prof, flags, k, mean, stdv, fasta_path, rlen, seconds=10.0):
+    """The REFERENCE's own gensig.c/genread.c (oracle/_ref/ref_harness, compiled in the build container from the upstream
+    sources where they lie), timed mode: every process loads the model and the FASTA, seeds its streams, then generates
+    reads for `seconds` of wall time and reports the samples and the time of that read loop alone.
+    Legs: T=1 alone on the machine; one -t 1 process per physical core (generation only); the same writing BLOW5 through
+    slow5lib (zlib + svb-zd, as the reference does).  Returns None when the binary did not travel."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     if not os.path.exists(harness):
         return None
-    with tempfile.TemporaryDirectory() as tmp:
+    cpu, phys_cores, threads = host_info()
+    aff, quota = cpu_allowance()
+    cores = max(1, min(phys_cores, aff, int(quota) if quota else phys_cores))     # processes that really get a core each
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
         mpath = os.path.join(tmp, "m.model")
         model.write_f5c_model(mpath, k, mean, stdv)
-        cfgs = []
-        for i in range(nproc):
-            cfg = {"fasta": GENOME, "model": mpath, "out": os.path.join(tmp, f"o{i}.bin"), "flags": flags, "amp_noise": 1.0,
-                   "seed": 1000 + 7919 * i, "threads": 1, "batch": 1000, "nreads": reads_per_proc, "rlen": rlen}
-            for name, v in zip(("digitisation", "sample_rate", "bps", "range", "offset_mean", "offset_std",
-                                "median_before_mean", "median_before_std", "dwell_mean", "dwell_std"), prof.as_tuple()):
-                cfg[name] = repr(float(v))
-            cp = os.path.join(tmp, f"c{i}.txt")
-            with open(cp, "w") as f:
-                f.write("".join(f"{a}={b}\n" for a, b in cfg.items()))
-            cfgs.append(cp)
-        t0 = time.perf_counter()
-        procs = [subprocess.Popen([harness, c], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for c in cfgs]
-        rcs = [p.wait() for p in procs]
-        dt = time.perf_counter() - t0
-        if any(rcs):
-            return None
-        import struct
-        ns = 0
-        for i in range(nproc):
-            # dump layout (oracle/ref_harness.c): "SQGREF1\0", int32 n; per read int32[6] (…, rlen at [4], …),
-            # f64 offset, f64 median, i64 len_raw_signal, i64 start_time, i64 ss_n, seq, int16 signal, int32 ss
-            with open(os.path.join(tmp, f"o{i}.bin"), "rb") as f:
-                f.seek(8)
-                (n,) = struct.unpack("<i", f.read(4))
-                for _ in range(n):
-                    hdr = struct.unpack("<6i", f.read(24))
-                    _, _, ln, _, ssn = struct.unpack("<ddqqq", f.read(40))
-                    ns += ln
-                    f.seek(hdr[4] + 2 * ln + 4 * ssn, 1)
-    return {"value": ns / dt, "unit": "samples/s", "cores": nproc, "kind": "reference",
-            "sample": f"{nproc} x ref_harness -t1 -n {reads_per_proc} (reference gensig.c/genread.c, synthetic table), "
-                      f"{dt:.2f} s wall incl. process start, model/FASTA load and the dump"}
+
+        def leg(nproc, secs, blow5):
+            cfgs = []
+            for i in range(nproc):
+                cfg = {"fasta": fasta_path, "model": mpath, "flags": flags, "amp_noise": 1.0, "seed": 1000 + 7919 * i,
+                       "threads": 1, "batch": 1000, "nreads": 1, "rlen": rlen, "time_s": secs}
+                if blow5:
+                    cfg["slow5"] = os.path.join(tmp, f"o{i}.blow5")
+                for name, v in zip(("digitisation", "sample_rate", "bps", "range", "offset_mean", "offset_std",
+                                    "median_before_mean", "median_before_std", "dwell_mean", "dwell_std"), prof.as_tuple()):
+                    cfg[name] = repr(float(v))
+                cp = os.path.join(tmp, f"c{i}.txt")
+                with open(cp, "w") as f:
+                    f.write("".join(f"{a}={b}\n" for a, b in cfg.items()))
+                cfgs.append(cp)
+            procs = [subprocess.Popen([harness, c], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for c in cfgs]
+            outs = [p.communicate()[0] for p in procs]
+            if any(p.returncode for p in procs):
+                return None
+            ns = rd = 0
+            tmax = 0.0
+            for o in outs:
+                kv = dict(t.split("=") for t in o.split() if "=" in t)
+                ns += int(kv["samples"]); rd += int(kv["reads"]); tmax = max(tmax, float(kv["loop_seconds"]))
+            for i in range(nproc):
+                try:
+                    os.unlink(os.path.join(tmp, f"o{i}.blow5"))
+                except OSError:
+                    pass
+            return ns / tmax, rd / tmax, tmax
+
+        one = leg(1, min(seconds, 5.0), False)
+        allc = leg(cores, seconds, False)
+        e2e = leg(cores, seconds, True)
+    if not one or not allc:
+        return None
+    return {"value": allc[0], "unit": "samples/s", "cores": cores, "kind": "reference",
+            "per_core": allc[0] / cores, "t1": one[0], "reads_per_s": allc[1],
+            "to_blow5": (e2e[0] if e2e else None), "cpu": cpu, "physical_cores": phys_cores, "hw_threads": threads,
+            "affinity_cpus": aff, "cgroup_cpu_quota": quota,
+            "sample": f"reference gensig.c/genread.c (oracle/_ref/ref_harness, gcc -O2 -std=c99 as the reference's Makefile), synthetic "
+                      f"pore table, same profile and -r on a {os.path.getsize(fasta_path) / 1e6:.0f} MB genome of the same layout; `value`: "
+                      f"{cores} x `-t 1` processes (one per core this container may use), {allc[2]:.1f} s of read loop each, generation only (no "
+                      f"output); `t1`: one process alone; `to_blow5`: the same {cores} processes writing BLOW5 (zlib+svb-zd) through slow5lib"}
+
+
+def cpu_port(prof, flags, k, mean, stdv, reads, workers, nthreads):
+    """the oracle restatement (oracle/libsqg_oracle.so) on the same reads -> (per-read results, samples/s)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    T = int(max(workers)) + 1 if len(workers) else 1
+    o = orc.Oracle(prof, flags, k, mean, stdv, 42, num_workers=T)
+    t0 = time.perf_counter()
+    res = o.run_batch_seqs(reads, want_ss=False, nthreads=nthreads if T > 1 else 1)      # (the reference's static partition over T)
+    dt = time.perf_counter() - t0
+    o.close()
+    return res, sum(len(r.sig) for r in res) / dt
+
+
+def parity_check(prof, flags, k, mean, stdv, contigs, rlen, n_reads, one_worker, mode):
+    """the oracle as the checker: n_reads host-drawn reads of the workload through the oracle and through the C ABI in the
+    bench's regime (one worker: the chain is cut into links, bucketed hand-out for 9-mers; else one worker per read), every
+    int16 compared"""
+    rng = np.random.default_rng(1234)
+    reads = sample_reads_host(contigs, n_reads, rlen, rng)
+    workers = np.zeros(n_reads, np.int32) if one_worker else np.arange(n_reads, dtype=np.int32)
+    res, rate = cpu_port(prof, flags, k, mean, stdv, reads, workers, nthreads=min(os.cpu_count() or 1, 64))
+    gen = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=int(workers.max()) + 1, mode=mode)
+    b = gen.submit(reads, workers)
+    sig = b.signal()
+    bad = 0
+    for i, r in enumerate(res):
+        got = sig[b.sig_off[i]:b.sig_off[i + 1]]
+        if len(got) != len(r.sig) or not np.array_equal(got, r.sig):
+            bad += 1
+    ns = int(sum(len(r.sig) for r in res))
+    out = {"reads": n_reads, "samples": ns, "reads_differing": bad, "equal": bad == 0 and int(b.n_samples) == ns,
+           "regime": "-t 1" if one_worker else "T = K"}
+    b.free(); gen.close()
+    return out, rate
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=12)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch-reads", type=int, default=None,
-                    help="reads per step per GPU (= virtual workers per GPU).  Default 32768 (6-mer: 1.4e11 samples/s at 512, "
-                         "4.8e11 at 8192, 5.4e11 at 32768 and 65536); 16384 for the 9-mer workload, whose 1-MiB-per-worker "
-                         "state table makes larger batches slower (1.2e11 at 1024, 1.63e11 at 8192-16384, 1.54e11 at 32768)")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="hg38-r10", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch-reads", type=int, default=None, help="reads per step per GPU (default: per workload)")
     ap.add_argument("--rlen", type=int, default=10000)
-    ap.add_argument("--workload", default="ncov-r9", choices=sorted(WORKLOADS),
-                    help="ncov-r9 is the headline (BASELINE.json configs[1]); the others are the remaining configs, reported for information")
-    ap.add_argument("--genome-mb", type=float, default=64.0, help="size of the synthetic genome of --workload synth-r10")
+    ap.add_argument("--genome-mb", type=float, default=None,
+                    help="hg38-r10 / synth-r10: scale the synthetic genome to this many Mb (default: hg38's 3088 Mb; synth-r10: 64)")
     ap.add_argument("--profile", default=None, help="override the workload's -x preset")
     ap.add_argument("--mode", default="certified", choices=["exact", "certified"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--host-sampler", action="store_true",
-                    help="sample the reads with numpy on the host (same distribution) instead of the device-side gen_read")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall time of each multi-process CPU leg")
     ap.add_argument("--no-store-probe", action="store_true")
+    ap.add_argument("--workers-per-gpu", type=int, default=None,
+                    help="W > 0: the job has T = N*W virtual workers, W per GPU (sharded by worker, no data-path collective), and every "
+                         "batch of N*K reads is split over them as the reference's static partition does (src/thread.c:80-99): "
+                         "`-t N*W -K N*K`; W = 1 on one GPU is the reference's reproducible `-t 1`.  0: one worker per read (T = K)")
     ap.add_argument("--job-workers", type=int, default=0,
-                    help="T of the whole job (the reference's -t).  Default: one worker per read, sharded by worker over the "
-                         "GPUs, no data-path collective.  With a value (e.g. 1: the reference's reproducible regime) every "
-                         "GPU owns all T workers and generates a range of each batch's reads; the per-stream sample counts "
-                         "are all-gathered over RCCL once per batch (range sharding, include/sqg.h)")
-    ap.add_argument("--workers-per-gpu", type=int, default=0,
-                    help="W > 0: the job has T = N*W virtual workers, W per GPU (sharded by worker, no data-path collective), and "
-                         "every batch of N*K reads is split over them as the reference's static partition does "
-                         "(src/thread.c:80-99): `-t N*W -K N*K`.  W = 1 on one GPU is the reference's reproducible `-t 1`")
+                    help="T of the whole job with RANGE sharding: every GPU owns all T workers and generates a range of each batch's "
+                         "reads; the per-stream sample counts are all-gathered over RCCL once per batch (include/sqg.h)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl (= RCCL) for one rank per GPU; gloo only to exercise the N>1 control flow on a "
-                         "box with fewer GPUs than ranks (ranks then share GPUs)")
+                    help="nccl (= RCCL) for one rank per GPU; gloo only to exercise the N>1 control flow on a box with fewer GPUs than "
+                         "ranks (ranks then share GPUs)")
+    ap.add_argument("--digest", type=int, default=0,
+                    help="D > 0 (tests): fetch every timed batch's signal and report, per batch, the sums of the reads' xxh64 digests "
+                         "over D equal parts of the job's batch (N ranks report N*D/N parts each)")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        # launched the way a 1-GPU run is: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        rc = subprocess.call(cmd)
+        sys.exit(rc)
 
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    world = int(world_env or "1")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: one rank per GPU")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the signal path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -284,22 +375,24 @@ def main():
         raise SystemExit(f"{world} ranks but {ndev} GPUs (use --backend gloo to share GPUs in a dry run)")
     local_rank %= ndev
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
 
-    wl_profile, wl_flags, wl_mode, wl_desc = WORKLOADS[args.workload]
-    if args.batch_reads is None:
-        args.batch_reads = 16384 if args.workload == "synth-r10" else 32768
+    wl_profile, wl_flags, wl_mode, wl_w, wl_k, wl_desc = WORKLOADS[args.workload]
+    K = args.batch_reads or wl_k
+    W = wl_w if args.workers_per_gpu is None else args.workers_per_gpu
     if args.profile is None:
         args.profile = wl_profile
     prof, flags = profiles.get_profile(args.profile)
     flags |= wl_flags
     k = profiles.default_kmer_size(flags)
     n_k = 1 << (2 * k)
-    # pore model: rank 0 owns it; RCCL broadcast to the other GPUs (the only collective on this path)
+    amode = api.MODE_EXACT if args.mode == "exact" else api.MODE_CERTIFIED
+    # pore model: rank 0 owns it; RCCL broadcast to the other GPUs (the only collective on the worker-sharded path)
     if rank == 0:
         mean, stdv = model.synthetic_model(k)
     else:
@@ -307,44 +400,40 @@ def main():
     if world > 1:
         mean, stdv = shard.broadcast_model(mean, stdv, src=0)
 
-    K = args.batch_reads
     range_mode = args.job_workers > 0
-    if range_mode and args.host_sampler:
-        raise SystemExit("--job-workers needs the device sampler")
-    W = args.workers_per_gpu
-    if W and (range_mode or K % W):
-        raise SystemExit("--workers-per-gpu: not with --job-workers, and it must divide --batch-reads")
+    if range_mode:
+        W = 0
+    if W and K % W:
+        raise SystemExit("--workers-per-gpu must divide --batch-reads")
     T = args.job_workers if range_mode else (W * world if W else K * world)
-    w_lo, w_hi = (0, T) if range_mode else shard.worker_range(rank, world, T)   # default: contiguous block of K virtual workers
-    gen = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=T, device=local_rank,
-                              mode=api.MODE_EXACT if args.mode == "exact" else api.MODE_CERTIFIED,
+    w_lo, w_hi = (0, T) if range_mode else shard.worker_range(rank, world, T)
+    gen = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=T, device=local_rank, mode=amode,
                               worker_lo=w_lo, worker_hi=w_hi)
     if range_mode:
         gen.set_range_mode(True)
     r_lo, r_hi = shard.read_range(rank, world, K * world)          # range mode: my reads of the job's K*world-read batches
-    if args.workload == "synth-r10":
-        contigs = synthetic_genome(args.genome_mb)
-    elif args.workload == "sequin-rna004":
-        contigs = load_contigs(os.path.join(ROOT, "tests", "golden", "inputs", "rnasequin_sequences_2.4.fa"))
+
+    host_contigs = None                                             # a host copy of (a small version of) the genome, for the CPU legs
+    sm = api.SAMPLE_RNA if wl_mode == "rna" else api.SAMPLE_DNA
+    if args.workload in ("hg38-r10", "synth-r10"):
+        mb = args.genome_mb if args.genome_mb is not None else (None if args.workload == "hg38-r10" else 64.0)
+        seq, lens = synthetic_genome_device(mb, dev)
+        torch.cuda.synchronize()
+        gen.load_genome_device(seq.data_ptr(), lens, args.rlen, sm)
+        genome_bases = int(sum(lens))
+        del seq
+        torch.cuda.empty_cache()
     else:
-        contigs = [load_genome(GENOME)]
-    genome = contigs[0]
-    rng = np.random.default_rng(42 + rank)
+        host_contigs = load_contigs(SEQUINS) if args.workload == "sequin-rna004" else load_contigs(GENOME)
+        gen.load_genome(host_contigs, args.rlen, sm)
+        genome_bases = sum(len(c) for c in host_contigs)
     # worker of this GPU's read i: one each (T = K), or the static partition of the job's N*K-read batch over T = N*W workers
     workers = np.arange(w_lo, w_hi, dtype=np.int32) if not W else (w_lo + np.arange(K, dtype=np.int32) // (K // W)).astype(np.int32)
 
+    # the reads ARE the reference's: gen_read (src/genread.c) with `--seed 42 -r <rlen> -t T -K N*K` on the resident genome,
+    # sampled on the device at staging time (outside the timed region)
     nsteps = args.warmup + args.steps
-    batches = []
-    if args.host_sampler:
-        for _ in range(nsteps):
-            blob, off = pack(sample_reads(genome, K, args.rlen, rng))
-            batches.append(gen.stage_packed(blob, off, workers))  # H2D happens here, outside the timed region
-    else:
-        # the reads ARE the reference's: gen_read (src/genread.c) with `--seed 42 -r <rlen> -t T -K T` on the
-        # resident genome, sampled on the device at staging time (outside the timed region)
-        gen.load_genome(contigs, args.rlen, api.SAMPLE_RNA if wl_mode == "rna" else api.SAMPLE_DNA)
-        for _ in range(nsteps):
-            batches.append(gen.sample(K * world, None, lo=r_lo, hi=r_hi) if range_mode else gen.sample(K, workers))
+    batches = [gen.sample(K * world, None, lo=r_lo, hi=r_hi) if range_mode else gen.sample(K, workers) for _ in range(nsteps)]
 
     def sync_all():
         torch.cuda.synchronize()
@@ -354,12 +443,13 @@ def main():
 
     n_rows = T * n_k
     keep = []
+    gen_has_streams = not (flags & (profiles.SQ_IDEAL | profiles.SQ_IDEAL_AMP))
 
     def run(b):
         """default: one asynchronous launch sequence.  Range mode: counts -> all-gather in range order -> the rest"""
         if not range_mode or not gen_has_streams:
             return b.run()
-        mine = shard.counts_tensor(b.run_begin(), n_rows, torch.device("cuda", local_rank))
+        mine = shard.counts_tensor(b.run_begin(), n_rows, dev)
         if world > 1:
             before, after = shard.exchange_counts(mine)
         else:
@@ -368,33 +458,52 @@ def main():
         keep.append((before, after))                               # alive until the batch has run
         return b.run_end(before.data_ptr(), after.data_ptr())
 
-    gen_has_streams = not (flags & (profiles.SQ_IDEAL | profiles.SQ_IDEAL_AMP))
-    iso_lean_ms = []                  # warm-up batches run one at a time: the sample kernel alone on the machine
     for b in batches[:args.warmup]:
         run(b).wait()
-        iso_lean_ms.append(gen.timing()["lean_ms"])
     sync_all()
     t0 = time.perf_counter()
-    sig_ms, dwell_ms, ev_ms, lean_ms = [], [], [], []
+    sig_ms, ev_ms, lean_ms = [], [], []
     samples = bases = reads = 0
+    digests = []
     for b in batches[args.warmup:]:
         run(b)                        # asynchronous: all K steps are queued back to back (range mode: one exchange per step)
     for b in batches[args.warmup:]:
         b.wait()
         tm = gen.timing()
-        sig_ms.append(tm["samples_ms"]); dwell_ms.append(tm["dwell_ms"]); ev_ms.append(tm["events_ms"])
+        sig_ms.append(tm["samples_ms"]); ev_ms.append(tm["events_ms"])
         lean_ms.append(tm["lean_ms"] if tm["lean_ms"] > 0 else tm["samples_ms"])
         samples += b.n_samples; bases += b.n_bases; reads += b.n_reads
     sync_all()
     dt = time.perf_counter() - t0
 
-    tot = torch.tensor([float(samples), float(reads), dt], dtype=torch.float64,
-                       device="cuda" if (world == 1 or args.backend == "nccl") else "cpu")
+    if args.digest:
+        # tests: per batch, the sum of the reads' xxh64 digests over each of this rank's D parts (parts of the JOB's batch)
+        import xxhash
+        for b in batches[args.warmup:]:
+            # (the slabs of older batches have been reused: generate again, deterministically the same?  No: the context's
+            # streams have moved on.  Digests therefore need steps <= 2, which the slabs still hold.)
+            sig = b.signal()
+            per = b.n_reads // args.digest
+            parts = []
+            for d in range(args.digest):
+                acc = 0
+                for i in range(d * per, (d + 1) * per):
+                    acc = (acc + xxhash.xxh64(sig[b.sig_off[i]:b.sig_off[i + 1]].tobytes()).intdigest()) & 0xFFFFFFFFFFFFFFFF
+                parts.append(acc)
+            digests.append(parts)
+
+    on_gpu = world == 1 or args.backend == "nccl"
+    tot = torch.tensor([float(samples), float(reads), dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
     if world > 1:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dt_max = float(mx[2])
+        if args.digest:
+            allq = [None] * world
+            dist.all_gather_object(allq, digests)
+            # rank order = order of the parts inside a batch
+            digests = [sum((allq[r][s] for r in range(world)), []) for s in range(len(digests))]
     else:
         dt_max = dt
     tot_samples, tot_reads = float(tot[0]), float(tot[1])
@@ -404,6 +513,16 @@ def main():
         alg_bytes = (2 * samples + bases + 24 * reads) / steps           # per k_samples_lean launch (this rank)
         k_ms = float(np.mean(lean_ms)) if lean_ms else float("nan")     # the dominant kernel alone
         achieved = alg_bytes / (k_ms * 1e-3)
+        ms_per_step = dt_max / steps * 1e3
+        if range_mode:
+            regime = (f"-t {T} -K {K * world} (range sharding: every GPU owns all {T} worker(s) and generates {K} reads of each "
+                      f"batch; one all-gather of {4 * n_rows} B per batch)")
+        elif W:
+            regime = (f"-t {T} -K {K * world} ({W} virtual worker(s) per GPU, sharded by worker; the reference's static partition of "
+                      f"each batch, {K} reads per GPU)")
+        else:
+            regime = f"-t {T} -K {T} (T=K virtual workers, {K} per GPU)"
+        wkey = f"{args.workload}|{args.profile}|W={W}|batch_reads={K}|rlen={args.rlen}|mode={args.mode}"
         out = {
             "metric": "simulated raw samples/sec",
             "value": tot_samples / dt_max,
@@ -411,55 +530,60 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt_max / steps * 1e3,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64" if args.mode == "exact" else "f32+f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{wl_desc}; -x {args.profile} --seed 42 -r {args.rlen}, "
-                            + (f"-t {T} -K {K * world} (range sharding: every GPU owns all {T} worker(s) and generates {K} reads of each "
-                               f"batch; one all-gather of {4 * n_rows} B per batch), {args.steps} batches" if range_mode else
-                               f"-t {T} -K {K * world} ({W} worker(s) per GPU, sharded by worker; static partition of each batch, "
-                               f"{K} reads per GPU), {args.steps} batches" if W else
-                               f"-t {T} -K {T} (T=K virtual workers, {K} per GPU), {args.steps} batches"),
+                "workload": f"{wl_desc}; -x {args.profile} --seed 42 -r {args.rlen}, {regime}, {args.steps} batches "
+                            f"({int(tot_reads)} reads)",
+                "genome_bases": genome_bases,
                 "reads_per_step_per_gpu": K, "kmer_size": k, "mode": args.mode,
-                "reads": "numpy draws of gen_read's distribution (host)" if args.host_sampler
-                         else "gen_read on the device-resident genome (library sampler), as the reference with these options",
+                "reads": "gen_read on the device-resident genome (library sampler), as the reference with these options",
                 "pore_model": "synthetic stand-in table (built-in ONT tables absent from the reference mount)",
             },
             "reads_per_s": tot_reads / dt_max,
             "samples_per_step_per_gpu": samples / steps,
-            "kernel_ms": {"k_samples_lean": k_ms, # from the end of k_events to the batch's last kernel; the fix-ups run on their own stream next to the NEXT batch's
-                          # k_events and are stretched by it, so this span is longer than the kernels in it
-                          "k_scan..k_fixup* (span; fix-ups overlap the next k_events)": float(np.mean(sig_ms)) if sig_ms else None,
-                          "k_events(+dwell)": float(np.mean(ev_ms)) if ev_ms else None,
-                          "k_dwell(separate)": float(np.mean(dwell_ms)) if dwell_ms and np.mean(dwell_ms) > 0.01 else None},
+            "kernel_ms": {"k_samples_lean": k_ms,
+                          # from the end of the event side to the batch's last kernel; the fix-ups run on their own stream next to
+                          # the NEXT batch's event kernels and are stretched by them, so this span is longer than the kernels in it
+                          "k_scan..k_fixup* (span; fix-ups overlap the next batch's event side)": float(np.mean(sig_ms)) if sig_ms else None,
+                          "event side (k_events, k_part_*)": float(np.mean(ev_ms)) if ev_ms else None},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S,
-                         "traffic": pmc_traffic(args.profile, K, args.rlen, args.mode),
-                         # with SQG_OVERLAP=1 the next batch's k_events runs next to this kernel and stretches it; the
-                         # warm-up batches run one at a time and give the kernel's duration alone on the machine
+                         "traffic": pmc_traffic(wkey),
                          "kernel_ms": k_ms,
-                         "kernel_ms_warmup": (iso_lean_ms[-1] if iso_lean_ms and iso_lean_ms[-1] > 0 else None),
-                         "streams": 2 if os.environ.get("SQG_OVERLAP") else 1,
-                         "kernel": "k_samples_lean" if args.mode == "certified" else "k_samples<exact>", "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel": "k_samples_lean" if args.mode == "certified" else "k_samples<exact>",
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         # the same algorithmic bytes over the whole step (event side + sample kernels + gaps): what the job sees
+                         "step_frac": alg_bytes / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S,
+                         "workload_key": wkey},
         }
         if not args.no_store_probe:
             out["roofline"]["measured_store_peak_GBps"] = gen.probe_store_bandwidth(1 << 30, 10) / 1e9
-        if not args.no_cpu_baseline and (args.workload != "ncov-r9" or world > 1):
-            out["cpu_baseline"] = None                       # the CPU legs: headline workload, single-GPU run only
-        elif not args.no_cpu_baseline:
-            # the reference's own gensig.c/genread.c (oracle/_ref, kind "reference") when the harness travelled with the
-            # repo, else the oracle restatement (kind "port"); the other one is reported next to it
-            port = cpu_baseline(prof, flags, k, mean, stdv, genome, args.rlen,
-                                check_mode=api.MODE_EXACT if args.mode == "exact" else api.MODE_CERTIFIED)
-            out["parity_check"] = port.pop("parity", None)
-            ref = cpu_reference(prof, flags, k, mean, stdv, nproc=min(os.cpu_count() or 1, 128), reads_per_proc=150)
-            out["cpu_baseline"] = ref or port
-            if ref:
-                out["cpu_port"] = port
+        if digests:
+            out["digest"] = digests
+        if args.no_cpu_baseline or world > 1:
+            out["cpu_baseline"] = None                       # the CPU legs: single-GPU run only
+        else:
+            # a host-side genome of the same layout (the CPU's per-sample cost does not depend on the genome's size)
+            if host_contigs is None:
+                host_contigs = synthetic_genome_host(48.0 if args.genome_mb is None else min(args.genome_mb, 48.0))
+            one_worker = bool(W) and not range_mode
+            n_chk = 600 if one_worker else min(4 * (os.cpu_count() or 8), 2000)
+            out["parity_check"], port_rate = parity_check(prof, flags, k, mean, stdv, host_contigs, args.rlen, n_chk, one_worker, amode)
+            ref = None
+            if not (flags & profiles.SQ_RNA):                     # (the harness' timed mode draws DNA reads from a FASTA)
+                with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+                    fa = os.path.join(tmp, "g.fa")
+                    with open(fa, "wb") as f:
+                        for i, c in enumerate(host_contigs):
+                            f.write(b">c%d\n" % i + c + b"\n")
+                    ref = cpu_reference(prof, flags, k, mean, stdv, fa, args.rlen, seconds=args.cpu_seconds)
+            out["cpu_baseline"] = ref or {"value": port_rate, "unit": "samples/s", "cores": 1 if one_worker else min(os.cpu_count() or 1, 64),
+                                          "kind": "port", "sample": f"oracle restatement on the {n_chk} reads of parity_check"}
         print(json.dumps(out))
     for b in batches:
         b.free()

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <time.h>
 
 #include "sq.h"      /* core_t, opt_t, profile_t, model_t, SQ_* flags */
 #include "format.h"  /* aln_t, init_aln, paf_str, sam_str, sam_hdr_wr */
@@ -45,7 +46,11 @@ typedef struct {
     uint32_t flags;
     float amp_noise;
     long seed, threads, batch, nreads, rlen;
+    double time_s;           /* > 0: timed mode -- reads are generated until this many seconds have gone into the read loop
+                                (model/FASTA load and stream seeding excluded); one "SQGTIME ..." line on stdout */
 } cfg_t;
+
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 
 static void parse_cfg(const char *path, cfg_t *c) {
     memset(c, 0, sizeof *c);
@@ -72,6 +77,7 @@ static void parse_cfg(const char *path, cfg_t *c) {
         if (!strcmp(k, "batch")) { c->batch = atol(v); continue; }
         if (!strcmp(k, "nreads")) { c->nreads = atol(v); continue; }
         if (!strcmp(k, "rlen")) { c->rlen = atol(v); continue; }
+        if (!strcmp(k, "time_s")) { c->time_s = strtod(v, NULL); continue; }
         fprintf(stderr, "ref_harness: unknown key '%s'\n", k); exit(2);
     }
     fclose(fp);
@@ -127,6 +133,7 @@ int main(int argc, char **argv) {
     if (argc != 2) { fprintf(stderr, "usage: %s <config>\n", argv[0]); return 2; }
     cfg_t cfg; parse_cfg(argv[1], &cfg);
     set_log_level(LOG_ERR);
+    const double t_start = now_s();
 
     if (cfg.svb_in[0]) {         /* compress arbitrary int16 arrays with the library's svb-zd coder, nothing else */
         FILE *fi = fopen(cfg.svb_in, "rb"), *fo = fopen(cfg.svb_out, "wb");
@@ -179,12 +186,15 @@ int main(int argc, char **argv) {
     core->sp = sp;
 
     long n = cfg.nreads;
+    if (cfg.time_s > 0) n = 2000000000L;                      /* timed mode: until the clock says stop */
     if (cfg.flags & SQ_FULL_CONTIG) n = core->ref->num_ref;
     if (fout) { int32_t n32 = (int32_t)n; put(fout, "SQGREF1", 8); put(fout, &n32, 4); }
 
     const int T = core->opt.num_thread;
-    long done = 0;
-    while (done < n) {
+    long done = 0, timed_reads = 0;
+    const double t_loop = now_s();
+    int stop = 0;
+    while (done < n && !stop) {
         const long nb = n - done < cfg.batch ? n - done : cfg.batch;
         const long step = T > 1 ? (nb + T - 1) / T : nb;      /* static partition, src/thread.c:80 */
         for (long i = 0; i < nb; i++) {
@@ -256,11 +266,18 @@ int main(int argc, char **argv) {
             }
             free_aln(aln);
             if (!(cfg.flags & SQ_FULL_CONTIG)) free(seq);
+            timed_reads++;
+            if (cfg.time_s > 0 && now_s() - t_loop >= cfg.time_s) { stop = 1; break; }
         }
         core->total_reads += nb;
         done += nb;
     }
     if (sp) slow5_close(sp);
+    if (cfg.time_s > 0) {
+        const double t_end = now_s();
+        printf("SQGTIME samples=%lld reads=%ld loop_seconds=%.6f total_seconds=%.6f\n", (long long)core->n_samples, timed_reads,
+               t_end - t_loop, t_end - t_start);
+    }
     if (fout) fclose(fout);
     if (ffa) fclose(ffa);
     if (fsvb) fclose(fsvb);

@@ -1,0 +1,64 @@
+"""bench.py --gpus N launches the N ranks itself and runs the HIP path in every rank.  On a one-GPU
+box the ranks share the GPU (--backend gloo); what must hold is what holds on N GPUs: the ranks' signals are, read for
+read, those of the single-rank run of the same job -- in both sharding modes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-store-probe", "--steps", "2",
+                        "--warmup", "1"] + [str(a) for a in args], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,single,dual", [
+    # 9-mers, one worker per GPU (the headline regime): -t 2 -K 1024
+    ("r10_by_worker", ["--genome-mb", 24, "--workers-per-gpu", 2, "--batch-reads", 1024, "--digest", 4],
+                      ["--genome-mb", 24, "--workers-per-gpu", 1, "--batch-reads", 512, "--digest", 2]),
+    # 9-mers, strict -t 1: every rank owns the worker and generates half of each batch; counts all-gathered per batch
+    ("r10_by_range", ["--genome-mb", 24, "--job-workers", 1, "--batch-reads", 1024, "--digest", 4],
+                     ["--genome-mb", 24, "--job-workers", 1, "--batch-reads", 512, "--digest", 2]),
+    # 6-mers, one worker per read: -t 512 -K 512
+    ("r9_t_equals_k", ["--workload", "ncov-r9", "--batch-reads", 512, "--digest", 4],
+                      ["--workload", "ncov-r9", "--batch-reads", 256, "--digest", 2]),
+    # 6-mers by range with three workers
+    ("r9_by_range_t3", ["--workload", "ncov-r9", "--job-workers", 3, "--batch-reads", 600, "--digest", 4],
+                       ["--workload", "ncov-r9", "--job-workers", 3, "--batch-reads", 300, "--digest", 2]),
+], ids=lambda v: v if isinstance(v, str) else None)
+def test_two_ranks_equal_one(name, single, dual):
+    one = _bench("--gpus", 1, *single)
+    two = _bench("--gpus", 2, "--backend", "gloo", *dual)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["steps"] == 2 and len(two["digest"]) == 2
+    assert one["digest"] == two["digest"], (one["digest"], two["digest"])
+    # the same reads and samples in total (value = whole-job samples / max-over-ranks time)
+    n1 = one["samples_per_step_per_gpu"] * one["steps"]
+    n2 = two["value"] * two["ms_per_step"] * 1e-3 * two["steps"]
+    assert abs(n1 - n2) <= 1e-6 * n1
+    assert two["reads_per_s"] * two["ms_per_step"] * 1e-3 * two["steps"] == pytest.approx(2 * one["config"]["reads_per_step_per_gpu"], rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_gpus_flag_without_enough_devices_fails_loudly():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    import torch
+    n = torch.cuda.device_count() + 1
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-store-probe", "--genome-mb", "8"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0
+    assert "ranks but" in (p.stderr + p.stdout)
