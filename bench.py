@@ -140,6 +140,22 @@ def sample_reads_host(contigs, n: int, rlen: int, rng: np.random.Generator):
     return out[:n]
 
 
+def load_genome(path):
+    """a single-contig FASTA as bytes"""
+    return b"".join(load_contigs(path))
+
+
+def sample_reads(genome: bytes, n: int, rlen: int, rng: np.random.Generator):
+    """sample_reads_host on one contig (tests and tools)"""
+    return sample_reads_host([genome], n, rlen, rng)
+
+
+def pack(reads):
+    off = np.zeros(len(reads) + 1, np.int64)
+    off[1:] = np.cumsum([len(r) for r in reads])
+    return b"".join(reads), off
+
+
 WORKLOADS = {
     # name: (profile, extra flags, sampler mode, workers per GPU (0: one per read), reads per step per GPU, description)
     "hg38-r10": ("dna-r10-prom", 0, "dna", 1, 8192,

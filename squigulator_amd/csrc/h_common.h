@@ -18,7 +18,9 @@ struct sqg_ctx {
     uint32_t* d_rows = nullptr;
     float2* d_model = nullptr;
     uint32_t* d_pow = nullptr;
-    unsigned int* d_err = nullptr;
+    unsigned int* d_err = nullptr;                 // the read sampler's error word (sqg_batch_sample* read and clear it synchronously);
+                                                   // the kernels of a batch report into the batch's own word
+    unsigned long long scan_tickets = 0;           // k_scan launches so far: every launch gets a ticket of its own
     // Everything a batch's kernels write lives in one of two SLOTS (batch seq & 1): a batch's results stay valid while
     // the next one runs (sqg_batch_wait / sqg_fetch_* of batch i do not wait for batch i+1), and with SQG_OVERLAP=1 the
     // event kernels of batch i+1 (stream) run while the sample kernels of batch i (stream2) are still busy.
@@ -36,6 +38,7 @@ struct sqg_ctx {
         ItemDesc* d_items = nullptr; size_t items_cap = 0;          // [n_stiles] work items of the lean kernel (k_items)
         uint32_t* d_part_state = nullptr; size_t part_state_cap = 0;   // [n_events] k > 6, split chains (k_part.h): stream state at each
                                                                     // bucketed event; read by the sample kernels like evrec
+        unsigned long long gen = 0;                // bumped whenever a batch starts writing the slot's buffers
         hipEvent_t done = nullptr;                 // recorded after the slot's last kernel (fix-ups included)
         hipEvent_t sampled = nullptr;              // recorded on stream2 after the slot's sample kernels, before the fix-ups
     } slot[2];
@@ -131,6 +134,10 @@ struct sqg_batch {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel-phase boundaries; [7]: the event side is done
     uint8_t* h_meta = nullptr; size_t h_meta_bytes = 0;   // pinned: the host-built arrays of the batch (descriptors, chain lists), uploaded in one copy
     hipEvent_t ev_staged = nullptr;      // recorded on the staging stream after the batch's last staging operation
+    unsigned int* d_err = nullptr;       // the batch's own device error word (in d_block; zeroed by the meta upload): batches queued back
+                                         // to back never see each other's errors
+    int wait_rc = 0;                     // what the first sqg_batch_wait returned (latched)
+    unsigned long long slot_gen = 0;     // generation of the slot when this batch took it (results are stale once it differs)
     int slot = 0;                        // which of the context's two buffer sets this batch runs in
     unsigned long long run_idx = 0;      // how many batches had been run before this one
     bool ran = false, waited = false, lean_timed = false, dwell_timed = false;

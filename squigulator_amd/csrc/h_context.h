@@ -24,7 +24,7 @@ extern "C" int sqg_device_count(void) {
 }
 
 extern "C" int32_t sqg_worker_of(int32_t i, int32_t n_rec, int32_t T) {
-    if (T <= 1) return 0;                                  // src/thread.c:122-125
+    if (T <= 1 || n_rec <= 0) return 0;                    // src/thread.c:122-125
     const int32_t step = (n_rec + T - 1) / T;              // src/thread.c:80
     return i / step;
 }

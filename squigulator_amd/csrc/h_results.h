@@ -2,6 +2,10 @@
 // Host side of include/sqg.h; included by sqg_hip.hip (one translation unit with the kernels), in the order listed there.
 #pragma once
 
+// the slot's buffers still hold this batch's results (two batches later they do not: range mode bumps the generation as soon
+// as sqg_batch_run_begin of a later batch starts writing them)
+static bool slot_is_mine(const sqg_ctx* c, const sqg_batch* b) { return c->slot[b->slot].gen == b->slot_gen; }
+
 extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
     if (!c || !b || !b->ran) return SQG_EINVAL;
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -11,14 +15,15 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
         b->n_samples = b->h_sigoff[b->n];
         for (int i = 0; i <= b->n; i++) b->sig_off[(size_t)i] = b->h_sigoff[i];
         unsigned int e = 0;
-        HIPCHK(c, hipMemcpy(&e, c->d_err, sizeof e, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&e, b->d_err, sizeof e, hipMemcpyDeviceToHost));   // the batch's own word: never cleared, never shared
 #if defined(SQG_ABL_EV_NOSTORE) || defined(SQG_ABL_NOSTORE)       /* timing-only ablation builds: results are garbage by design */
-        if (e) { HIPCHK(c, hipMemset(c->d_err, 0, sizeof e)); e = 0; }
+        e = 0;
 #endif
+        b->waited = true;
         if (e) {
-            HIPCHK(c, hipMemset(c->d_err, 0, sizeof e));
             c->err = "device reported: " + std::string((e & 1) ? "dwell>65535 " : "") + ((e & 2) ? "read>=UINT32_MAX samples " : "") + ((e & 4) ? "internal length mismatch " : "") + ((e & 8) ? "FP64 fix-up list overflow " : "") + ((e & 32) ? "one k-mer stream asked for >= 2^32 samples by one batch" : "");
-            return (e & 12) ? SQG_EDEVICE : SQG_EOVERFLOW;
+            b->wait_rc = (e & 12) ? SQG_EDEVICE : SQG_EOVERFLOW;
+            return b->wait_rc;
         }
         float d = 0, s = 0, t = 0, ee = 0;
         if (b->dwell_timed) HIPCHK(c, hipEventElapsedTime(&d, b->ev[0], b->ev[1]));
@@ -29,26 +34,29 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
         c->timing.lean_ms = 0.f;
         if (b->lean_timed) HIPCHK(c, hipEventElapsedTime(&c->timing.lean_ms, b->ev[5], b->ev[6]));
         unsigned int nfix = 0;
-        if (c->cfg.mode == SQG_MODE_CERTIFIED) {
+        if (c->cfg.mode == SQG_MODE_CERTIFIED && slot_is_mine(c, b)) {
             unsigned int cnt[4] = {0, 0, 0, 0};
             HIPCHK(c, hipMemcpy(cnt, S.d_fix_count, sizeof cnt, hipMemcpyDeviceToHost));
             nfix = cnt[0] + cnt[2];                         // global list + the per-item slots of the lean kernel (counted by k_fixup_tiles)
         }
         c->timing.dwell_ms = d; c->timing.samples_ms = s; c->timing.total_ms = t; c->timing.fallback_samples = nfix;
-        b->waited = true;
+    } else if (b->wait_rc) {
+        c->err = "this batch failed on the device (see the first sqg_batch_wait)";
+        return b->wait_rc;
     }
     if (res) {
+        const bool mine = slot_is_mine(c, b);               // else: the slabs have been handed to a later batch
         res->n_reads = b->n; res->n_events = b->n_events; res->n_samples = b->n_samples; res->n_bases = b->n_bases;
         res->sig_off = (const int64_t*)b->sig_off.data(); res->ev_off = (const int64_t*)b->ev_off.data();
         res->offset = b->offset.data(); res->median_before = b->median.data();
-        res->d_signal = S.d_sig; res->d_dwell = c->use_dwell_stream ? S.d_dwell : nullptr;
+        res->d_signal = mine ? S.d_sig : nullptr; res->d_dwell = (mine && c->use_dwell_stream) ? S.d_dwell : nullptr;
     }
     return SQG_OK;
 }
 
 extern "C" int sqg_fetch_signal(sqg_ctx_t* c, sqg_batch_t* b, int16_t* dst) {
     if (!c || !b || !b->ran || !dst) return SQG_EINVAL;
-    if (b->run_idx + 2 < c->runs) return SQG_ESEQUENCE;       // slab already reused (two batches later)
+    if (b->run_idx + 2 < c->runs || !slot_is_mine(c, b)) return SQG_ESEQUENCE;       // slab already reused (two batches later)
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipEventSynchronize(b->ev[4]));
     if (!b->waited) b->n_samples = b->h_sigoff[b->n];
@@ -58,7 +66,7 @@ extern "C" int sqg_fetch_signal(sqg_ctx_t* c, sqg_batch_t* b, int16_t* dst) {
 
 extern "C" int sqg_fetch_dwell(sqg_ctx_t* c, sqg_batch_t* b, int32_t* dst) {
     if (!c || !b || !b->ran || !dst) return SQG_EINVAL;
-    if (b->run_idx + 2 < c->runs) return SQG_ESEQUENCE;
+    if (b->run_idx + 2 < c->runs || !slot_is_mine(c, b)) return SQG_ESEQUENCE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipEventSynchronize(b->ev[4]));
     if (!c->use_dwell_stream) {
@@ -88,7 +96,7 @@ extern "C" int sqg_submit(sqg_ctx_t* c, int32_t n, const char* seqs, const int64
 
 extern "C" int sqg_batch_compress(sqg_ctx_t* c, sqg_batch_t* b, sqg_svb_t* out) {
     if (!c || !b || !b->ran || !out) return SQG_EINVAL;
-    if (b->run_idx + 2 < c->runs) return SQG_ESEQUENCE;       // the signals of an older batch are gone
+    if (b->run_idx + 2 < c->runs || !slot_is_mine(c, b)) return SQG_ESEQUENCE;       // the signals of an older batch are gone
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipEventSynchronize(b->ev[4]));
     sqg_ctx::Slot& S = c->slot[b->slot];

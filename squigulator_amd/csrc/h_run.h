@@ -16,6 +16,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     if (phase != 2) b->run_idx = c->runs;
     b->slot = (int)(b->run_idx & 1);
     sqg_ctx::Slot& S = c->slot[b->slot];
+    if (phase != 2) b->slot_gen = ++S.gen;                      // from here on the slot's buffers belong to this batch
     sqg_ctx::Slot& other = c->slot[b->slot ^ 1];
     if (phase != 2) {
         // this slot's buffers were last used by the sample kernels of batch seq-2 (stream2)
@@ -66,7 +67,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     P.dmean = p.dwell_mean; P.dstd = p.dwell_std;
     P.seglen = S.d_seglen; P.sig_off = S.d_sigoff; P.model = c->d_model; P.pw = c->d_pow; P.rows = c->d_rows;
     P.seed_base = canon((long long)c->cfg.seed + (long long)c->wlo * ((long long)(1u << (2 * c->k)) + 10)); P.seed_step = canon((long long)(1u << (2 * c->k)) + 10);
-    P.err = c->d_err; P.dig = p.digitisation; P.range = p.range; P.kd = p.digitisation / p.range;
+    P.err = b->d_err; P.dig = p.digitisation; P.range = p.range; P.kd = p.digitisation / p.range;
     P.chain_order = b->d_chain_order; P.delta_x = c->delta_x; P.thr_all = c->thr_all;
     P.k = c->k; P.num_kmer = c->num_kmer; P.const_sps = (int)p.dwell_mean;
     P.use_streams = c->use_kmer_streams ? 1 : 0;
@@ -100,10 +101,10 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 if (nblk > 0) {
                     if (certified)
                         hipLaunchKernelGGL(k_dwell<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, b->d_reads, n, b->d_blk_read,
-                                           b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, c->delta_x, S.d_dwell, S.d_seglen, c->d_err);
+                                           b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, c->delta_x, S.d_dwell, S.d_seglen, b->d_err);
                     else
                         hipLaunchKernelGGL(k_dwell<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, b->d_reads, n, b->d_blk_read,
-                                           b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, 0.f, S.d_dwell, S.d_seglen, c->d_err);
+                                           b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, 0.f, S.d_dwell, S.d_seglen, b->d_err);
                 }
                 if ((rc = dbg_sync(c, "k_dwell"))) return rc;
             } else if (!c->use_dwell_stream) {
@@ -139,7 +140,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 }
             }
             if (phase != 1) {
-                hipLaunchKernelGGL(k_part_scan, sg, dim3(256), 0, c->stream, c->d_phist, c->d_rows, c->num_kmer, b->d_wgroup_off, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, c->d_err);
+                hipLaunchKernelGGL(k_part_scan, sg, dim3(256), 0, c->stream, c->d_phist, c->d_rows, c->num_kmer, b->d_wgroup_off, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, b->d_err);
                 if (before) {                                     // every worker's row moves past the whole batch, all ranges
                     const dim3 ag((unsigned)((n_rows + 255) / 256));
                     hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
@@ -198,7 +199,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 HIPCHK(c, hipMemsetAsync(c->d_scan_part, 0, c->scan_part_cap * sizeof(unsigned long long), c->stream));
         }
         hipLaunchKernelGGL(k_scan, dim3(scan_wgs), dim3(SCAN_WG), 0, c->stream, S.d_seglen, n, S.d_sigoff, b->h_sigoff_dev,
-                           c->d_err, S.d_fix_count, c->d_scan_part, b->run_idx + 1);
+                           b->d_err, S.d_fix_count, c->d_scan_part, ++c->scan_tickets);   // (a ticket per launch, also after a failed run)
         HIPCHK(c, hipGetLastError());
         if ((rc = dbg_sync(c, "k_scan"))) return rc;
     } else HIPCHK(c, hipMemsetAsync(S.d_fix_count, 0, 4 * sizeof(unsigned int), c->stream));

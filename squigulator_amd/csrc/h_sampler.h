@@ -145,7 +145,20 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
     SampleRec* d_try = (SampleRec*)(sb + o_try); unsigned char* d_ok = sb + o_ok; long long* d_ao = (long long*)(sb + o_ao);
     std::vector<SampleRec> rec((size_t)n);
     int rc = SQG_OK;
-    auto cleanup = [&]() {};
+    // a failed call must leave the context where it was: the workers' streams -- sampler streams on the device, scalar streams
+    // on the host -- are put back (the reference's sequence would otherwise silently stop matching)
+    const std::vector<uint32_t> snap_time = c->time_c;
+    const std::vector<long long> snap_off = c->off_x, snap_med = c->med_x;
+    const long long snap_full = c->full_next;
+    std::vector<uint32_t> snap_samp((size_t)c->nw * 3);
+    if (hipMemcpy(snap_samp.data(), c->d_samp, snap_samp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { c->err = "sampler streams unreadable"; return SQG_EDEVICE; }
+    bool failed = true;                                           // cleared on the way out of a successful call
+    auto cleanup = [&]() {
+        if (!failed) return;
+        c->time_c = snap_time; c->off_x = snap_off; c->med_x = snap_med; c->full_next = snap_full;
+        (void)hipStreamSynchronize(c->stage_stream);
+        (void)hipMemcpy(c->d_samp, snap_samp.data(), snap_samp.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    };
 #define CHKS(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE; } } while (0)
     if (n > 0) {
         CHKS(hipMemcpyAsync(d_co, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
@@ -207,6 +220,7 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
     rc = stage_common(c, m, nullptr, seq_off.data(), m != n ? wk_glob.data() + lo : worker, d_rec + lo, out);
     if (rc == SQG_OK && m != n)
         for (int i = hi; i < n; i++) skip_read(c, wk[(size_t)i], read_events(c, rec[(size_t)i].rlen));
+    failed = rc != SQG_OK;
     cleanup();
     if (rc) return rc;
     sqg_batch* b = *out;

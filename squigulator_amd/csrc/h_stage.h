@@ -255,6 +255,9 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
 
     const uint32_t a2 = lcg_mul(LCG_A, LCG_A);
     const bool no_lean = getenv("SQG_TEST_NO_LEAN") != nullptr;
+    // the workers' scalar streams advance below; a staging that fails afterwards (allocation) puts them back
+    const std::vector<uint32_t> snap_time = c->time_c;
+    const std::vector<long long> snap_off = c->off_x, snap_med = c->med_x;
     // the per-read scalar draws (host libm, so that `offset` / `median_before` are the doubles the CPU reference prints):
     // chains are independent, a few host threads share them
     auto chain_range = [&](int q_lo, int q_hi) {
@@ -308,14 +311,15 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     }
 
     st_mark("chains+streams+blocks");
-    auto bail = [&](int code) { sqg_batch_free(c, b); return code; };
+    auto bail = [&](int code) { c->time_c = snap_time; c->off_x = snap_off; c->med_x = snap_med; sqg_batch_free(c, b); return code; };
 #define CHKB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE); } } while (0)
-    size_t meta_bytes = 0, mo_reads = 0, mo_blk = 0, mo_coff = 0, mo_crd = 0, mo_ord = 0, mo_wlo = 0, mo_wlw = 0, mo_lg = 0, mo_wgo = 0, mo_cb = 0;
+    size_t meta_bytes = 0, mo_err = 0, mo_reads = 0, mo_blk = 0, mo_coff = 0, mo_crd = 0, mo_ord = 0, mo_wlo = 0, mo_wlw = 0, mo_lg = 0, mo_wgo = 0, mo_cb = 0;
     {   // one device allocation per batch, carved into the batch's arrays (256-byte aligned)
         size_t off = 0;
         auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
         // the host-built arrays first and back to back: they go up in one copy from the batch's pinned mirror
-        const size_t o_reads = carve(std::max<size_t>(1, rd.size()) * sizeof(ReadDesc)),
+        const size_t o_err = carve(256),
+                     o_reads = carve(std::max<size_t>(1, rd.size()) * sizeof(ReadDesc)),
                      o_blk = carve(blk_read.size() * sizeof(int)), o_coff = carve(chain_off.size() * sizeof(int)),
                      o_crd = carve(std::max<size_t>(1, chain_reads.size()) * sizeof(int)),
                      o_ord = carve(std::max<size_t>(1, chain_order.size()) * sizeof(int)),
@@ -325,7 +329,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         meta_bytes = off;
         const size_t o_bases = carve((size_t)nb + 16),
                      o_st = carve((size_t)std::max<long long>(nst, 1) * sizeof(int)), o_t = carve((size_t)std::max<long long>(ntile, 1) * sizeof(int));
-        mo_reads = o_reads; mo_blk = o_blk; mo_coff = o_coff; mo_crd = o_crd; mo_ord = o_ord; mo_wlo = o_wlo; mo_wlw = o_wlw; mo_lg = o_lg; mo_wgo = o_wgo; mo_cb = o_cb;
+        mo_err = o_err; mo_reads = o_reads; mo_blk = o_blk; mo_coff = o_coff; mo_crd = o_crd; mo_ord = o_ord; mo_wlo = o_wlo; mo_wlw = o_wlw; mo_lg = o_lg; mo_wgo = o_wgo; mo_cb = o_cb;
         // a freed batch's block, pinned offsets and events are reused when they are large enough
         for (size_t pi = 0; pi < c->pool.size(); pi++) {
             sqg_ctx::Recycled& r = c->pool[pi];
@@ -350,6 +354,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
             CHKB(hipHostMalloc(&b->h_meta, b->h_meta_bytes, hipHostMallocDefault));
         }
         uint8_t* base = b->d_block;
+        b->d_err = (unsigned int*)(base + o_err);
         b->d_bases = base + o_bases; b->d_reads = (ReadDesc*)(base + o_reads); b->d_blk_read = (int*)(base + o_blk);
         b->d_chain_off = (int*)(base + o_coff); b->d_chain_reads = (int*)(base + o_crd); b->d_stile_read = (int*)(base + o_st);
         b->d_tile_read = (int*)(base + o_t); b->d_chain_order = (int*)(base + o_ord);
@@ -358,6 +363,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     }
     {   // the host-built arrays -> pinned mirror -> one asynchronous copy
         uint8_t* m = b->h_meta;
+        memset(m + mo_err, 0, 256);                         // the batch's error word starts clear
         if (n) memcpy(m + mo_reads, rd.data(), rd.size() * sizeof(ReadDesc));
         memcpy(m + mo_blk, blk_read.data(), blk_read.size() * sizeof(int));
         memcpy(m + mo_coff, chain_off.data(), chain_off.size() * sizeof(int));

@@ -380,7 +380,8 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
         // base index of event e: e in segment 0, e + (k-1) in segment 1 (the stall's k-mers do not
         // straddle the boundary, src/genread.c:87-88)
         #define EV_BASE(e_) ((int)(e_) + ((e_) >= rd.ne0 ? rd.len0 - rd.ne0 : 0))
-        uint32_t done = 0;                                            // samples before this segment
+        unsigned long long done = 0;                                  // samples before this segment (a read of >= 2^32 - 1 samples is
+                                                                      // rejected by k_scan, src/sim.c:559-562: its tile offsets may wrap)
         uint32_t c_seg = DW ? __builtin_amdgcn_readfirstlane(lcg_mul(rd.time_c0, LCG_A)) : 0u;   // a * (time-stream state at the segment's first event)
         if (DW && tid == 0) n1_sh = -1;
         // prefetch of segment 0: EPT base bytes per thread (+ halo), EPT dwells per thread
@@ -533,14 +534,14 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
                     if (DW && EV_IN(e0 + q) && e0 + q == rd.ne0) n1_sh = (long long)done + run;   // samples of segment 0
                     run += sps[q];
                 }
-                done += (uint32_t)seg_total;
+                done += (unsigned long long)seg_total;
                 lds_barrier();                                        // codes / wsum are rewritten by the next segment
                 return;
             }
             if (DIRECT || PART) lds_barrier(); else __syncthreads();                          // (2) global rows: + earlier row stores have landed
             prefetch_next(s0);                                        // lands while this segment waits for its states
             // first sample of every 64-event tile (TL lanes) within the read
-            if ((lane & (TL - 1)) == 0 && EV_IN(e0)) P.tile_so[rd.tile_off + (e0 >> 6)] = done + (uint32_t)lane_excl;
+            if ((lane & (TL - 1)) == 0 && EV_IN(e0)) P.tile_so[rd.tile_off + (e0 >> 6)] = (uint32_t)done + (uint32_t)lane_excl;
             uint32_t c_ev[EPT];
             {
                 int run = lane_excl;
@@ -653,7 +654,7 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
 #pragma unroll
             for (int q = 0; q < EPT; q++)
                 if (EV_IN(e0 + q)) P.evrec[rd.ev_off + e0 + q] = make_uint2(c_ev[q], rank[q]);
-            done += (uint32_t)seg_total;
+            done += (unsigned long long)seg_total;
             // no barrier here: every LDS structure rewritten at the top of the next segment (codes, wsum, bins) was last
             // read before barrier (2)/(3) of this one, which every thread has passed
         };

@@ -259,8 +259,7 @@ __global__ __launch_bounds__(256) void k_copy_reads(const GenomeParams G, const 
             const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
             if (isN) {
                 const int j = before + __popcll(m & ((1ull << lane) - 1)); // 0-based; draw j+1 of the state-100 stream
-                uint32_t cst = 100u;
-                for (int q = 0; q <= j; q++) cst = lcg_mul(cst, LCG_A);    // <= 10 % of the read: a short walk
+                const uint32_t cst = lcg_mul(100u, lcg_pow_a((unsigned long long)j + 1));
                 const int v = (int)round(lcg_uniform(cst) * 3);
                 c = v == 0 ? 'A' : v == 1 ? 'C' : v == 2 ? 'G' : 'T';
             }

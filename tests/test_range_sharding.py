@@ -193,3 +193,40 @@ def test_random_worker_counts_rank_counts_and_batch_sizes(seed):
     T, G = int(rng.integers(1, 5)), int(rng.integers(2, 5))
     batches = [int(rng.integers(1, 24)) for _ in range(3)]
     _run(name, fasta, T, G, batches, rlen, sflags=sflags, mode=mode, seed=int(rng.integers(1, 1 << 20)))
+
+
+@pytest.mark.gpu
+def test_results_of_a_reused_slot_are_refused():
+    """Outputs live in two slots used alternately.  In range mode sqg_batch_run_begin of batch r+2 already writes the slot
+    of batch r (dwells, lengths): from then on batch r's device results are gone -- sqg_fetch_* must say so instead of
+    handing out the newer batch's data, and sqg_batch_wait must not return device pointers into it."""
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    mean, stdv = model.synthetic_model(6)
+    g = api.SignalGenerator(prof, fl, 6, mean, stdv, 42, num_workers=1, mode=api.MODE_CERTIFIED)
+    rng = np.random.default_rng(3)
+    hip = Hip()
+    zero = hip.to_device(np.zeros(4096, np.uint32))
+    g.set_range_mode(True)
+    bs = []
+    for _ in range(3):
+        bs.append(g.stage([bytes(rng.choice(list(b"ACGT"), 700).astype(np.uint8)) for _ in range(6)]))
+    for b in bs[:2]:
+        b.run_begin()
+        b.run_end(zero, zero).wait()
+    d0 = bs[0].dwell()                                     # still there
+    assert len(d0) == bs[0].n_events
+    bs[2].run_begin()                                      # takes the slot of batch 0
+    with pytest.raises(api.SqgError) as e:
+        bs[0].dwell()
+    assert e.value.code == -4
+    with pytest.raises(api.SqgError):
+        bs[0].signal()
+    bs[0].wait()
+    assert not bs[0].res.d_signal and not bs[0].res.d_dwell
+    assert len(bs[1].dwell()) == bs[1].n_events            # the other slot is untouched
+    bs[2].run_end(zero, zero).wait()
+    np.testing.assert_array_equal(bs[2].dwell() > 0, True)
+    for b in bs:
+        b.free()
+    hip.free(zero)
+    g.close()

@@ -9,12 +9,12 @@ from squigulator_amd import api, model, profiles
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 wl = sys.argv[3] if len(sys.argv) > 3 else "ncov-r9"
-pname, wflags, wmode, _ = bench.WORKLOADS[wl]
+pname, wflags, wmode = bench.WORKLOADS[wl][:3]
 prof, fl = profiles.get_profile(pname)
 fl |= wflags
 k = profiles.default_kmer_size(fl)
 mean, stdv = model.synthetic_model(k)
-contigs = bench.synthetic_genome(64) if wl == "synth-r10" else [bench.load_genome(bench.GENOME)]
+contigs = bench.synthetic_genome_host(64) if wl == "synth-r10" else [bench.load_genome(bench.GENOME)]
 for setting in ("0", None):
     if setting is None:
         os.environ.pop("SQG_SPLIT_CHAINS", None)
