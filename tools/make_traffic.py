@@ -11,14 +11,19 @@ import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-key = sys.argv[3] if len(sys.argv) > 3 else "dna-r9-prom|batch_reads=32768|rlen=10000|mode=certified"
+key = sys.argv[3] if len(sys.argv) > 3 else None
+if key is None:                                            # the workload key of the profiled bench line
+    for ln in open(os.path.join(src, "trace.log")):
+        if ln.startswith('{"metric"'):
+            key = json.loads(ln)["roofline"]["workload_key"]
+rnd = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f, name in (("pmc4", "FETCH_SIZE"), ("pmc5", "WRITE_SIZE")):
     path = os.path.join(src, f + "_counter_collection.csv")
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == name:
             acc[r["Kernel_Name"]][name].append(float(r["Counter_Value"]))
-out = {"round": 1, "workload_key": key,
+out = {"round": rnd, "workload_key": key,
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/prof_pmc.sh); unit KiB; "
                  "FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM); WRITE_SIZE checked on "
                  "k_store_probe (1 GiB written per launch)",
@@ -27,6 +32,8 @@ for kn, d in acc.items():
     short = kn.split("(")[0].split("<")[0].replace("void ", "").strip()
     if not short.startswith("k_"):
         continue
+    if short == "k_events":                                # several instantiations per batch (count / scatter passes): keep them apart
+        short = kn.split("(")[0].replace("void ", "").strip()
     f = sum(d.get("FETCH_SIZE", [0])) / max(len(d.get("FETCH_SIZE", [0])), 1)
     w = sum(d.get("WRITE_SIZE", [0])) / max(len(d.get("WRITE_SIZE", [0])), 1)
     out["kernels"][short] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2 * f + w) * 1024}

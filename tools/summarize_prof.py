@@ -22,8 +22,10 @@ tr = os.path.join(src, "trace_kernel_trace.csv")
 if os.path.exists(tr):
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(tr)):
-        for key in ("k_samples_lean", "k_events"):
+        for key in ("k_samples_lean", "k_events", "k_part_hand", "k_part_hist"):
             if key in r["Kernel_Name"]:
+                if key == "k_events":                      # the counting and the scatter pass are two instantiations
+                    key = r["Kernel_Name"].split("(")[0].replace("void ", "")
                 per[key].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     bench_line = None
     log = os.path.join(src, "trace.log")
@@ -55,9 +57,9 @@ for f in ("pmc1", "pmc2", "pmc3"):
         continue
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        acc[r["Kernel_Name"][:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for kn, d in acc.items():
-        if not any(t in kn for t in ("k_samples", "k_events", "k_dwell")):
+        if not any(t in kn for t in ("k_samples", "k_events", "k_dwell", "k_part")):
             continue
         lines.append(f"* `{kn}` ({f}): " + ", ".join(f"{c}={sum(v) / len(v) / 1e6:.1f}" for c, v in sorted(d.items())))
 open(dst + "_summary.md", "w").write("\n".join(lines) + "\n")
