@@ -43,6 +43,8 @@ extern "C" {
 #define SQG_IDEAL_TIME  0x008u
 #define SQG_IDEAL_AMP   0x010u
 #define SQG_PREFIX      0x020u
+#define SQG_R10         0x040u   /* header of the BLOW5 writer: sequencing_kit (src/gensig.c:104-109)                 */
+#define SQG_ONT         0x400u   /* ... and the ONT-friendly extra field end_reason (src/gensig.c:160-168)            */
 
 /* error codes */
 #define SQG_OK            0
@@ -172,6 +174,25 @@ typedef struct {
 } sqg_svb_t;
 int  sqg_batch_compress(sqg_ctx_t *ctx, sqg_batch_t *b, sqg_svb_t *out);
 int  sqg_fetch_svb(sqg_ctx_t *ctx, sqg_batch_t *b, uint8_t *dst /* n_bytes */);
+
+/* ---- native BLOW5 writer: the slow5_encode / slow5_write_bytes half of work_per_single_read and output_db
+ * (src/sim.c:604-640), without slow5lib.  The file `squigulator -o x.blow5` writes: zlib record compression, svb-zd signal
+ * compression (slow5lib/src/slow5.c:421-423), header of set_header_attributes / set_header_aux_fields
+ * (src/gensig.c:40-169), records laid out as slow5_rec_to_mem does (slow5lib/src/slow5.c:3928-4072), "5WOLB" at the end.
+ * The signal field of a record is the svb-zd encoding sqg_batch_compress made on the device; framing and zlib (one deflate
+ * stream per record, as slow5lib's) run on `threads` host threads (<= 0: up to 16).  read_number and start_time continue
+ * over the calls in read order (src/sim.c:602).  Pure host code: usable without a GPU when the encodings come from elsewhere. */
+typedef struct sqg_blow5 sqg_blow5_t;
+int  sqg_blow5_open(const char *path, const sqg_profile_t *profile, uint32_t flags /* SQG_RNA | SQG_R10 | SQG_ONT */,
+                    int32_t threads, sqg_blow5_t **out);
+/*   read_ids/id_off [n+1]: the reads' ids, concatenated (src/sim.c:564-570); offset, median_before [n]; sig_off [n+1]: samples
+ *   per read as differences (sqg_result_t.sig_off); svb/svb_off [n+1]: the encodings (sqg_fetch_svb / sqg_svb_t.svb_off) */
+int  sqg_blow5_write(sqg_blow5_t *w, int32_t n, const char *read_ids, const int64_t *id_off, const double *offset,
+                     const double *median_before, const int64_t *sig_off, const uint8_t *svb, const int64_t *svb_off);
+/* the same for a batch that has been run: waits for it, compresses on the device, fetches and writes */
+int  sqg_blow5_write_batch(sqg_blow5_t *w, sqg_ctx_t *ctx, sqg_batch_t *b, const char *read_ids, const int64_t *id_off);
+int  sqg_blow5_close(sqg_blow5_t *w, int64_t *n_bytes /* may be NULL: the file's size */);
+const char *sqg_blow5_last_error(const sqg_blow5_t *w);
 
 /* ---- next row: device-resident genome + read sampling on the device ----
  * sqg_genome_load keeps the reference sequences (ref_t after load_ref, src/ref.c:54-117) in HBM;

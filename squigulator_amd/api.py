@@ -78,7 +78,8 @@ EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_d
            "sqg_batch_free", "sqg_get_timing", "sqg_submit", "sqg_worker_of", "sqg_probe_store_bandwidth",
            "sqg_batch_compress", "sqg_fetch_svb", "sqg_genome_load", "sqg_batch_sample", "sqg_fetch_reads",
            "sqg_host_alloc", "sqg_host_free", "sqg_set_range_mode", "sqg_skip_reads", "sqg_batch_sample_range",
-           "sqg_batch_run_begin", "sqg_batch_run_end", "sqg_genome_load_device")
+           "sqg_batch_run_begin", "sqg_batch_run_end", "sqg_genome_load_device",
+           "sqg_blow5_open", "sqg_blow5_write", "sqg_blow5_write_batch", "sqg_blow5_close", "sqg_blow5_last_error")
 
 _lib = None
 
@@ -149,9 +150,69 @@ def load_library(path: str | None = None):
     L.sqg_batch_run_begin.argtypes = [vp, vp, C.POINTER(vp)]
     L.sqg_batch_run_end.restype = C.c_int
     L.sqg_batch_run_end.argtypes = [vp, vp, vp, vp]
+    L.sqg_blow5_open.restype = C.c_int
+    L.sqg_blow5_open.argtypes = [C.c_char_p, C.POINTER(CProfile), C.c_uint32, i32, C.POINTER(vp)]
+    L.sqg_blow5_write.restype = C.c_int
+    L.sqg_blow5_write.argtypes = [vp, i32, C.c_char_p, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                  C.POINTER(i64), vp, C.POINTER(i64)]
+    L.sqg_blow5_write_batch.restype = C.c_int
+    L.sqg_blow5_write_batch.argtypes = [vp, vp, vp, C.c_char_p, C.POINTER(i64)]
+    L.sqg_blow5_close.restype = C.c_int
+    L.sqg_blow5_close.argtypes = [vp, C.POINTER(i64)]
+    L.sqg_blow5_last_error.restype = C.c_char_p
+    L.sqg_blow5_last_error.argtypes = [vp]
     if path == _build.LIB:
         _lib = L
     return L
+
+
+class Blow5Writer:
+    """The library's native BLOW5 writer (sqg_blow5_*): header, record framing and zlib on host threads; the signal field is
+    the svb-zd encoding made on the device.  Pure host code: write() works without a GPU."""
+
+    def __init__(self, path: str, profile: P.Profile, flags: int, threads: int = 0, lib_path: str | None = None):
+        self.L = load_library(lib_path)
+        self.h = C.c_void_p()
+        cp = CProfile(*profile.as_tuple())
+        rc = self.L.sqg_blow5_open(os.fsencode(path), C.byref(cp), flags & (P.SQ_RNA | P.SQ_R10 | P.SQ_ONT), threads, C.byref(self.h))
+        if rc != 0:
+            raise SqgError(rc, "sqg_blow5_open", path)
+
+    def _chk(self, rc, where):
+        if rc != 0:
+            raise SqgError(rc, where, self.L.sqg_blow5_last_error(self.h).decode())
+
+    @staticmethod
+    def _ids(read_ids):
+        blob = b"".join(read_ids)
+        off = np.zeros(len(read_ids) + 1, np.int64)
+        off[1:] = np.cumsum([len(r) for r in read_ids])
+        return blob, off
+
+    def write(self, read_ids, offset, median_before, sig_off, svb, svb_off):
+        """read_ids: list of bytes; svb: uint8 array of the concatenated svb-zd encodings, svb_off their offsets"""
+        blob, ioff = self._ids(read_ids)
+        offset = np.ascontiguousarray(offset, np.float64); median_before = np.ascontiguousarray(median_before, np.float64)
+        sig_off = np.ascontiguousarray(sig_off, np.int64); svb_off = np.ascontiguousarray(svb_off, np.int64)
+        svb = np.ascontiguousarray(svb, np.uint8)
+        dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int64)
+        self._chk(self.L.sqg_blow5_write(self.h, len(read_ids), blob, ioff.ctypes.data_as(ip), offset.ctypes.data_as(dp),
+                                         median_before.ctypes.data_as(dp), sig_off.ctypes.data_as(ip), svb.ctypes.data,
+                                         svb_off.ctypes.data_as(ip)), "sqg_blow5_write")
+
+    def write_batch(self, batch: "Batch", read_ids):
+        blob, ioff = self._ids(read_ids)
+        self._chk(self.L.sqg_blow5_write_batch(self.h, batch.gen.ctx, batch.handle, blob, ioff.ctypes.data_as(C.POINTER(C.c_int64))),
+                  "sqg_blow5_write_batch")
+
+    def close(self) -> int:
+        n = C.c_int64()
+        if self.h:
+            rc = self.L.sqg_blow5_close(self.h, C.byref(n))
+            self.h = None
+            if rc != 0:
+                raise SqgError(rc, "sqg_blow5_close")
+        return n.value
 
 
 class Batch:

@@ -20,7 +20,7 @@ LIB = os.path.join(CSRC, "libsqg_hip.so")
 SOURCES = [os.path.join(CSRC, "sqg_hip.hip")]
 HEADERS = [os.path.join(os.path.dirname(HERE), "include", "sqg.h")] + \
           [os.path.join(CSRC, h) for h in ("sqg_kernels.h", "k_common.h", "k_events.h", "k_part.h", "k_samples.h", "k_sampler.h", "k_svb.h",
-                                           "h_common.h", "h_context.h", "h_stage.h", "h_sampler.h", "h_run.h", "h_results.h")]
+                                           "h_common.h", "h_context.h", "h_stage.h", "h_sampler.h", "h_run.h", "h_results.h", "h_blow5.h")]
 ARCH = "gfx950"
 
 
@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
     cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-result", "-o", LIB] + SOURCES
+           "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-result", "-o", LIB] + SOURCES + ["-lz"]
     if verbose:
         print("[squigulator_amd.build]", " ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -1,0 +1,180 @@
+// h_blow5.h -- native BLOW5 writer: header, record framing, zlib record compression (sqg_blow5_*)
+// Host side of include/sqg.h; included by sqg_hip.hip (one translation unit with the kernels), in the order listed there.
+//
+// The other half of work_per_single_read (src/sim.c:604-640: slow5_encode per read, slow5_write_bytes in output_db): the file
+// the reference writes through slow5lib for `-o x.blow5` -- zlib record compression, svb-zd signal compression
+// (slow5lib/src/slow5.c:421-423) -- written without slow5lib.  The signal field of a record is the svb-zd encoding
+// sqg_batch_compress made on the device; this file frames it:
+//   file    = magic "BLOW5\1" | version 0.2.0 | record method (1: zlib) | num_read_groups u32 | signal method (1: svb-zd) |
+//             zeros up to byte 64 | header size u32 | header text | records | "5WOLB"     (slow5_hdr_to_mem, slow5.c:948-1158)
+//   header  = "@attr\tvalue\n" sorted by attribute (set_header_attributes, src/gensig.c:40-129), the type line and the
+//             column line with the auxiliary fields of set_header_aux_fields (src/gensig.c:131-169)
+//   record  = u64 compressed size | zlib(deflate level default, window 15, memLevel 8, one stream per record) of:
+//             u16 len(read_id) | read_id | u32 read_group | f64 digitisation | f64 offset | f64 range | f64 sampling_rate |
+//             u64 bytes of the compressed signal | those bytes | u64 1 | "0" (channel_number) | f64 median_before |
+//             i32 read_number | u8 start_mux | u64 start_time [| u8 end_reason]    (slow5_rec_to_mem, slow5.c:3928-4072;
+//             set_record_primary_fields / set_record_aux_fields, src/gensig.c:171-223)
+#pragma once
+
+#include <zlib.h>
+
+struct sqg_blow5 {
+    FILE* fp = nullptr;
+    sqg_profile_t profile{};
+    uint32_t flags = 0;
+    int threads = 1;
+    long long n_reads = 0;               // records written: the next read_number
+    unsigned long long n_samples = 0;    // samples written: the next start_time (core->n_samples, src/sim.c:602)
+    unsigned long long n_bytes = 0;      // file bytes so far
+    std::string err;
+};
+
+extern "C" const char* sqg_blow5_last_error(const sqg_blow5_t* w) { return w ? w->err.c_str() : ""; }
+
+static std::string blow5_header(const sqg_profile_t& p, uint32_t flags) {
+    const bool rna = flags & SQG_RNA, r10 = flags & SQG_R10, ont = flags & SQG_ONT;
+    const char* kit = rna ? (r10 ? "sqk-rna004" : "sqk-rna002") : (r10 ? "sqk-lsk114" : "sqk-lsk109");
+    char freq[64];
+    snprintf(freq, sizeof freq, "%d", (int)p.sample_rate);             // src/gensig.c:122-123
+    std::string t;
+    // slow5lib writes the attributes in sorted order (slow5_get_hdr_keys)
+    t += "@asic_id\tasic_id_0\n";
+    t += "@exp_start_time\t2022-07-20T00:00:00Z\n";
+    t += std::string("@experiment_type\t") + (rna ? "rna" : "genomic_dna") + "\n";
+    t += "@flow_cell_id\tFAN00000\n";
+    t += "@run_id\trun_0\n";
+    t += std::string("@sample_frequency\t") + freq + "\n";
+    t += std::string("@sequencing_kit\t") + kit + "\n";
+    t += "#char*\tuint32_t\tdouble\tdouble\tdouble\tdouble\tuint64_t\tint16_t*\tchar*\tdouble\tint32_t\tuint8_t\tuint64_t";
+    if (ont) t += "\tenum{unknown,partial,mux_change,unblock_mux_change,data_service_unblock_mux_change,signal_positive,signal_negative}";
+    t += "\n#read_id\tread_group\tdigitisation\toffset\trange\tsampling_rate\tlen_raw_signal\traw_signal\tchannel_number\tmedian_before\tread_number\tstart_mux\tstart_time";
+    if (ont) t += "\tend_reason";
+    t += "\n";
+    std::string h("BLOW5\1", 6);
+    const unsigned char fixed[] = {0, 2, 0, /*record: zlib*/ 1, /*num_read_groups*/ 1, 0, 0, 0, /*signal: svb-zd*/ 1};
+    h.append(reinterpret_cast<const char*>(fixed), sizeof fixed);
+    h.resize(64, '\0');
+    const uint32_t hs = (uint32_t)t.size();
+    h.append(reinterpret_cast<const char*>(&hs), 4);
+    return h + t;
+}
+
+extern "C" int sqg_blow5_open(const char* path, const sqg_profile_t* profile, uint32_t flags, int32_t threads, sqg_blow5_t** out) {
+    if (!path || !profile || !out) return SQG_EINVAL;
+    *out = nullptr;
+    if (!(profile->sample_rate > 0) || profile->sample_rate > 1000000000.0) return SQG_EINVAL;     // src/gensig.c:117-120
+    sqg_blow5* w = new (std::nothrow) sqg_blow5();
+    if (!w) return SQG_ENOMEM;
+    w->fp = fopen(path, "wb");
+    if (!w->fp) { delete w; return SQG_EINVAL; }
+    w->profile = *profile; w->flags = flags;
+    w->threads = threads > 0 ? threads : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    const std::string h = blow5_header(*profile, flags);
+    if (fwrite(h.data(), 1, h.size(), w->fp) != h.size()) { fclose(w->fp); delete w; return SQG_EINVAL; }
+    w->n_bytes = h.size();
+    *out = w;
+    return SQG_OK;
+}
+
+// one record, compressed, appended to `dst` (size prefix included); zs: the thread's deflate stream
+static bool blow5_record(z_stream& zs, std::vector<uint8_t>& raw, std::vector<uint8_t>& dst, const sqg_blow5* w, const char* id, size_t id_len,
+                         double offset, double median_before, const uint8_t* svb, uint64_t svb_bytes, int32_t read_number, uint64_t start_time) {
+    raw.clear();
+    auto put = [&](const void* p, size_t n) { const uint8_t* q = (const uint8_t*)p; raw.insert(raw.end(), q, q + n); };
+    const uint16_t idl = (uint16_t)id_len;
+    const uint32_t rg = 0;
+    put(&idl, 2); put(id, id_len); put(&rg, 4);
+    put(&w->profile.digitisation, 8); put(&offset, 8); put(&w->profile.range, 8); put(&w->profile.sample_rate, 8);
+    put(&svb_bytes, 8); put(svb, (size_t)svb_bytes);
+    const uint64_t one = 1; const char ch = '0'; const uint8_t mux = 0;
+    put(&one, 8); put(&ch, 1);                                          // channel_number = "0"
+    put(&median_before, 8); put(&read_number, 4); put(&mux, 1); put(&start_time, 8);
+    if (w->flags & SQG_ONT) { const uint8_t end_reason = 0; put(&end_reason, 1); }
+    if (deflateReset(&zs) != Z_OK) return false;
+    const size_t at = dst.size();
+    const uLong bound = deflateBound(&zs, (uLong)raw.size());
+    dst.resize(at + 8 + bound);
+    zs.next_in = raw.data(); zs.avail_in = (uInt)raw.size();
+    zs.next_out = dst.data() + at + 8; zs.avail_out = (uInt)bound;
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) return false;
+    const uint64_t csize = bound - zs.avail_out;
+    memcpy(dst.data() + at, &csize, 8);
+    dst.resize(at + 8 + csize);
+    return true;
+}
+
+extern "C" int sqg_blow5_write(sqg_blow5_t* w, int32_t n, const char* read_ids, const int64_t* id_off, const double* offset,
+                               const double* median_before, const int64_t* sig_off, const uint8_t* svb, const int64_t* svb_off) {
+    if (!w || !w->fp || n < 0) return SQG_EINVAL;
+    if (n == 0) return SQG_OK;
+    if (!read_ids || !id_off || !offset || !median_before || !sig_off || !svb || !svb_off) return SQG_EINVAL;
+    for (int i = 0; i < n; i++) {
+        const int64_t il = id_off[i + 1] - id_off[i];
+        if (il < 0 || il > 65535 || svb_off[i + 1] < svb_off[i] || sig_off[i + 1] < sig_off[i]) { w->err = "sqg_blow5_write: bad offsets"; return SQG_EINVAL; }
+        if (svb_off[i + 1] - svb_off[i] > 0xfffffff0LL) { w->err = "sqg_blow5_write: record too large"; return SQG_EOVERFLOW; }
+    }
+    // start_time of read i = samples of every read before it (src/sim.c:602, in read order)
+    std::vector<unsigned long long> start((size_t)n);
+    unsigned long long run = w->n_samples;
+    for (int i = 0; i < n; i++) { start[(size_t)i] = run; run += (unsigned long long)(sig_off[i + 1] - sig_off[i]); }
+    const int nth = std::max(1, std::min(w->threads, n));
+    std::vector<std::vector<uint8_t>> outs((size_t)nth);
+    std::vector<int> bad((size_t)nth, 0);
+    auto work = [&](int t) {
+        const int lo = (int)((long long)n * t / nth), hi = (int)((long long)n * (t + 1) / nth);
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        // zlib_init_deflate, slow5lib/src/slow5_press.c:789-800
+        if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, MAX_WBITS, 8, Z_DEFAULT_STRATEGY) != Z_OK) { bad[(size_t)t] = 1; return; }
+        std::vector<uint8_t> raw;
+        std::vector<uint8_t>& dst = outs[(size_t)t];
+        dst.reserve((size_t)(svb_off[hi] - svb_off[lo]) + (size_t)(hi - lo) * 160);
+        for (int i = lo; i < hi; i++)
+            if (!blow5_record(zs, raw, dst, w, read_ids + id_off[i], (size_t)(id_off[i + 1] - id_off[i]), offset[i], median_before[i],
+                              svb + svb_off[i], (uint64_t)(svb_off[i + 1] - svb_off[i]), (int32_t)(w->n_reads + i), start[(size_t)i])) { bad[(size_t)t] = 1; break; }
+        deflateEnd(&zs);
+    };
+    if (nth == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nth; t++) th.emplace_back(work, t);
+        for (auto& t : th) t.join();
+    }
+    for (int t = 0; t < nth; t++) if (bad[(size_t)t]) { w->err = "sqg_blow5_write: zlib failed"; return SQG_EINVAL; }
+    for (int t = 0; t < nth; t++) {
+        if (fwrite(outs[(size_t)t].data(), 1, outs[(size_t)t].size(), w->fp) != outs[(size_t)t].size()) { w->err = "sqg_blow5_write: short write"; return SQG_EINVAL; }
+        w->n_bytes += outs[(size_t)t].size();
+    }
+    w->n_reads += n;
+    w->n_samples = run;
+    return SQG_OK;
+}
+
+// the batch's records: svb-zd on the device (sqg_batch_compress), ~1.3 B/sample over PCIe, framing and zlib on the host threads
+extern "C" int sqg_blow5_write_batch(sqg_blow5_t* w, sqg_ctx_t* c, sqg_batch_t* b, const char* read_ids, const int64_t* id_off) {
+    if (!w || !c || !b) return SQG_EINVAL;
+    sqg_result_t res;
+    int rc = sqg_batch_wait(c, b, &res);
+    if (rc) { w->err = c->err; return rc; }
+    sqg_svb_t sv;
+    if ((rc = sqg_batch_compress(c, b, &sv))) { w->err = c->err; return rc; }
+    uint8_t* host = (uint8_t*)sqg_host_alloc((size_t)std::max<int64_t>(sv.n_bytes, 1));
+    if (!host) return SQG_ENOMEM;
+    rc = sqg_fetch_svb(c, b, host);
+    if (rc == SQG_OK) rc = sqg_blow5_write(w, res.n_reads, read_ids, id_off, res.offset, res.median_before, res.sig_off, host, sv.svb_off);
+    else w->err = c->err;
+    sqg_host_free(host);
+    return rc;
+}
+
+extern "C" int sqg_blow5_close(sqg_blow5_t* w, int64_t* n_bytes) {
+    if (!w) return SQG_EINVAL;
+    int rc = SQG_OK;
+    if (w->fp) {
+        if (fwrite("5WOLB", 1, 5, w->fp) != 5) rc = SQG_EINVAL;          // slow5_eof_fwrite, slow5.c:4206
+        else w->n_bytes += 5;
+        if (fclose(w->fp) != 0) rc = SQG_EINVAL;
+    }
+    if (n_bytes) *n_bytes = (int64_t)w->n_bytes;
+    delete w;
+    return rc;
+}

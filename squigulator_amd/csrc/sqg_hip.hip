@@ -31,3 +31,4 @@
 #include "h_sampler.h"    // sqg_genome_load, sqg_batch_sample, sqg_batch_sample_range, sqg_skip_reads, sqg_fetch_reads
 #include "h_run.h"        // sqg_batch_run, sqg_batch_run_begin / _end, sqg_set_range_mode
 #include "h_results.h"    // sqg_batch_wait, sqg_fetch_*, sqg_batch_compress, sqg_get_timing, ...
+#include "h_blow5.h"      // sqg_blow5_*: the native BLOW5 writer

@@ -20,7 +20,7 @@ def lib():
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "sqg.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(sqg_[a-z_]+)\s*\(", hdr)))
+    return sorted(set(re.findall(r"\b(sqg_[a-z0-9_]+)\s*\(", hdr)))
 
 
 def test_every_declared_symbol_is_exported(lib):
@@ -72,9 +72,7 @@ def test_product_does_not_reference_the_oracle():
     assert not bad, bad
 
 
-def test_header_is_plain_c_and_the_c_example_compiles(tmp_path):
-    """include/sqg.h is consumed by a C host (the reference is C): the example host loop must compile as C99 with
-    -pedantic and link against the library without any HIP/C++/torch header."""
+def _build_example(tmp_path):
     import shutil
     import subprocess
     if not shutil.which("gcc"):
@@ -87,9 +85,25 @@ def test_header_is_plain_c_and_the_c_example_compiles(tmp_path):
     exe = str(tmp_path / "process_db_gpu")
     subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), src, "-L", libdir, "-lsqg_hip",
                            "-Wl,-rpath," + libdir, "-o", exe])
-    # without a GPU the program must fail loudly at sqg_create (no CPU fallback); with one it must run
+    return exe
+
+
+def test_header_is_plain_c_and_the_c_example_compiles(tmp_path):
+    """include/sqg.h is consumed by a C host (the reference is C): the example host loop must compile as C99 with
+    -pedantic and link against the library without any HIP/C++/torch header.  Without a GPU the program must fail loudly
+    at sqg_create (no CPU fallback)."""
+    import subprocess
+    exe = _build_example(tmp_path)
     r = subprocess.run([exe, "4"], capture_output=True, text=True)
-    if r.returncode == 0:
-        assert r.stdout.count("read ") == 4, r.stdout
-    else:
+    if r.returncode != 0:
         assert "sqg_create" in r.stderr, r.stderr
+
+
+@pytest.mark.gpu
+def test_the_c_example_runs_on_the_gpu(tmp_path):
+    """the plain-C caller of include/sqg.h (examples/process_db_gpu.c) on a real device: every read comes back"""
+    import subprocess
+    exe = _build_example(tmp_path)
+    r = subprocess.run([exe, "4"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.count("read ") == 4, r.stdout

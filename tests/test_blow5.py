@@ -1,0 +1,144 @@
+"""Native BLOW5 writer (sqg_blow5_*, squigulator_amd/csrc/h_blow5.h) against the files the compiled reference wrote through
+its own slow5lib (tests/golden/blow5, tools/make_blow5_golden.py): `cmp`-identical, header to "5WOLB".
+
+CPU: the writer is host code; the svb-zd bytes it frames come from the oracle's coder here (itself pinned on slow5lib's
+bytes, tests/test_svb.py).  GPU: the whole product path -- reads from the fixture, signals from the kernels, svb-zd on the
+device, sqg_blow5_write_batch -- must produce the same file, and a full-size batch must decode back to its signals."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import orc
+from blow5_cases import BLOW5_CASES
+from squigulator_amd import api, model, options, profiles
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "blow5")
+INPUTS = os.path.join(os.path.dirname(__file__), "golden", "inputs")
+
+
+def _case(cid):
+    d = np.load(os.path.join(GOLD, cid + ".npz"))
+    o = options.parse_args(str(d["cmd"]))
+    ids = bytes(d["ids"]).split(b"\n")
+    so = np.concatenate(([0], np.cumsum(d["lens"]))).astype(np.int64)
+    return o, ids, d["offset"], d["median"], so, d["sig"]
+
+
+def parse_blow5(buf):
+    """-> (header text, [uncompressed records]); checks magic, sizes and the EOF marker"""
+    assert buf[:6] == b"BLOW5\x01" and buf[6:9] == b"\x00\x02\x00" and buf[9] == 1 and buf[14] == 1
+    assert struct.unpack_from("<I", buf, 10)[0] == 1 and buf[15:64] == b"\0" * 49
+    hs = struct.unpack_from("<I", buf, 64)[0]
+    p = 68 + hs
+    recs = []
+    while buf[p:] != b"5WOLB":
+        (n,) = struct.unpack_from("<Q", buf, p)
+        recs.append(zlib.decompress(buf[p + 8:p + 8 + n]))
+        p += 8 + n
+    return buf[68:68 + hs], recs
+
+
+@pytest.mark.parametrize("cid", [c[0] for c in BLOW5_CASES])
+@pytest.mark.parametrize("threads", [1, 3])
+def test_writer_reproduces_the_reference_file(cid, threads, tmp_path):
+    o, ids, offset, median, so, sig = _case(cid)
+    want = open(os.path.join(GOLD, cid + ".blow5"), "rb").read()
+    encs = [orc.svb_zd(sig[so[i]:so[i + 1]]) for i in range(len(ids))]
+    path = str(tmp_path / "x.blow5")
+    w = api.Blow5Writer(path, o.profile, o.flags, threads=threads)
+    # in the reference's batches (-K): read_number and start_time carry over the calls
+    done = 0
+    while done < len(ids):
+        nb = min(o.batch, len(ids) - done)
+        e = encs[done:done + nb]
+        eo = np.concatenate(([0], np.cumsum([len(x) for x in e]))).astype(np.int64)
+        w.write(ids[done:done + nb], offset[done:done + nb], median[done:done + nb], so[done:done + nb + 1] - so[done],
+                np.concatenate(e), eo)
+        done += nb
+    n = w.close()
+    got = open(path, "rb").read()
+    assert n == len(got)
+    hdr_g, rec_g = parse_blow5(got)
+    hdr_w, rec_w = parse_blow5(want)
+    assert hdr_g == hdr_w
+    assert rec_g == rec_w                      # the uncompressed records (independent of the zlib build)
+    assert got == want                         # and the very bytes (same zlib as the reference build in this image)
+
+
+def test_empty_file_and_bad_arguments(tmp_path):
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    w = api.Blow5Writer(str(tmp_path / "e.blow5"), prof, fl)
+    w.write([], np.zeros(0), np.zeros(0), np.zeros(1, np.int64), np.zeros(1, np.uint8), np.zeros(1, np.int64))
+    assert w.close() == os.path.getsize(tmp_path / "e.blow5")
+    hdr, recs = parse_blow5(open(tmp_path / "e.blow5", "rb").read())
+    assert recs == [] and b"@sequencing_kit\tsqk-lsk109\n" in hdr
+    with pytest.raises(api.SqgError):
+        api.Blow5Writer(str(tmp_path / "no" / "such" / "dir.blow5"), prof, fl)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid", ["r9_t1", "r10_t1", "rna004_prefix", "r9_two_batches"])
+def test_product_path_writes_the_reference_file(cid, tmp_path):
+    """fixture reads -> kernels -> svb-zd on the device -> sqg_blow5_write_batch == the reference's BLOW5"""
+    o, ids, offset, median, so, sig = _case(cid)
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "refvec", "r9_t1.npz"))     # (layout of the refvec fixtures)
+    del d
+    # the reads themselves: sample them as the reference did (device sampler on the same FASTA, same seed)
+    import bench
+    contigs = bench.load_contigs(os.path.join(INPUTS, o.ref))
+    k = o.kmer_size_default
+    mean, stdv = model.synthetic_model(k)
+    gen = api.SignalGenerator(o.profile, o.flags, k, mean, stdv, o.seed, num_workers=o.threads, mode=api.MODE_CERTIFIED)
+    gen.load_genome(contigs, o.rlen, api.SAMPLE_RNA if (o.flags & profiles.SQ_RNA) else api.SAMPLE_DNA)
+    path = str(tmp_path / "x.blow5")
+    w = api.Blow5Writer(path, o.profile, o.flags, threads=2)
+    done = 0
+    while done < len(ids):
+        nb = min(o.batch, len(ids) - done)
+        b = gen.sample(nb).run().wait()
+        np.testing.assert_array_equal(b.offset, offset[done:done + nb])
+        w.write_batch(b, ids[done:done + nb])
+        b.free()
+        done += nb
+    w.close()
+    gen.close()
+    assert open(path, "rb").read() == open(os.path.join(GOLD, cid + ".blow5"), "rb").read()
+
+
+@pytest.mark.gpu
+def test_full_size_batch_round_trip(tmp_path):
+    """a bench-sized batch: every record inflates, its signal field decodes (svb-zd) to the batch's int16 samples"""
+    import bench
+    prof, fl = profiles.get_profile("dna-r10-prom")
+    mean, stdv = model.synthetic_model(9)
+    gen = api.SignalGenerator(prof, fl, 9, mean, stdv, 42, num_workers=1, mode=api.MODE_CERTIFIED)
+    gen.load_genome(bench.synthetic_genome_host(8.0), 10000, api.SAMPLE_DNA)
+    b = gen.sample(1024).run().wait()
+    sig = b.signal()
+    ids = [b"S1_%d!c!0!1!+" % (i + 1) for i in range(b.n_reads)]
+    path = str(tmp_path / "big.blow5")
+    w = api.Blow5Writer(path, prof, fl)
+    w.write_batch(b, ids)
+    n = w.close()
+    buf = open(path, "rb").read()
+    assert n == len(buf) and n < 2 * len(sig) * 0.8              # smaller than the raw int16
+    _, recs = parse_blow5(buf)
+    assert len(recs) == b.n_reads
+    start = 0
+    for i in (0, 1, 17, 500, b.n_reads - 1):
+        r = recs[i]
+        (idl,) = struct.unpack_from("<H", r, 0)
+        q = 2 + idl + 4
+        dig, off, rng_, sr = struct.unpack_from("<4d", r, q); q += 32
+        (nb,) = struct.unpack_from("<Q", r, q); q += 8
+        dec, used = orc.svb_zd_decode(np.frombuffer(r, np.uint8, nb, q))
+        np.testing.assert_array_equal(dec, sig[b.sig_off[i]:b.sig_off[i + 1]])
+        assert used == nb and off == b.offset[i] and dig == prof.digitisation
+        q += nb
+        one, ch = struct.unpack_from("<Qc", r, q); q += 9
+        med, rn, mux, st = struct.unpack_from("<diBQ", r, q)
+        assert (one, ch, med, rn, mux, st) == (1, b"0", b.median_before[i], i, 0, int(b.sig_off[i]))
+    b.free(); gen.close()
