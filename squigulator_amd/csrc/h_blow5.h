@@ -1,5 +1,6 @@
 // h_blow5.h -- native BLOW5 writer: header, record framing, zlib record compression (sqg_blow5_*)
 // Host side of include/sqg.h; included by sqg_hip.hip (one translation unit with the kernels), in the order listed there.
+// Nothing here touches the device or the context's internals: the batch is reached through the public entry points only.
 //
 // The other half of work_per_single_read (src/sim.c:604-640: slow5_encode per read, slow5_write_bytes in output_db): the file
 // the reference writes through slow5lib for `-o x.blow5` -- zlib record compression, svb-zd signal compression
@@ -154,14 +155,14 @@ extern "C" int sqg_blow5_write_batch(sqg_blow5_t* w, sqg_ctx_t* c, sqg_batch_t* 
     if (!w || !c || !b) return SQG_EINVAL;
     sqg_result_t res;
     int rc = sqg_batch_wait(c, b, &res);
-    if (rc) { w->err = c->err; return rc; }
+    if (rc) { w->err = sqg_last_error(c); return rc; }
     sqg_svb_t sv;
-    if ((rc = sqg_batch_compress(c, b, &sv))) { w->err = c->err; return rc; }
+    if ((rc = sqg_batch_compress(c, b, &sv))) { w->err = sqg_last_error(c); return rc; }
     uint8_t* host = (uint8_t*)sqg_host_alloc((size_t)std::max<int64_t>(sv.n_bytes, 1));
     if (!host) return SQG_ENOMEM;
     rc = sqg_fetch_svb(c, b, host);
     if (rc == SQG_OK) rc = sqg_blow5_write(w, res.n_reads, read_ids, id_off, res.offset, res.median_before, res.sig_off, host, sv.svb_off);
-    else w->err = c->err;
+    else w->err = sqg_last_error(c);
     sqg_host_free(host);
     return rc;
 }
