@@ -37,10 +37,12 @@ void set_header_attributes(slow5_file_t *sp, int8_t rna, int8_t r10, double samp
 void set_header_aux_fields(slow5_file_t *sp, int8_t ont_friendly);
 void set_record_primary_fields(profile_t *profile, slow5_rec_t *rec, char *read_id, double offset, int64_t len_raw_signal, int16_t *raw_signal);
 void set_record_aux_fields(slow5_rec_t *rec, slow5_file_t *sp, double median_before, int32_t read_number, uint64_t start_time, int8_t ont_friendly);
+void load_meth_freq(const char *meth_freq, ref_t *ref);        /* src/ref.c:291 */
 
 typedef struct {
     char fasta[4096], model[4096], out[4096], slow5[4096], fasta_out[4096], paf[4096], sam[4096], trans_count[4096];
     char svb_out[4096];      /* per read: int64 nbytes + slow5lib's own svb-zd encoding of the raw signal */
+    char meth_freq[4096];    /* --meth-freq: CpG methylation; `model` is then the 5-letter table (5^k rows, src/sim.c:297-326) */
     char svb_in[4096];       /* stand-alone mode: int32 n, then n x (int64 len, int16[len]) -> svb_out in the same framing */
     profile_t p;
     uint32_t flags;
@@ -67,7 +69,7 @@ static void parse_cfg(const char *path, cfg_t *c) {
         const char *k = line;
 #define STR(name) if (!strcmp(k, #name)) { strncpy(c->name, v, sizeof c->name - 1); continue; }
 #define DBL(name) if (!strcmp(k, #name)) { c->p.name = strtod(v, NULL); continue; }
-        STR(fasta) STR(model) STR(out) STR(slow5) STR(fasta_out) STR(paf) STR(sam) STR(trans_count) STR(svb_out) STR(svb_in)
+        STR(fasta) STR(model) STR(out) STR(slow5) STR(fasta_out) STR(paf) STR(sam) STR(trans_count) STR(svb_out) STR(svb_in) STR(meth_freq)
         DBL(digitisation) DBL(sample_rate) DBL(bps) DBL(range) DBL(offset_mean) DBL(offset_std)
         DBL(median_before_mean) DBL(median_before_std) DBL(dwell_mean) DBL(dwell_std)
         if (!strcmp(k, "flags")) { c->flags = (uint32_t)strtoul(v, NULL, 0); continue; }
@@ -85,7 +87,7 @@ static void parse_cfg(const char *path, cfg_t *c) {
 
 /* f5c-format text table -> model_t[]; the same "%f" conversions the
  * reference's reader applies (src/model.c:101-102) */
-static uint32_t load_table(const char *path, model_t *m) {
+static uint32_t load_table(const char *path, model_t *m, int meth) {
     FILE *fp = fopen(path, "r");
     if (!fp) { perror(path); exit(2); }
     char line[512], kmer[32];
@@ -97,7 +99,9 @@ static uint32_t load_table(const char *path, model_t *m) {
         n++;
     }
     fclose(fp);
-    if (!k || n != (1u << (2 * k))) { fprintf(stderr, "bad model file (k=%u, n=%u)\n", k, n); exit(2); }
+    uint32_t want = 1u << (2 * k);
+    if (meth) { want = 1; for (uint32_t i = 0; i < k; i++) want *= 5; }      /* rows in file order, src/model.c:100-120 */
+    if (!k || n != want) { fprintf(stderr, "bad model file (k=%u, n=%u)\n", k, n); exit(2); }
     return k;
 }
 
@@ -112,7 +116,8 @@ static void seed_workers(core_t *core) {
     core->rand_offset = malloc(T * sizeof(nrng_t *));
     core->rand_median_before = malloc(T * sizeof(nrng_t *));
     core->kmer_gen = malloc(T * sizeof(nrng_t **));
-    core->rand_meth = NULL;
+    const model_t *m = core->opt.meth_freq ? core->cpgmodel : core->model;      /* src/sim.c:231-236 */
+    core->rand_meth = core->opt.meth_freq ? malloc(T * sizeof(int64_t)) : NULL;
     int64_t s = core->opt.seed;
     for (int t = 0; t < T; t++, s += nk + 10) {
         core->ref_pos[t] = s;
@@ -123,7 +128,8 @@ static void seed_workers(core_t *core) {
         core->rand_median_before[t] = init_nrng(s + 5, p.median_before_mean, p.median_before_std);
         core->kmer_gen[t] = malloc(nk * sizeof(nrng_t *));
         for (uint32_t j = 0; j < nk; j++)
-            core->kmer_gen[t][j] = init_nrng(s + j, core->model[j].level_mean, core->model[j].level_stdv * core->opt.amp_noise);
+            core->kmer_gen[t][j] = init_nrng(s + j, m[j].level_mean, m[j].level_stdv * core->opt.amp_noise);
+        if (core->rand_meth) core->rand_meth[t] = s + 6;                          /* src/sim.c:252-254 */
     }
 }
 
@@ -162,10 +168,18 @@ int main(int argc, char **argv) {
     core->opt.amp_noise = cfg.amp_noise;
     core->profile = cfg.p;
     core->model = malloc(sizeof(model_t) * MAX_NUM_KMER);
-    core->kmer_size = load_table(cfg.model, core->model);
-    core->num_kmer = 1u << (2 * core->kmer_size);
+    if (cfg.meth_freq[0]) {                                    /* src/sim.c:296-326 */
+        core->opt.meth_freq = cfg.meth_freq;
+        core->cpgmodel = malloc(sizeof(model_t) * MAX_NUM_KMER_METH);
+        core->kmer_size = load_table(cfg.model, core->cpgmodel, 1);
+        core->num_kmer = (uint32_t)pow(5, core->kmer_size);
+    } else {
+        core->kmer_size = load_table(cfg.model, core->model, 0);
+        core->num_kmer = 1u << (2 * core->kmer_size);
+    }
     seed_workers(core);
     core->ref = load_ref(cfg.fasta);
+    if (cfg.meth_freq[0]) load_meth_freq(cfg.meth_freq, core->ref);          /* src/sim.c:339-341 */
     if (cfg.trans_count[0]) load_trans_count(cfg.trans_count, core->ref);
 
     const int8_t rna = (cfg.flags & SQ_RNA) ? 1 : 0, ont = (cfg.flags & SQ_ONT) ? 1 : 0;

@@ -87,6 +87,23 @@ uint32_t orc_kmer_rank(const char *s, uint32_t k) {
     return r;
 }
 
+/* src/seq.h:45-74: the 5-letter alphabet of the methylation models, A C G M T = 0..4 (upper case only; anything else
+ * -> 0 with a warning); first base is the most significant base-5 digit */
+static uint32_t meth_base_rank(char b) {
+    switch (b) {
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'M': return 3;
+    case 'T': return 4;
+    default: return 0;
+    }
+}
+uint32_t orc_meth_kmer_rank(const char *s, uint32_t k) {
+    uint32_t p = 1, r = 0;
+    for (uint32_t i = 0; i < k; i++) { r += meth_base_rank(s[k - i - 1]) * p; p *= 5; }
+    return r;
+}
+
 /* src/seq.h:78-112: complement maps anything outside ACGTacgt to 'T' */
 char *orc_revcomp(const char *f) {
     const size_t n = strlen(f);
@@ -234,7 +251,38 @@ void orc_ref_free(orc_ref_t *ref) {
     for (int i = 0; i < ref->num_ref; i++) { free(ref->names[i]); free(ref->seqs[i]); }
     free(ref->names); free(ref->seqs); free(ref->lengths);
     free(ref->trans_csum); free(ref->trans_idx);
+    if (ref->meth) { for (int i = 0; i < ref->num_ref; i++) free(ref->meth[i]); free(ref->meth); }
     free(ref);
+}
+
+/* src/ref.c:291-361: tab-separated [contig, 0-based position, frequency in 0..1]; the position must hold a C; the frequency is
+ * kept as round(255*freq) in a per-contig byte array allocated on the contig's first line.  '#' lines are skipped.
+ * Returns 0, or -(1-based line number) where the reference prints an error and exits. */
+int orc_ref_load_meth_freq(orc_ref_t *ref, const char *tsv) {
+    FILE *fp = fopen(tsv, "r");
+    if (!fp) return -1000000000;
+    ref->meth = (uint8_t **)calloc((size_t)ref->num_ref, sizeof(uint8_t *));
+    char *line = NULL; size_t cap = 0; ssize_t len;
+    int ln = 0, rc = 0;
+    while ((len = getline(&line, &cap, fp)) != -1) {
+        ln++;
+        if (line[0] == '#') continue;
+        char *name = strtok(line, "\t"), *pos_s = strtok(NULL, "\t"), *fr_s = strtok(NULL, "\t");
+        if (!name || !pos_s || !fr_s) { rc = -ln; break; }
+        int idx = -1;
+        for (int i = 0; i < ref->num_ref; i++) if (!strcmp(ref->names[i], name)) { idx = i; break; }
+        if (idx < 0) { rc = -ln; break; }
+        const int32_t pos = atoi(pos_s);
+        if (pos < 0 || pos >= ref->lengths[idx]) { rc = -ln; break; }
+        const char b = ref->seqs[idx][pos];
+        if (!(b == 'C' || b == 'c')) { rc = -ln; break; }
+        const float freq = atof(fr_s);
+        if (freq < 0 || freq > 1) { rc = -ln; break; }
+        if (!ref->meth[idx]) ref->meth[idx] = (uint8_t *)calloc((size_t)ref->lengths[idx], 1);
+        ref->meth[idx][pos] = (uint8_t)roundf(freq * 255);
+    }
+    free(line); fclose(fp);
+    return rc;
 }
 
 /* ------------------------------------------------------------------ */
@@ -253,6 +301,7 @@ orc_core_t *orc_core_new(const orc_profile_t *p, uint32_t flags, float amp_noise
     orc_core_t *c = (orc_core_t *)calloc(1, sizeof *c);
     c->prof = *p; c->flags = flags; c->amp_noise = amp_noise;
     c->kmer_size = kmer_size; c->num_kmer = 1u << (2 * kmer_size);
+    if (flags & ORC_METH) { c->num_kmer = 1; for (uint32_t i = 0; i < kmer_size; i++) c->num_kmer *= 5; }   /* (uint32_t)pow(5,k), src/sim.c:325 */
     c->seed = seed; c->num_workers = num_workers; c->rlen = rlen;
     c->model = (orc_kmer_t *)xmalloc(c->num_kmer * sizeof(orc_kmer_t));
     memcpy(c->model, model, c->num_kmer * sizeof(orc_kmer_t));
@@ -315,7 +364,7 @@ static void emit_events(orc_core_t *c, sigbuf_t *b, double offset, const char *r
     int64_t n_ev = (int64_t)len - k + 1;
     if (len < (int32_t)k) { n_ev = 5; read = "ACGTACGTACGT"; }       /* gensig.c:242-245 */
     for (int i = 0; i < n_ev; i++) {
-        const uint32_t rank = orc_kmer_rank(read + i, k);
+        const uint32_t rank = (c->flags & ORC_METH) ? orc_meth_kmer_rank(read + i, k) : orc_kmer_rank(read + i, k);   /* gensig.c:250-253 */
         if (!(ideal || ideal_time)) {                                /* gensig.c:254-257 */
             sps = round(orc_nrng(&w->dwell));
             sps = sps < 1 ? -sps + 1 : sps;
@@ -465,7 +514,23 @@ static char pick_strand(orc_core_t *c, int tid) {
     return v ? '+' : '-';
 }
 
-/* src/genread.c:243-281 (methylation branch out of scope) */
+/* src/genread.c:207-241: every CpG of the read's span on the (forward) reference -- both bases upper case, both inside the
+ * read -- takes one draw from the worker's rand_meth stream, whatever the outcome; the C becomes 'M' when
+ * (int)(u*254) <= the position's frequency byte.  On the '-' strand the CpG sits at rlen-i-2 of the reverse complement.
+ * Contigs without any line in the frequency file take no draws. */
+static void methylate(orc_core_t *c, const orc_ref_t *ref, int idx, int32_t ref_len, int32_t ref_pos, int32_t rlen, char strand,
+                      char *seq, int tid) {
+    if (!ref->meth || !ref->meth[idx]) return;
+    const char *g = ref->seqs[idx];
+    for (int i = 0; i < rlen; i++) {
+        if (ref_pos + i + 1 < ref_len && i + 1 < rlen && g[ref_pos + i] == 'C' && g[ref_pos + i + 1] == 'G') {
+            const int methr = orc_rng(&c->workers[tid].meth_x) * 254;
+            if (methr <= ref->meth[idx][ref_pos + i]) seq[strand == '-' ? rlen - i - 2 : i] = 'M';
+        }
+    }
+}
+
+/* src/genread.c:243-281 */
 static char *sample_dna(orc_core_t *c, const orc_ref_t *ref, int tid, int32_t *ref_idx,
                         int32_t *ref_len, int32_t *ref_pos, int32_t *rlen, char *strand) {
     char *seq;
@@ -484,6 +549,7 @@ static char *sample_dna(orc_core_t *c, const orc_ref_t *ref, int tid, int32_t *r
         char *r = orc_revcomp(seq);
         free(seq); seq = r;
     }
+    if (c->flags & ORC_METH) methylate(c, ref, *ref_idx, *ref_len, *ref_pos, *rlen, *strand, seq, tid);   /* genread.c:276-278 */
     return seq;
 }
 

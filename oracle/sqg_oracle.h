@@ -32,6 +32,10 @@ extern "C" {
 #define ORC_TRANS_TRUNC 0x100
 #define ORC_CDNA        0x200
 #define ORC_ONT         0x400
+/* not an opt_t.flag bit: the reference keys methylation on opt.meth_freq != NULL (src/sim.c:231,297; src/gensig.c:231,251).
+ * Set: the pore model is the 5-letter (A C G M T) table of 5^k rows, ranks are src/seq.h:45-74, a worker's seeds advance
+ * by 5^k + 10, and gen_read methylates CpGs from the contig's frequency array (src/genread.c:207-241,276-277) */
+#define ORC_METH        0x1000
 
 /* profile_t, src/sq.h:47-58 */
 typedef struct {
@@ -62,7 +66,7 @@ typedef struct { double a, b; int64_t x; } orc_gamma_t;
 typedef struct {
     int64_t pos_x;        /* core->ref_pos[tid]      */
     int64_t strand_x;     /* core->rand_strand[tid]  */
-    int64_t meth_x;       /* core->rand_meth[tid] (unused: methylation out of scope) */
+    int64_t meth_x;       /* core->rand_meth[tid] */
     orc_norm_t dwell;     /* core->rand_time[tid]    */
     orc_gamma_t rlen;     /* core->rand_rlen[tid]    */
     orc_norm_t offset;    /* core->rand_offset[tid]  */
@@ -80,6 +84,7 @@ typedef struct {
     int32_t trans_n;      /* 0 when no --trans-count table */
     float *trans_csum;
     int32_t *trans_idx;
+    uint8_t **meth;       /* ref->ref_meth: per contig NULL or round(255*freq) per base (src/ref.c:291-361); NULL: no --meth-freq */
 } orc_ref_t;
 
 typedef struct {
@@ -137,6 +142,8 @@ char    *orc_revcomp(const char *f);                 /* src/seq.h:78-112  */
 uint32_t orc_read_model(const char *path, orc_kmer_t **out);
 orc_ref_t *orc_ref_load(const char *fasta);          /* src/ref.c:54-117 (plain text FASTA only) */
 int      orc_ref_load_trans_count(orc_ref_t *ref, const char *tsv); /* src/ref.c:206-273 */
+int      orc_ref_load_meth_freq(orc_ref_t *ref, const char *tsv);   /* src/ref.c:291-361; 0 ok, <0: the line the reference would exit on */
+uint32_t orc_meth_kmer_rank(const char *s, uint32_t k);             /* src/seq.h:45-74 */
 void     orc_ref_free(orc_ref_t *ref);
 
 /* ---- core ---- */

@@ -12,9 +12,10 @@ from __future__ import annotations
 import numpy as np
 
 
-def synthetic_model(k: int, salt: int = 0):
-    """(level_mean float32[4^k], level_stdv float32[4^k]) from a fixed integer hash of the rank."""
-    n = 1 << (2 * k)
+def synthetic_model(k: int, salt: int = 0, meth: bool = False):
+    """(level_mean float32[n], level_stdv float32[n]) from a fixed integer hash of the rank; n = 4^k, or 5^k for the
+    5-letter (A C G M T) methylation tables (src/sim.c:325)."""
+    n = 5 ** k if meth else 1 << (2 * k)
     r = np.arange(n, dtype=np.uint64)
     h = (r + np.uint64(salt) * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
     h = (h * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
@@ -35,13 +36,20 @@ def kmer_string(rank: int, k: int) -> str:
     return "".join(_BASES[(rank >> (2 * (k - 1 - i))) & 3] for i in range(k))
 
 
+def meth_kmer_string(rank: int, k: int) -> str:
+    """the k-mer of a 5-letter rank (src/seq.h:45-74: A C G M T = 0..4, first base most significant)"""
+    return "".join("ACGMT"[(rank // 5 ** (k - 1 - i)) % 5] for i in range(k))
+
+
 def write_f5c_model(path, k: int, mean, stdv) -> None:
+    """f5c-format text table; 5^k rows are written with the 5-letter k-mers (rows are taken in file order, src/model.c:100)"""
+    meth = len(mean) == 5 ** k
     with open(path, "w") as f:
         f.write("#model_name\tsynthetic\n")
         f.write(f"#k\t{k}\n")
         f.write("kmer\tlevel_mean\tlevel_stdv\tsd_mean\tsd_stdv\n")
-        for r in range(1 << (2 * k)):
-            f.write(f"{kmer_string(r, k)}\t{float(mean[r]):f}\t{float(stdv[r]):f}\t0.0\t0.0\n")
+        for r in range(len(mean)):
+            f.write(f"{meth_kmer_string(r, k) if meth else kmer_string(r, k)}\t{float(mean[r]):f}\t{float(stdv[r]):f}\t0.0\t0.0\n")
 
 
 def read_f5c_model(path):

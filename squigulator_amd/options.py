@@ -181,6 +181,7 @@ def parse_args(argv) -> SimOptions:
             _yes_no(o, P.SQ_ONT, val)
         elif name == "--meth-freq":
             o.meth_freq = val
+            o.flags |= P.SQ_METH
         elif name in ("-v", "--verbose", "--meth-model"):
             pass
 

@@ -21,6 +21,9 @@ SQ_PAF_REF = 0x080
 SQ_TRANS_TRUNC = 0x100
 SQ_CDNA = 0x200
 SQ_ONT = 0x400
+# not an opt_t.flag bit: the reference keys CpG methylation on opt.meth_freq != NULL (src/sim.c:231,297, src/gensig.c:231,251);
+# here it is a flag of the context: 5-letter (A C G M T) pore table of 5^k rows, ranks of src/seq.h:45-74
+SQ_METH = 0x1000
 
 
 @dataclass(frozen=True)

@@ -39,7 +39,7 @@ class Ref(C.Structure):
     _fields_ = [("num_ref", C.c_int32), ("sum", C.c_int64), ("names", C.POINTER(C.c_char_p)),
                 ("seqs", C.POINTER(C.c_char_p)), ("lengths", C.POINTER(C.c_int32)),
                 ("trans_n", C.c_int32), ("trans_csum", C.POINTER(C.c_float)),
-                ("trans_idx", C.POINTER(C.c_int32))]
+                ("trans_idx", C.POINTER(C.c_int32)), ("meth", C.POINTER(C.POINTER(C.c_uint8)))]
 
 
 class Core(C.Structure):
@@ -86,6 +86,10 @@ def lib():
         L.orc_ref_load.argtypes = [C.c_char_p]
         L.orc_ref_load_trans_count.restype = C.c_int
         L.orc_ref_load_trans_count.argtypes = [C.POINTER(Ref), C.c_char_p]
+        L.orc_ref_load_meth_freq.restype = C.c_int
+        L.orc_ref_load_meth_freq.argtypes = [C.POINTER(Ref), C.c_char_p]
+        L.orc_meth_kmer_rank.restype = C.c_uint32
+        L.orc_meth_kmer_rank.argtypes = [C.c_char_p, C.c_uint32]
         L.orc_ref_free.argtypes = [C.POINTER(Ref)]
         L.orc_core_new.restype = C.POINTER(Core)
         L.orc_core_new.argtypes = [C.POINTER(Profile), C.c_uint32, C.c_float, C.c_uint32,
@@ -140,12 +144,15 @@ class Oracle:
                                         seed, num_workers, rlen)
         self.ref = None
 
-    def load_ref(self, fasta, trans_count=None):
+    def load_ref(self, fasta, trans_count=None, meth_freq=None):
         self.ref = self.L.orc_ref_load(os.fsencode(fasta))
         if not self.ref:
             raise FileNotFoundError(fasta)
         if trans_count:
             rc = self.L.orc_ref_load_trans_count(self.ref, os.fsencode(trans_count))
+            assert rc == 0, rc
+        if meth_freq:
+            rc = self.L.orc_ref_load_meth_freq(self.ref, os.fsencode(meth_freq))
             assert rc == 0, rc
         return self.ref.contents
 

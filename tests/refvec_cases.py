@@ -21,4 +21,10 @@ REFVEC_CASES = [
     ("r10_t1", "nCoV-2019.reference.fasta -x dna-r10-prom -n 5 --seed 42 -r 1000 -t1"),
     ("r10_tk8", "nCoV-2019.reference.fasta -x dna-r10-prom -n 16 --seed 42 -r 600 -t 8 -K 8"),
     ("cdna_tc", "rnasequin_sequences_2.4.fa -x dna-r10-min -n 3 --seed 3 -t1 --cdna --trans-count sequin_count.tsv"),
+    # CpG methylation (--meth-freq): the 5-letter 5^k table; mfreq.tsv is the reference's own 5-line test file, mfreq_dense.tsv
+    # a frequency for every fourth CpG of the genome (tools/make_methfreq.py)
+    ("r9_meth", "nCoV-2019.reference.fasta -x dna-r9-prom -n 3 --seed 1 -r 4000 -t1 --meth-freq mfreq.tsv"),
+    ("r9_meth_dense", "nCoV-2019.reference.fasta -x dna-r9-prom -n 6 --seed 5 -r 1500 -t1 --meth-freq mfreq_dense.tsv"),
+    ("r9_meth_tk4", "nCoV-2019.reference.fasta -x dna-r9-prom -n 8 --seed 11 -r 1200 -t 4 -K 4 --meth-freq mfreq_dense.tsv"),
+    ("r10_meth_dense", "nCoV-2019.reference.fasta -x dna-r10-prom -n 3 --seed 2 -r 1200 -t1 --meth-freq mfreq_dense.tsv"),
 ]

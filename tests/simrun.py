@@ -18,10 +18,11 @@ def run_oracle(cmdline: str, model_override=None, nthreads=1):
         k, mean, stdv = model_override
     else:
         k = o.kmer_size_default
-        mean, stdv = model.synthetic_model(k)
+        mean, stdv = model.synthetic_model(k, meth=bool(o.meth_freq))
     orac = orc.Oracle(o.profile, o.flags, k, mean, stdv, o.seed, o.threads, o.rlen, o.amp_noise)
     ref = orac.load_ref(os.path.join(INPUTS, o.ref),
-                        os.path.join(INPUTS, o.trans_count) if o.trans_count else None)
+                        os.path.join(INPUTS, o.trans_count) if o.trans_count else None,
+                        os.path.join(INPUTS, o.meth_freq) if o.meth_freq else None)
     names = [ref.names[i].decode() for i in range(ref.num_ref)]
     lengths = [ref.lengths[i] for i in range(ref.num_ref)]
     n = options.resolve_nreads(o, ref.num_ref, ref.sum)

@@ -31,13 +31,13 @@ HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 _model_files = {}
 
 
-def model_file(k, tmp):
-    if k not in _model_files:
-        mean, stdv = model.synthetic_model(k)
-        path = os.path.join(tmp, f"synthetic_{k}mer.model")
+def model_file(k, tmp, meth=False):
+    if (k, meth) not in _model_files:
+        mean, stdv = model.synthetic_model(k, meth=meth)
+        path = os.path.join(tmp, f"synthetic_{k}mer{'_meth' if meth else ''}.model")
         model.write_f5c_model(path, k, mean, stdv)
-        _model_files[k] = path
-    return _model_files[k]
+        _model_files[(k, meth)] = path
+    return _model_files[(k, meth)]
 
 
 def run_harness(cmdline, tmp, extra=None):
@@ -45,12 +45,14 @@ def run_harness(cmdline, tmp, extra=None):
     k = o.kmer_size_default
     out = os.path.join(tmp, "out.bin")
     cfg = {
-        "fasta": os.path.join(INPUTS, o.ref), "model": model_file(k, tmp), "out": out,
+        "fasta": os.path.join(INPUTS, o.ref), "model": model_file(k, tmp, bool(o.meth_freq)), "out": out,
         "flags": o.flags, "amp_noise": repr(float(np.float32(o.amp_noise))), "seed": o.seed,
         "threads": o.threads, "batch": o.batch, "nreads": o.nreads, "rlen": o.rlen,
     }
     if o.trans_count:
         cfg["trans_count"] = os.path.join(INPUTS, o.trans_count)
+    if o.meth_freq:
+        cfg["meth_freq"] = os.path.join(INPUTS, o.meth_freq)
     for name, v in zip(("digitisation", "sample_rate", "bps", "range", "offset_mean", "offset_std",
                         "median_before_mean", "median_before_std", "dwell_mean", "dwell_std"),
                        o.profile.as_tuple()):
