@@ -45,6 +45,11 @@ extern "C" {
 #define SQG_PREFIX      0x020u
 #define SQG_R10         0x040u   /* header of the BLOW5 writer: sequencing_kit (src/gensig.c:104-109)                 */
 #define SQG_ONT         0x400u   /* ... and the ONT-friendly extra field end_reason (src/gensig.c:160-168)            */
+/* not an opt_t.flag bit: the reference keys CpG methylation on opt.meth_freq != NULL (src/sim.c:231,297; src/gensig.c:231,251).
+ * Set: cfg.model is the 5-letter (A C G M T) table of 5^k rows (core->cpgmodel), k-mer ranks are the base-5 numbers of
+ * src/seq.h:45-74, and a worker's seeds advance by 5^k + 10 (src/sim.c:325).  Reads handed to sqg_batch_stage carry 'M' where
+ * gen_read methylated a CpG; the device sampler does it itself once sqg_genome_set_meth has been called. */
+#define SQG_METH        0x1000u
 
 /* error codes */
 #define SQG_OK            0

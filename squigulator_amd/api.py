@@ -306,14 +306,14 @@ class SignalGenerator:
                  worker_lo: int = 0, worker_hi: int | None = None, lib_path: str | None = None):
         self.L = load_library(lib_path)
         self.ctx = None
-        n = 1 << (2 * kmer_size)
+        n = 5 ** kmer_size if (flags & P.SQ_METH) else 1 << (2 * kmer_size)
         if len(level_mean) != n or len(level_stdv) != n:
-            raise ValueError("pore model must have 4^k rows")
+            raise ValueError("pore model must have 4^k rows (5^k for the methylation tables)")
         self._model = (CKmer * n)()
         a = np.frombuffer(self._model, dtype=np.float32).reshape(n, 2)
         a[:, 0] = level_mean
         a[:, 1] = level_stdv
-        cfg = CCfg(ABI_VERSION, CProfile(*profile.as_tuple()), flags & 0x3d, amp_noise, kmer_size,
+        cfg = CCfg(ABI_VERSION, CProfile(*profile.as_tuple()), flags & 0x103d, amp_noise, kmer_size,
                    self._model, seed, num_workers, worker_lo,
                    num_workers if worker_hi is None else worker_hi, device, mode)
         h = C.c_void_p()

@@ -66,7 +66,8 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     if (!(cfg->profile.range != 0.0) || !(cfg->profile.dwell_mean >= 1.0)) return SQG_EINVAL;
     if (cfg->profile.dwell_mean + 8.0 * std::fabs(cfg->profile.dwell_std) > 60000.0) return SQG_EINVAL;
     if (cfg->mode != SQG_MODE_EXACT && cfg->mode != SQG_MODE_CERTIFIED) return SQG_EINVAL;
-    const long long nk = 1LL << (2 * cfg->kmer_size);
+    long long nk = 1LL << (2 * cfg->kmer_size);
+    if (cfg->flags & SQG_METH) { nk = 1; for (uint32_t i = 0; i < cfg->kmer_size; i++) nk *= 5; }     // (uint32_t)pow(5,k), src/sim.c:325
     // canonical-form validity: |seed| + T*(nk+10) must stay where Schrage's uncorrected state is
     // within (-M, M) after one step (see DESIGN.md "LCG")
     const double span = std::fabs((double)cfg->seed) + (double)cfg->num_workers * (double)(nk + 10);
@@ -192,7 +193,7 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     if (c->use_kmer_streams) {
         const long long total = (long long)c->nw * nk;
         CHK(hipMalloc(&c->d_rows, (size_t)total * sizeof(uint32_t)));
-        if (c->k <= 6) {
+        if (c->num_kmer <= 4096) {
             // rows hold the stream STATES; a chain moves its whole row through LDS (src/sim.c:248-256)
             const int blocks = (int)((total + 255) / 256);
             hipLaunchKernelGGL(k_init_rows, dim3(blocks), dim3(256), 0, c->stream, c->d_rows, (int)nk, (long long)cfg->seed, c->wlo, total);

@@ -32,7 +32,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     // Dwell draws are made inside k_events (SQG_SEPARATE_DWELL=1 keeps the stand-alone k_dwell for A/B runs).
     static const bool separate_dwell = getenv("SQG_SEPARATE_DWELL") != nullptr;
     const bool inline_dwell = c->use_dwell_stream && !separate_dwell;
-    const bool direct = c->k <= 6;
+    const bool direct = c->num_kmer <= 4096;                    // the worker's whole row of stream states fits in LDS
     if (phase != 2 && !direct && c->use_kmer_streams && n > 0) {
         // the rows count samples in 32 bits; only the count mod (M-1)/2 matters (range mode: the other ranges' counts are not
         // known here, so the rows are reduced before every batch)
@@ -49,12 +49,13 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         c->row_bound += bnd;
     }
     if (phase != 2 && b->split && !b->part && (rc = ensure(c, (void**)&c->d_link_rows, &c->link_rows_cap, (size_t)b->n_chains * (size_t)c->num_kmer, sizeof(uint32_t)))) return rc;
-    const int n_part = c->num_kmer >> PART_SUB_BITS;
+    const int n_part = (c->num_kmer + PART_SUB - 1) >> PART_SUB_BITS;
+    const int kmer_pad = n_part * PART_SUB;
     if (phase != 2 && b->part) {
         if ((rc = ensure(c, (void**)&c->d_part, &c->part_cap, (size_t)b->n_events + PART_SLACK, sizeof(uint32_t)))) return rc;
         if ((rc = ensure(c, (void**)&c->d_pcnt, &c->pcnt_cap, (size_t)2 * b->n_chains * (size_t)n_part, sizeof(uint32_t)))) return rc;   // counts, offsets
         if ((rc = ensure(c, (void**)&c->d_slice, &c->slice_cap, (size_t)2 * b->n_groups * (size_t)n_part, sizeof(uint32_t)))) return rc;
-        if ((rc = ensure(c, (void**)&c->d_phist, &c->phist_cap, (size_t)b->n_groups * (size_t)c->num_kmer, sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(c, (void**)&c->d_phist, &c->phist_cap, (size_t)b->n_groups * (size_t)kmer_pad, sizeof(uint32_t)))) return rc;
     }
     const size_t n_rows = (size_t)c->nw * (size_t)c->num_kmer;
     if (phase == 1 && (rc = ensure(c, (void**)&c->d_xcounts, &c->xcounts_cap, n_rows, sizeof(uint32_t)))) return rc;
@@ -66,10 +67,12 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     P.dwell = c->use_dwell_stream ? S.d_dwell : nullptr; P.dwell_out = S.d_dwell; P.seglen_out = S.d_seglen;
     P.dmean = p.dwell_mean; P.dstd = p.dwell_std;
     P.seglen = S.d_seglen; P.sig_off = S.d_sigoff; P.model = c->d_model; P.pw = c->d_pow; P.rows = c->d_rows;
-    P.seed_base = canon((long long)c->cfg.seed + (long long)c->wlo * ((long long)(1u << (2 * c->k)) + 10)); P.seed_step = canon((long long)(1u << (2 * c->k)) + 10);
+    P.seed_base = canon((long long)c->cfg.seed + (long long)c->wlo * ((long long)c->num_kmer + 10)); P.seed_step = canon((long long)c->num_kmer + 10);
     P.err = b->d_err; P.dig = p.digitisation; P.range = p.range; P.kd = p.digitisation / p.range;
     P.chain_order = b->d_chain_order; P.delta_x = c->delta_x; P.thr_all = c->thr_all;
     P.k = c->k; P.num_kmer = c->num_kmer; P.const_sps = (int)p.dwell_mean;
+    P.meth = (c->cfg.flags & SQG_METH) ? 1 : 0; P.num_kmer_pad = kmer_pad;
+    P.meth_top = 1; for (int i = 1; i < c->k; i++) P.meth_top *= 5u;
     P.use_streams = c->use_kmer_streams ? 1 : 0;
     P.dwell_unbounded = c->dwell_hi > 65535.0 ? 1 : 0;
     P.rna = (c->cfg.flags & SQG_RNA) ? 1 : 0;
@@ -135,12 +138,12 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 if ((rc = dbg_sync(c, "k_events<scatter>/k_part_hist"))) return rc;
                 if (phase == 1) {                                 // range sharding: what this range draws per stream, for the exchange
                     HIPCHK(c, hipMemsetAsync(c->d_xcounts, 0, n_rows * sizeof(uint32_t), c->stream));
-                    hipLaunchKernelGGL(k_part_totals, sg, dim3(256), 0, c->stream, c->d_phist, c->num_kmer, b->d_wgroup_off, b->d_wlink_worker, c->d_xcounts);
+                    hipLaunchKernelGGL(k_part_totals, sg, dim3(256), 0, c->stream, c->d_phist, c->num_kmer, kmer_pad, b->d_wgroup_off, b->d_wlink_worker, c->d_xcounts);
                     HIPCHK(c, hipGetLastError());
                 }
             }
             if (phase != 1) {
-                hipLaunchKernelGGL(k_part_scan, sg, dim3(256), 0, c->stream, c->d_phist, c->d_rows, c->num_kmer, b->d_wgroup_off, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, b->d_err);
+                hipLaunchKernelGGL(k_part_scan, sg, dim3(256), 0, c->stream, c->d_phist, c->d_rows, c->num_kmer, kmer_pad, b->d_wgroup_off, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, b->d_err);
                 if (before) {                                     // every worker's row moves past the whole batch, all ranges
                     const dim3 ag((unsigned)((n_rows + 255) / 256));
                     hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);

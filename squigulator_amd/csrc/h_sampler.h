@@ -36,7 +36,7 @@ static int genome_load_impl(sqg_ctx_t* c, const sqg_genome_t* g, const bool on_d
     // the workers' sampler streams: ref_pos = s, rand_strand = s+1, rand_rlen = s+3 (src/sim.c:238-247)
     HIPCHK(c, hipMalloc(&c->d_samp, (size_t)c->nw * 3 * sizeof(uint32_t)));
     hipLaunchKernelGGL(k_init_sampler, dim3((unsigned)((c->nw + 255) / 256)), dim3(256), 0, c->stage_stream, c->d_samp,
-                       (long long)c->cfg.seed, c->wlo, c->nw, (int)(1u << (2 * c->k)));
+                       (long long)c->cfg.seed, c->wlo, c->nw, c->num_kmer);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stage_stream));
     GenomeParams& G = c->genome;

@@ -175,7 +175,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         const bool want = c->range_mode ? n > 0 : forced >= 0 ? (forced > 0 && multi) : (multi && n_wchains < 1024 && nev >= 65536);
         if (c->use_kmer_streams && want) {
             const size_t row_bytes = (size_t)c->num_kmer * sizeof(uint32_t);
-            const bool part_ok = k > 6 && nev < 4294967000LL && !getenv("SQG_NO_PART");     // bucketed hand-out (below): no per-link rows
+            const bool part_ok = c->num_kmer > 4096 && c->num_kmer <= PART_MAX * PART_SUB && nev < 4294967000LL && !getenv("SQG_NO_PART");   // bucketed hand-out (below): no per-link rows
             long long target = forced > 0 ? forced : part_ok ? 4096 : 2048;
             if (!part_ok) target = std::min<long long>(target, std::max<long long>(8, (long long)(((size_t)1 << 30) / row_bytes)));
             std::vector<int> link_off(1, 0);
@@ -210,8 +210,8 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     // the per-link rows of round 1, for A/B runs).
     std::vector<int> link_group, wgroup_off(1, 0);
     std::vector<uint32_t> cbase;
-    if (b->split && k > 6 && nev < 4294967000LL && !getenv("SQG_NO_PART")) {                  // (= part_ok above)
-        const int n_part = c->num_kmer >> PART_SUB_BITS;
+    if (b->split && c->num_kmer > 4096 && c->num_kmer <= PART_MAX * PART_SUB && nev < 4294967000LL && !getenv("SQG_NO_PART")) {   // (= part_ok above)
+        const int n_part = (c->num_kmer + PART_SUB - 1) >> PART_SUB_BITS;
         const char* genv = getenv("SQG_PART_GROUPS");
         const long long tg = genv ? std::max(1, atoi(genv)) : std::max(1, 4096 / n_part);
         link_group.assign((size_t)b->n_chains, 0);
@@ -237,7 +237,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         b->n_groups = g;
         b->part = true;
     }
-    if (c->use_kmer_streams && k > 6 && !b->part && (double)b->max_wchain_ev * c->dwell_hi >= 4294967295.0 - (double)LCG_ORD2) {
+    if (c->use_kmer_streams && c->num_kmer > 4096 && !b->part && (double)b->max_wchain_ev * c->dwell_hi >= 4294967295.0 - (double)LCG_ORD2) {
         delete b; c->err = "one worker's reads of a batch may draw more than 3.2e9 samples (k > 6): use smaller batches"; return SQG_EINVAL;
     }
     // (a counting sort over 4096 length classes: exact order within a class does not matter for the tail)

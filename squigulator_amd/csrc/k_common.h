@@ -99,6 +99,25 @@ __host__ __device__ static inline uint32_t base_code(uint8_t b) {
     }
 }
 
+// base -> digit of the 5-letter methylation alphabet A C G M T, src/seq.h:45-60 (upper case only; anything else -> 0)
+__host__ __device__ static inline uint32_t meth_code(uint8_t b) {
+    switch (b) {
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'M': return 3;
+    case 'T': return 4;
+    default: return 0;
+    }
+}
+
+// k-mer rank of k bases: 2 bits per base (src/seq.h:31-42), or base-5 digits for the methylation tables (src/seq.h:62-74)
+__device__ static inline uint32_t kmer_rank_of(const uint8_t* bp, int k, int meth) {
+    uint32_t rank = 0;
+    if (meth) { for (int q = 0; q < k; q++) rank = rank * 5u + meth_code(bp[q]); }
+    else { for (int q = 0; q < k; q++) rank = (rank << 2) | base_code(bp[q]); }
+    return rank;
+}
+
 // ---- descriptors ---------------------------------------------------------------------------
 struct ReadDesc {
     long long base_off;   // first byte of segment 0 in the batch's base buffer
@@ -176,6 +195,9 @@ struct SigParams {
     float delta_x;               // swept bound on |x_fast - x_exact| (incl. margin)
     float thr_all;               // 1/2 - (largest eps over all k-mers): acceptance threshold of the lean kernel
     int k, num_kmer;
+    int meth;                    // 5-letter (A C G M T) table of 5^k rows: ranks are base-5 numbers (src/seq.h:45-74, src/gensig.c:250-253)
+    uint32_t meth_top;           // 5^(k-1)
+    int num_kmer_pad;            // num_kmer rounded up to whole partitions (k_part.h)
     int const_sps;               // (int)dwell_mean, used when dwell == null
     int dwell_unbounded;         // the hard bound of a dwell draw (|z| <= 6.5556) exceeds 65535: k_events checks every draw
     int use_streams;             // 0 in --ideal / --ideal-amp (src/gensig.c:265-269)

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
     constexpr int NW = NT / 64, SEG = NT * EPT, HT = 2 * SEG, TL = 64 / EPT;   // TL: lanes per 64-event tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int i = tid; i < EV_JUMP_N; i += NT) L.jump[i] = P.pw[2 * POW_N + i];
-    for (int i = tid; i < 256; i += NT) L.lut[i] = (uint8_t)base_code((uint8_t)i);
+    for (int i = tid; i < 256; i += NT) L.lut[i] = (uint8_t)(P.meth ? meth_code((uint8_t)i) : base_code((uint8_t)i));
 
     const int chain = P.chain_order[blockIdx.x];
     const int c_lo = P.chain_off[chain], c_hi = P.chain_off[chain + 1];
@@ -487,7 +487,12 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
                 if (EV_IN(e)) {
                     const int cb = EV_BASE(e) - bseg;
                     if (q > 0 && e != rd.ne0) {
-                        rank[q] = ((rank[q - 1] << 2) | L.codes[cb + k - 1]) & kmask;          // my previous event's k-mer, shifted by one base
+                        // my previous event's k-mer, shifted by one base
+                        rank[q] = P.meth ? (rank[q - 1] % P.meth_top) * 5u + L.codes[cb + k - 1] : ((rank[q - 1] << 2) | L.codes[cb + k - 1]) & kmask;
+                    } else if (P.meth) {                              // base-5 digits, src/seq.h:62-74
+                        uint32_t rk = 0;
+                        for (int i = 0; i < k; i++) rk = rk * 5u + L.codes[cb + i];
+                        rank[q] = rk;
                     } else {
                         // src/seq.h:31-42; the usual k are unrolled so that the byte reads are in flight together
                         uint32_t rk = 0;

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* __restrict__ 
 // group finds it: seed(worker, rank) * a^(2 * samples before), the seed being (seed_base + worker*seed_step + rank) mod M
 // (src/sim.c:249) -- from there on k_part_hand advances states, one modular multiplication per event, as the 6-mer path does.
 // grid (num_kmer / 256, worker chains).
-__global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ phist, uint32_t* __restrict__ rows, const int num_kmer,
+__global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ phist, uint32_t* __restrict__ rows, const int num_kmer, const int pad,
                                                    const int* __restrict__ wgroup_off, const int* __restrict__ wlink_worker,
                                                    const uint32_t* __restrict__ before, const uint32_t* __restrict__ pw,
                                                    const uint32_t seed_base, const uint32_t seed_step, unsigned int* __restrict__ err) {
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ phist,
     if (before) run += before[wj];
     const int g0 = wgroup_off[q], g1 = wgroup_off[q + 1];
     for (int g = g0; g < g1; g++) {
-        uint32_t* cell = phist + (size_t)g * num_kmer + j;
+        uint32_t* cell = phist + (size_t)g * pad + j;             // (a group's table is whole partitions: pad >= num_kmer)
         const uint32_t cnt = *cell;
         const uint32_t n = (uint32_t)run;                         // (an overflow is reported below; the batch fails)
         *cell = n ? lcg_mul(seed, lcg_jump2(pw, n)) : seed;
@@ -113,12 +113,12 @@ __global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ phist,
 }
 
 // range sharding: samples this batch's local reads draw from each (worker, rank) stream (counts zeroed beforehand)
-__global__ __launch_bounds__(256) void k_part_totals(const uint32_t* __restrict__ phist, const int num_kmer, const int* __restrict__ wgroup_off,
+__global__ __launch_bounds__(256) void k_part_totals(const uint32_t* __restrict__ phist, const int num_kmer, const int pad, const int* __restrict__ wgroup_off,
                                                      const int* __restrict__ wlink_worker, uint32_t* __restrict__ counts) {
     const int q = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
     if (j >= num_kmer) return;
     uint32_t sum = 0;
-    for (int g = wgroup_off[q]; g < wgroup_off[q + 1]; g++) sum += phist[(size_t)g * num_kmer + j];
+    for (int g = wgroup_off[q]; g < wgroup_off[q + 1]; g++) sum += phist[(size_t)g * pad + j];
     counts[(size_t)wlink_worker[q] * num_kmer + j] = sum;
 }
 

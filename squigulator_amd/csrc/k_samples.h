@@ -555,8 +555,7 @@ __global__ __launch_bounds__(256) void k_fixup_tiles(const SigParams P, const in
         const uint4 fe = P.tfix[(size_t)gi * FIX_SLOTS + slot];
         const int e = (int)fe.z;
         const uint8_t* bp = P.bases + rd.base_off + (e < rd.ne0 ? (long long)e : (long long)rd.len0 + (e - rd.ne0));
-        uint32_t rank = 0;
-        for (int q = 0; q < P.k; q++) rank = (rank << 2) | base_code(bp[q]);
+        const uint32_t rank = kmer_rank_of(bp, P.k, P.meth);
         const float2 md = P.model[rank];
         int16_t q = sample_exact(fe.y, md.x, md.y, P.dig, P.range, rd.offset);
         if (fe.w) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);      // RNA adaptor level shift
@@ -571,8 +570,7 @@ __global__ __launch_bounds__(256) void k_fixup(const SigParams P) {
         const ReadDesc rd = P.reads[fe.read];
         const int e = (int)(fe.ev - rd.ev_off);
         const uint8_t* bp = P.bases + rd.base_off + (e < rd.ne0 ? (long long)e : (long long)rd.len0 + (e - rd.ne0));
-        uint32_t rank = 0;
-        for (int q = 0; q < P.k; q++) rank = (rank << 2) | base_code(bp[q]);
+        const uint32_t rank = kmer_rank_of(bp, P.k, P.meth);
         const float2 md = P.model[rank];
         int16_t q = sample_exact(fe.c1, md.x, md.y, P.dig, P.range, rd.offset);
         if (fe.shifted) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);

@@ -16,7 +16,7 @@ def run_hip_on_reads(cmdline, seqs, mode=api.MODE_EXACT, model_override=None, wa
         k, mean, stdv = model_override
     else:
         k = o.kmer_size_default
-        mean, stdv = model.synthetic_model(k)
+        mean, stdv = model.synthetic_model(k, meth=bool(o.meth_freq))
     gen = api.SignalGenerator(o.profile, o.flags, k, mean, stdv, o.seed, num_workers=o.threads,
                               amp_noise=o.amp_noise, mode=mode)
     global LAST_FALLBACK

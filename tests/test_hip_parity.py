@@ -56,7 +56,13 @@ def test_hip_matches_reference_vectors(cid, cmd, mode):
     "rnasequin_sequences_2.4.fa -x rna-r9-min -n 20 --seed 11 -t 20 -K 20 --prefix=yes",
     "rnasequin_sequences_2.4.fa -x rna004-prom -n 24 --seed 13 -t 8 -K 8 --prefix=yes --dwell-std 5",
     "nCoV-2019.reference.fasta -x dna-r9-min -n 6 --seed 3 -r 1000 -t1 --dwell-mean 20 --dwell-std 30",
-], ids=["r9_tk128", "r9_t5_k12", "r10_tk32", "rna9min_prefix", "rna004_prefix_dwellstd", "r9_wide_dwell"])
+    # CpG methylation: 5^6 = 15625 streams per worker -- one worker per read (rows in HBM), and -t 1 / -t 3 with enough events
+    # for the chains to be cut (bucketed hand-out over 4 partitions)
+    "nCoV-2019.reference.fasta -x dna-r9-prom -n 48 --seed 5 -r 2500 -t 24 -K 24 --meth-freq mfreq_dense.tsv",
+    "nCoV-2019.reference.fasta -x dna-r9-prom -n 70 --seed 6 -r 2500 -t 1 -K 40 --meth-freq mfreq_dense.tsv",
+    "nCoV-2019.reference.fasta -x dna-r9-prom -n 60 --seed 7 -r 2500 -t 3 -K 60 --meth-freq mfreq.tsv --prefix=yes",
+], ids=["r9_tk128", "r9_t5_k12", "r10_tk32", "rna9min_prefix", "rna004_prefix_dwellstd", "r9_wide_dwell",
+        "meth_tk24", "meth_t1", "meth_t3_prefix"])
 @pytest.mark.parametrize("mode", [api.MODE_EXACT, api.MODE_CERTIFIED], ids=["exact", "certified"])
 def test_hip_matches_oracle(cmd, mode):
     o, k, names, lengths, reads, orac = simrun.run_oracle(cmd, nthreads=8)
