@@ -233,6 +233,12 @@ int  sqg_genome_load(sqg_ctx_t *ctx, const sqg_genome_t *g);
 /* the same with g->seqs in DEVICE memory (a reference already resident in HBM -- e.g. decompressed or synthesised there --
  * is copied device to device; everything else in *g is host memory as above) */
 int  sqg_genome_load_device(sqg_ctx_t *ctx, const sqg_genome_t *g);
+/* --meth-freq (contexts created with SQG_METH), after sqg_genome_load: `freq` holds one byte per base of the loaded genome,
+ * contigs back to back -- round(255 * frequency) at the C of a CpG, 0 elsewhere, as load_meth_freq builds ref->ref_meth
+ * (src/ref.c:291-361); contig_has[i] != 0: contig i has at least one line in the frequency file (ref->ref_meth[i] != NULL:
+ * only its reads take draws from rand_meth).  sqg_batch_sample* then methylate as gen_read_dna does
+ * (methylate_dna, src/genread.c:207-241,276-278): the reads carry 'M'. */
+int  sqg_genome_set_meth(sqg_ctx_t *ctx, const uint8_t *freq, const uint8_t *contig_has);
 int  sqg_batch_sample(sqg_ctx_t *ctx, int32_t n_reads, const int32_t *worker, sqg_batch_t **out, sqg_sample_t *info);
 /* the sampled reads as gen_read returned them (after N substitution and revcomp), for the FASTA/SAM writers */
 int  sqg_fetch_reads(sqg_ctx_t *ctx, sqg_batch_t *b, char *dst /* seq_off[n_reads] bytes */);

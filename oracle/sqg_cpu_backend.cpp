@@ -238,6 +238,18 @@ static int genome_load(sqg_ctx_t* c, const sqg_genome_t* g) {
     c->core->flags = f;
     return SQG_OK;
 }
+extern "C" int sqg_genome_set_meth(sqg_ctx_t* c, const uint8_t* freq, const uint8_t* contig_has) {
+    if (!c || !c->ref || !freq || !contig_has) return SQG_EINVAL;
+    orc_ref_t* r = c->ref;
+    if (r->meth) { for (int i = 0; i < r->num_ref; i++) free(r->meth[i]); free(r->meth); }
+    r->meth = (uint8_t**)calloc((size_t)r->num_ref, sizeof(uint8_t*));
+    size_t at = 0;
+    for (int i = 0; i < r->num_ref; i++) {
+        if (contig_has[i]) { r->meth[i] = (uint8_t*)malloc((size_t)r->lengths[i] + 1); memcpy(r->meth[i], freq + at, (size_t)r->lengths[i]); }
+        at += (size_t)r->lengths[i];
+    }
+    return SQG_OK;
+}
 extern "C" int sqg_genome_load(sqg_ctx_t* c, const sqg_genome_t* g) { return genome_load(c, g); }
 extern "C" int sqg_genome_load_device(sqg_ctx_t* c, const sqg_genome_t* g) { return genome_load(c, g); }   /* (host memory here) */
 

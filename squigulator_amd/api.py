@@ -79,7 +79,8 @@ EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_d
            "sqg_batch_compress", "sqg_fetch_svb", "sqg_genome_load", "sqg_batch_sample", "sqg_fetch_reads",
            "sqg_host_alloc", "sqg_host_free", "sqg_set_range_mode", "sqg_skip_reads", "sqg_batch_sample_range",
            "sqg_batch_run_begin", "sqg_batch_run_end", "sqg_genome_load_device",
-           "sqg_blow5_open", "sqg_blow5_write", "sqg_blow5_write_batch", "sqg_blow5_close", "sqg_blow5_last_error")
+           "sqg_blow5_open", "sqg_blow5_write", "sqg_blow5_write_batch", "sqg_blow5_close", "sqg_blow5_last_error",
+           "sqg_genome_set_meth")
 
 _lib = None
 
@@ -132,6 +133,8 @@ def load_library(path: str | None = None):
     L.sqg_genome_load.argtypes = [vp, C.POINTER(CGenome)]
     L.sqg_genome_load_device.restype = C.c_int
     L.sqg_genome_load_device.argtypes = [vp, C.POINTER(CGenome)]
+    L.sqg_genome_set_meth.restype = C.c_int
+    L.sqg_genome_set_meth.argtypes = [vp, vp, vp]
     L.sqg_batch_sample.restype = C.c_int
     L.sqg_batch_sample.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(vp), C.POINTER(CSample)]
     L.sqg_fetch_reads.restype = C.c_int
@@ -371,6 +374,25 @@ class SignalGenerator:
             g.trans_csum = csum.ctypes.data_as(C.POINTER(C.c_float))
             g.trans_idx = idx.ctypes.data_as(C.POINTER(C.c_int32))
         self._chk(self.L.sqg_genome_load(self.ctx, C.byref(g)), "sqg_genome_load")
+
+    def set_meth(self, contigs, names, meth_freq_path: str):
+        """--meth-freq FILE (tab separated: contig, 0-based position of a C, frequency) for the genome loaded with
+        load_genome(contigs): the per-base frequency bytes load_meth_freq builds (src/ref.c:291-361)"""
+        idx = {n: i for i, n in enumerate(names)}
+        arrs = [np.zeros(len(c), np.uint8) for c in contigs]
+        has = np.zeros(len(contigs), np.uint8)
+        with open(meth_freq_path) as f:
+            for ln in f:
+                if ln.startswith("#"):
+                    continue
+                name, pos, fr = ln.rstrip("\n").split("\t")[:3]
+                i, p = idx[name], int(pos)
+                if contigs[i][p:p + 1] not in (b"C", b"c"):
+                    raise ValueError(f"{name}:{p} is not a C")
+                has[i] = 1
+                arrs[i][p] = int(np.floor(float(np.float32(float(fr)) * np.float32(255)) + 0.5))     # (uint8_t)roundf(freq*255), float freq
+        blob = np.concatenate(arrs) if arrs else np.zeros(1, np.uint8)
+        self._chk(self.L.sqg_genome_set_meth(self.ctx, blob.ctypes.data, has.ctypes.data), "sqg_genome_set_meth")
 
     def load_genome_device(self, d_seqs: int, contig_lens, rlen: int, mode: int = SAMPLE_DNA):
         """The same for a reference that already sits in device memory: d_seqs is the device address of the concatenated

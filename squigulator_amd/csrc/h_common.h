@@ -78,6 +78,8 @@ struct sqg_ctx {
     long long* d_contig_off = nullptr; long long* d_cum = nullptr;
     float* d_trans_csum = nullptr; int* d_trans_idx = nullptr;
     uint32_t* d_samp = nullptr;                                 // [nw][3] sampler stream states: ref_pos, rand_strand, rand_rlen
+    uint8_t* d_meth = nullptr; uint8_t* d_meth_has = nullptr;   // --meth-freq (sqg_genome_set_meth): frequency byte per base, flag per contig
+    uint32_t* d_meth_st = nullptr;                              // [nw] rand_meth stream states
     GenomeParams genome{};
     uint8_t* d_samp_scratch = nullptr; size_t samp_scratch_cap = 0;   // sqg_batch_sample: records, chain lists, attempt slots
     bool genome_loaded = false;

@@ -48,6 +48,7 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     (void)hipFree(ctx->d_svb); (void)hipFree(ctx->d_svb_size); (void)hipFree(ctx->d_svb_off);
     (void)hipFree(ctx->d_genome); (void)hipFree(ctx->d_contig_off); (void)hipFree(ctx->d_cum);
     (void)hipFree(ctx->d_trans_csum); (void)hipFree(ctx->d_trans_idx); (void)hipFree(ctx->d_samp);
+    (void)hipFree(ctx->d_meth); (void)hipFree(ctx->d_meth_has); (void)hipFree(ctx->d_meth_st);
     if (ctx->stage_stream) { (void)hipStreamSynchronize(ctx->stage_stream); (void)hipStreamDestroy(ctx->stage_stream); }
     for (auto& r : ctx->pool) { (void)hipFree(r.d_block); (void)hipHostFree(r.h_sigoff); (void)hipHostFree(r.h_meta); for (auto& e : r.ev) if (e) (void)hipEventDestroy(e); if (r.ev_staged) (void)hipEventDestroy(r.ev_staged); }
     ctx->pool.clear();

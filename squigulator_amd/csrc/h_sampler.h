@@ -44,9 +44,34 @@ static int genome_load_impl(sqg_ctx_t* c, const sqg_genome_t* g, const bool on_d
     G.trans_csum = c->d_trans_csum; G.trans_idx = c->d_trans_idx;
     G.sum = total; G.grng_b = (double)(g->rlen / 2); G.n_contigs = nc; G.n_trans = g->n_trans; G.rlen = g->rlen;
     G.flags = (int)g->mode;
+    (void)hipFree(c->d_meth); (void)hipFree(c->d_meth_has); (void)hipFree(c->d_meth_st);
+    c->d_meth = nullptr; c->d_meth_has = nullptr; c->d_meth_st = nullptr;
+    G.meth = nullptr; G.meth_has = nullptr;
     c->h_contig_off = off;
     c->full_next = 0;
     c->genome_loaded = true;
+    return SQG_OK;
+}
+
+// --meth-freq: load_meth_freq (src/ref.c:291-361) has turned the file into one byte per base; the workers' rand_meth streams
+// start at seed + 6 (src/sim.c:252-254)
+extern "C" int sqg_genome_set_meth(sqg_ctx_t* c, const uint8_t* freq, const uint8_t* contig_has) {
+    if (!c || !freq || !contig_has) return SQG_EINVAL;
+    if (!c->genome_loaded) { c->err = "sqg_genome_load has not been called"; return SQG_EINVAL; }
+    if (!(c->cfg.flags & SQG_METH)) { c->err = "sqg_genome_set_meth needs a context created with SQG_METH (5-letter pore table)"; return SQG_EINVAL; }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    (void)hipFree(c->d_meth); (void)hipFree(c->d_meth_has); (void)hipFree(c->d_meth_st);
+    c->d_meth = nullptr; c->d_meth_has = nullptr; c->d_meth_st = nullptr;
+    const size_t total = (size_t)c->genome.sum;
+    HIPCHK(c, hipMalloc(&c->d_meth, total + 16));
+    HIPCHK(c, hipMemcpy(c->d_meth, freq, total, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_meth_has, (size_t)c->genome.n_contigs));
+    HIPCHK(c, hipMemcpy(c->d_meth_has, contig_has, (size_t)c->genome.n_contigs, hipMemcpyHostToDevice));
+    std::vector<uint32_t> st((size_t)c->nw);
+    for (int w = 0; w < c->nw; w++) st[(size_t)w] = canon((long long)c->cfg.seed + (long long)(w + c->wlo) * ((long long)c->num_kmer + 10) + 6);
+    HIPCHK(c, hipMalloc(&c->d_meth_st, st.size() * sizeof(uint32_t)));
+    HIPCHK(c, hipMemcpy(c->d_meth_st, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->genome.meth = c->d_meth; c->genome.meth_has = c->d_meth_has;
     return SQG_OK;
 }
 
@@ -132,7 +157,8 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
     auto room = [&](size_t bytes) { const size_t o = top; top += (bytes + 255) & ~(size_t)255; return o; };
     const size_t o_rec = room(std::max<size_t>(1, (size_t)n) * sizeof(SampleRec)), o_co = room(chain_off.size() * sizeof(int)),
                  o_cr = room(std::max<size_t>(1, chain_reads.size()) * sizeof(int)), o_cw = room(std::max<size_t>(1, chain_worker.size()) * sizeof(int)),
-                 o_try = room(na * sizeof(SampleRec)), o_ok = room(na), o_ao = room((att_off.size() + (size_t)n_chains) * sizeof(long long));
+                 o_try = room(na * sizeof(SampleRec)), o_ok = room(na), o_ao = room((att_off.size() + (size_t)n_chains) * sizeof(long long)),
+                 o_mc = room(std::max<size_t>(1, (size_t)n) * sizeof(int)), o_ms = room(std::max<size_t>(1, (size_t)n) * sizeof(uint32_t));
     if (top > c->samp_scratch_cap) {
         (void)hipStreamSynchronize(c->stage_stream);
         (void)hipFree(c->d_samp_scratch); c->d_samp_scratch = nullptr; c->samp_scratch_cap = 0;
@@ -143,6 +169,9 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
     SampleRec* d_rec = (SampleRec*)(sb + o_rec);
     int *d_co = (int*)(sb + o_co), *d_cr = (int*)(sb + o_cr), *d_cw = (int*)(sb + o_cw);
     SampleRec* d_try = (SampleRec*)(sb + o_try); unsigned char* d_ok = sb + o_ok; long long* d_ao = (long long*)(sb + o_ao);
+    int* d_mcnt = (int*)(sb + o_mc); uint32_t* d_mstate = (uint32_t*)(sb + o_ms);
+    // CpG methylation (methylate_dna, src/genread.c:207-241) is part of gen_read_dna only
+    const bool do_meth = c->d_meth && n > 0 && !(c->genome.flags & (SQG_SAMPLE_RNA | SQG_SAMPLE_CDNA | SQG_SAMPLE_FULL));
     std::vector<SampleRec> rec((size_t)n);
     int rc = SQG_OK;
     // a failed call must leave the context where it was: the workers' streams -- sampler streams on the device, scalar streams
@@ -150,14 +179,16 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
     const std::vector<uint32_t> snap_time = c->time_c;
     const std::vector<long long> snap_off = c->off_x, snap_med = c->med_x;
     const long long snap_full = c->full_next;
-    std::vector<uint32_t> snap_samp((size_t)c->nw * 3);
+    std::vector<uint32_t> snap_samp((size_t)c->nw * 3), snap_meth(c->d_meth_st ? (size_t)c->nw : 0);
     if (hipMemcpy(snap_samp.data(), c->d_samp, snap_samp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { c->err = "sampler streams unreadable"; return SQG_EDEVICE; }
+    if (!snap_meth.empty() && hipMemcpy(snap_meth.data(), c->d_meth_st, snap_meth.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { c->err = "sampler streams unreadable"; return SQG_EDEVICE; }
     bool failed = true;                                           // cleared on the way out of a successful call
     auto cleanup = [&]() {
         if (!failed) return;
         c->time_c = snap_time; c->off_x = snap_off; c->med_x = snap_med; c->full_next = snap_full;
         (void)hipStreamSynchronize(c->stage_stream);
         (void)hipMemcpy(c->d_samp, snap_samp.data(), snap_samp.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (!snap_meth.empty()) (void)hipMemcpy(c->d_meth_st, snap_meth.data(), snap_meth.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     };
 #define CHKS(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE; } } while (0)
     if (n > 0) {
@@ -192,6 +223,11 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
                                n_chains, d_rec, c->d_err);
             CHKS(hipGetLastError());
         }
+        if (do_meth) {                                         // every read of the batch, staged here or not: the stream is the worker's
+            hipLaunchKernelGGL(k_meth_count, dim3((unsigned)n), dim3(256), 0, c->stage_stream, c->genome, d_rec, n, d_mcnt);
+            hipLaunchKernelGGL(k_meth_scan, dim3((unsigned)n_chains), dim3(256), 0, c->stage_stream, d_co, d_cr, d_cw, d_mcnt, c->d_meth_st, d_mstate);
+            CHKS(hipGetLastError());
+        }
         CHKS(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(SampleRec), hipMemcpyDeviceToHost, c->stage_stream));
         CHKS(hipStreamSynchronize(c->stage_stream));
         if (!att_used.empty()) {
@@ -217,7 +253,7 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
         for (int i = 0; i < n; i++) wk_glob[(size_t)i] = wk[(size_t)i] + c->wlo;
         for (int i = 0; i < lo; i++) skip_read(c, wk[(size_t)i], read_events(c, rec[(size_t)i].rlen));
     }
-    rc = stage_common(c, m, nullptr, seq_off.data(), m != n ? wk_glob.data() + lo : worker, d_rec + lo, out);
+    rc = stage_common(c, m, nullptr, seq_off.data(), m != n ? wk_glob.data() + lo : worker, d_rec + lo, out, do_meth ? d_mstate + lo : nullptr);
     if (rc == SQG_OK && m != n)
         for (int i = hi; i < n; i++) skip_read(c, wk[(size_t)i], read_events(c, rec[(size_t)i].rlen));
     failed = rc != SQG_OK;

@@ -69,7 +69,7 @@ static int grow_slot(sqg_ctx* c, sqg_ctx::Slot& Z, const sqg_batch* b, bool with
 // sampled on the device: seqs == null, d_rec holds one SampleRec per read and k_copy_reads fills the base buffer).
 #include <chrono>
 static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t* seq_off,
-                        const int32_t* worker, const SampleRec* d_rec, sqg_batch_t** out) {
+                        const int32_t* worker, const SampleRec* d_rec, sqg_batch_t** out, const uint32_t* d_mstate = nullptr) {
     *out = nullptr;
     static const bool st_on = getenv("SQG_STAGE_TIMING") != nullptr;
     auto st_t0 = std::chrono::steady_clock::now();
@@ -384,7 +384,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     else CHKB(hipMemsetAsync(b->d_bases + nb, 'A', 16, c->stage_stream));
     if (!seqs && n) {                                      // the reads come from the resident genome
         hipLaunchKernelGGL(k_copy_reads, dim3((unsigned)n), dim3(256), 0, c->stage_stream, c->genome, d_rec, b->d_reads, b->d_bases, n,
-                           rna ? 1 : 0, prefix ? 1 : 0);
+                           rna ? 1 : 0, prefix ? 1 : 0, d_mstate);
         CHKB(hipGetLastError());
         // reads shorter than k (only --full-contigs can produce them here): the reference generates 5 events of a fixed
         // sequence instead (src/gensig.c:242-245)

@@ -16,6 +16,8 @@ struct GenomeParams {
     long long sum;               // ref->sum
     double grng_b;               // (double)(rlen / 2)
     int n_contigs, n_trans, rlen, flags;
+    const uint8_t* meth;         // --meth-freq (sqg_genome_set_meth): round(255*freq) per base, laid out like seq; or null
+    const uint8_t* meth_has;     // [n_contigs] the contig has an array at all (ref->ref_meth[i] != NULL, src/genread.c:208)
 };
 
 struct SampleRec {               // what gen_read returns, per read
@@ -210,6 +212,62 @@ __global__ __launch_bounds__(256) void k_sample_pick(const GenomeParams G, uint3
     if (lane == 0) { st[3 * w] = c_pos; st[3 * w + 1] = c_strand; st[3 * w + 2] = c_len; att_used[ch] = used; }
 }
 
+// ---- CpG methylation of the sampled reads (methylate_dna, src/genread.c:207-241) ------------------------------------
+// Every CpG of a read's span on the forward reference (both bases upper case and inside the read) takes ONE draw from the
+// worker's rand_meth stream, whatever the outcome, in position order; reads of a worker in read order.  So a read's first
+// draw is addressed by the CpGs of the worker's earlier reads: count (k_meth_count), scan per worker chain (k_meth_scan),
+// then k_copy_reads takes the j-th CpG's draw as state * a^(j+1).
+__device__ static inline bool meth_is_cpg(const uint8_t* __restrict__ src, int i, int n, int ref_pos, int ref_len) {
+    return i + 1 < n && ref_pos + i + 1 < ref_len && src[i] == 'C' && src[i + 1] == 'G';
+}
+
+// one workgroup per read of the batch: CpGs that draw
+__global__ __launch_bounds__(256) void k_meth_count(const GenomeParams G, const SampleRec* __restrict__ recs, int n_reads, int* __restrict__ cnt) {
+    __shared__ int wsum[4];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    if (r >= n_reads) return;
+    const SampleRec rec = recs[r];
+    int c = 0;
+    if (G.meth_has[rec.ref_idx]) {
+        const uint8_t* src = G.seq + rec.src;
+        for (int i = tid; i < rec.rlen; i += 256) c += meth_is_cpg(src, i, rec.rlen, rec.ref_pos, rec.ref_len) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((tid & 63) == 0) wsum[tid >> 6] = c;
+    __syncthreads();
+    if (tid == 0) cnt[r] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// one workgroup per worker chain: mstate[read] = the worker's rand_meth state before the read's first draw; the worker's
+// stream moves past the chain
+__global__ __launch_bounds__(256) void k_meth_scan(const int* __restrict__ chain_off, const int* __restrict__ chain_reads,
+                                                   const int* __restrict__ chain_worker, const int* __restrict__ cnt,
+                                                   uint32_t* __restrict__ st, uint32_t* __restrict__ mstate) {
+    __shared__ long long wsum[4];
+    __shared__ long long base_sh;
+    const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lo = chain_off[ch], hi = chain_off[ch + 1];
+    const int w = chain_worker[ch];
+    const uint32_t s0 = st[w];
+    if (tid == 0) base_sh = 0;
+    __syncthreads();
+    for (int i0 = lo; i0 < hi; i0 += 256) {
+        const int i = i0 + tid;
+        const long long v = i < hi ? (long long)cnt[chain_reads[i]] : 0;
+        long long x = v;
+        for (int o = 1; o < 64; o <<= 1) { const long long y = __shfl_up(x, o); if (lane >= o) x += y; }
+        if (lane == 63) wsum[wid] = x;
+        __syncthreads();
+        long long before = base_sh, total = 0;
+        for (int q = 0; q < 4; q++) { if (q < wid) before += wsum[q]; total += wsum[q]; }
+        if (i < hi) mstate[chain_reads[i]] = lcg_mul(s0, lcg_pow_a((unsigned long long)(before + x - v)));
+        __syncthreads();
+        if (tid == 0) base_sh += total;
+        __syncthreads();
+    }
+    if (tid == 0) st[w] = lcg_mul(s0, lcg_pow_a((unsigned long long)base_sh));
+}
+
 __device__ static const char kd_stall_dna[] = "TTTTTTTTTTTTTTTTTTAATCAA";                       // src/genread.c:110
 __device__ static const char kd_adaptor_dna[] = "GGCGTCTGCTTGGGTGTTTAACCTTTTTTTTTTAATGTACTTCGTTCAGTTACGTATTGCT";  // src/genread.c:38
 __device__ static const char kd_adaptor_rna[] = "TGATGATGAGGGATAGACGATGGTTGTTTCTGTTGGTGCTGATATTGCTTTTTTTTTTTTTATGATGCAAGATACGCAC";  // src/genread.c:39
@@ -218,8 +276,10 @@ __device__ static const char kd_stall_rna[] = "AAAAAGAAAAAACCCCCCCCCCCCCCCCCC"; 
 // one workgroup per read: the sampled slice of the genome -> the batch's base buffer, exactly as gen_read returns
 // it ('N' -> a base from a FRESH state-100 stream per read, src/genread.c:132-138; '-' -> revcomp, src/seq.h:78-112)
 // with the prefix / stall attached as src/genread.c:95-123 does.  read_at: where the read starts in segment 0.
+// mstate (optional): per read the worker's rand_meth state before the read's first CpG draw -> methylated Cs become 'M'
 __global__ __launch_bounds__(256) void k_copy_reads(const GenomeParams G, const SampleRec* __restrict__ recs, const ReadDesc* __restrict__ reads,
-                                                    uint8_t* __restrict__ bases, int n_reads, int rna, int prefix) {
+                                                    uint8_t* __restrict__ bases, int n_reads, int rna, int prefix,
+                                                    const uint32_t* __restrict__ mstate) {
     __shared__ int wcnt[4];
     __shared__ int carry;
     const int r = blockIdx.x;
@@ -279,6 +339,32 @@ __global__ __launch_bounds__(256) void k_copy_reads(const GenomeParams G, const 
                 }
                 dst[read_at + n - 1 - i] = o;
             } else dst[read_at + i] = c;
+        }
+    }
+    if (mstate && G.meth && G.meth_has[rec.ref_idx]) {               // methylate_dna, src/genread.c:207-241
+        __syncthreads();                                              // the read is in place (same workgroup wrote it)
+        const uint32_t ms = mstate[r];
+        const uint8_t* mf = G.meth + rec.src;
+        if (tid == 0) carry = 0;
+        __syncthreads();
+        for (int i0 = 0; i0 < n; i0 += 256) {
+            const int i = i0 + tid;
+            const bool cg = i < n && meth_is_cpg(src, i, n, rec.ref_pos, rec.ref_len);
+            const unsigned long long m = __ballot(cg);
+            if (lane == 0) wcnt[wid] = __popcll(m);
+            __syncthreads();
+            int before = carry;
+            for (int w2 = 0; w2 < wid; w2++) before += wcnt[w2];
+            const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            if (cg) {
+                const int j = before + __popcll(m & ((1ull << lane) - 1));     // the read's j-th CpG takes draw j+1
+                const uint32_t cst = lcg_mul(ms, lcg_pow_a((unsigned long long)j + 1));
+                const int methr = (int)(lcg_uniform(cst) * 254);
+                if (methr <= (int)mf[i]) dst[read_at + (rev ? n - i - 2 : i)] = 'M';
+            }
+            __syncthreads();
+            if (tid == 0) carry += tot;
+            __syncthreads();
         }
     }
 }

@@ -21,17 +21,21 @@ def _contigs(ref):
     return [bytes(ref.seqs[i][:ref.lengths[i]]) for i in range(ref.num_ref)]
 
 
-def _run(profile, k, fasta, T, batches, rlen, oflags=0, sflags=0, mode=api.SAMPLE_DNA, trans_count=None, seed=42):
+def _run(profile, k, fasta, T, batches, rlen, oflags=0, sflags=0, mode=api.SAMPLE_DNA, trans_count=None, seed=42, meth_freq=None):
     prof, fl = profiles.get_profile(profile)
-    mean, stdv = model.synthetic_model(k)
+    if meth_freq:
+        sflags |= profiles.SQ_METH
+    mean, stdv = model.synthetic_model(k, meth=bool(meth_freq))
     orac = orc.Oracle(prof, fl | oflags | sflags, k, mean, stdv, seed, num_workers=T, rlen=rlen)
-    ref = orac.load_ref(fasta, trans_count)
+    ref = orac.load_ref(fasta, trans_count, meth_freq)
     trans = None
     if trans_count:
         trans = (np.ctypeslib.as_array(ref.trans_csum, shape=(ref.trans_n,)).copy(),
                  np.ctypeslib.as_array(ref.trans_idx, shape=(ref.trans_n,)).copy())
     gen = api.SignalGenerator(prof, fl | sflags, k, mean, stdv, seed, num_workers=T, mode=api.MODE_CERTIFIED)
     gen.load_genome(_contigs(ref), rlen, mode, trans)
+    if meth_freq:
+        gen.set_meth(_contigs(ref), [ref.names[i].decode() for i in range(ref.num_ref)], meth_freq)
     total = 0
     for nb in batches:
         want = orac.run_batch(nb)
@@ -232,3 +236,29 @@ def test_sampler_and_compress_error_paths():
     for b in bs:
         b.free()
     gen.close()
+
+
+MFREQ = os.path.join(INPUTS, "mfreq.tsv")
+MFREQ_DENSE = os.path.join(INPUTS, "mfreq_dense.tsv")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,batches,rlen,mf", [(1, [6, 5], 4000, MFREQ), (1, [40, 30], 1500, MFREQ_DENSE), (8, [8, 8, 8], 2500, MFREQ_DENSE),
+                                              (3, [20, 33], 1200, MFREQ_DENSE)], ids=["t1_ref_file", "t1_long_chain", "tk8", "t3"])
+def test_cpg_methylation_in_the_device_sampler(T, batches, rlen, mf):
+    """--meth-freq: every CpG of a read's reference span draws from the worker's rand_meth stream in order; methylated Cs
+    become 'M' (also on the '-' strand), the signal comes from the 5-letter table (src/genread.c:207-241, src/seq.h:45-74)"""
+    _run("dna-r9-prom", 6, NCOV, T, batches, rlen=rlen, meth_freq=mf)
+
+
+@pytest.mark.gpu
+def test_methylation_only_draws_for_contigs_with_a_frequency_array(tmp_path):
+    """two contigs, frequencies for one of them only: reads of the other take no rand_meth draws (src/genread.c:208)"""
+    rng = np.random.default_rng(4)
+    contigs = [bytes(rng.choice(list(b"ACGT"), n).astype(np.uint8)) for n in (9000, 7000)]
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(f">c{i}\n{c.decode()}\n" for i, c in enumerate(contigs)))
+    cpg = [i for i in range(len(contigs[1]) - 1) if contigs[1][i:i + 2] == b"CG"]
+    mf = tmp_path / "m.tsv"
+    mf.write_text("".join(f"c1\t{p}\t{(j % 11) / 10:.1f}\n" for j, p in enumerate(cpg[::2])))
+    _run("dna-r9-prom", 6, str(fa), 2, [10, 10, 7], rlen=1200, seed=9, meth_freq=str(mf))
