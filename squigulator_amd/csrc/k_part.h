@@ -131,12 +131,17 @@ __global__ __launch_bounds__(256) void k_part_totals(const uint32_t* __restrict_
 // stream's tag and reads it back; the events that do not find themselves write "contended" over the tag; an event that still
 // finds itself after that is alone on its stream in this phase: it takes the stream's state and advances it by its dwell
 // (a^(2 * dwell) from LDS).  The events of contended streams (6 % of them: 256 events over 4096 streams) queue on a small
-// hashed tag array with an atomic min of their position, so that the earliest wins the round, until none is left.
+// hashed tag array with an atomic min of their position, so that the earliest wins the round; what is still waiting after two
+// such rounds belongs to streams with many events in the phase (poly-A tails, adaptors): those are taken a stream at a time,
+// the dwells of the stream's events scanned in order.
 // LDS operations of one wavefront execute in program order, which is all the ordering the protocol needs.
 // BIGD: dwells of PART_JT samples and more exist (their multiplier comes from the global jump tables)
 #define PART_ATAGS 256
 #define PART_JT 256
 #define PART_STEP 1024
+#ifndef PART_ATOMIC_ROUNDS
+#define PART_ATOMIC_ROUNDS 2     // rounds of the earliest-wins protocol before the contended streams are taken one stream at a time
+#endif
 #define PART_SLACK (2 * PART_STEP)   // entries behind the bucketed events: read ahead by the last step of a slice, and the dump of idle lanes' stores
 template <bool BIGD>
 __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out,
@@ -163,13 +168,14 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
         uint32_t out[NR];
 #pragma unroll
         for (int ph = 0; ph < NR / 4; ph++) {
-            uint32_t sub[4], mul[4], st[4];
+            uint32_t sub[4], mul[4], st[4], dw[4];
             uint16_t pri[4];
             bool pend[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t rec = cur[4 * ph + q], d = rec >> 16;
                 sub[q] = rec & (PART_SUB - 1);
+                dw[q] = d;
                 pri[q] = (uint16_t)(64 * q + lane);
                 pend[q] = b + 256 * ph + 64 * q + lane < hi;
                 mul[q] = jt[d & (PART_JT - 1)];
@@ -194,24 +200,52 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
                     pend[q] = false;
                 }
             }
+            int round = 0;
             while (__builtin_amdgcn_ballot_w64(pend[0] | pend[1] | pend[2] | pend[3])) {     // contended streams, in order
+                if (round++ < PART_ATOMIC_ROUNDS) {                  // two events on a stream (the usual case): the earliest wins a round
 #pragma unroll
-                for (int q = 0; q < 4; q++) if (pend[q]) atomicMin(&atg[sub[q] & (PART_ATAGS - 1)], (uint32_t)pri[q]);
-                uint32_t ta[4], s0[4];
+                    for (int q = 0; q < 4; q++) if (pend[q]) atomicMin(&atg[sub[q] & (PART_ATAGS - 1)], (uint32_t)pri[q]);
+                    uint32_t ta[4], s0[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    ta[q] = __hip_atomic_load(&atg[sub[q] & (PART_ATAGS - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    s0[q] = __hip_atomic_load(&row[sub[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    for (int q = 0; q < 4; q++) {
+                        ta[q] = __hip_atomic_load(&atg[sub[q] & (PART_ATAGS - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        s0[q] = __hip_atomic_load(&row[sub[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        if (pend[q] && ta[q] == (uint32_t)pri[q]) {
+                            __hip_atomic_store(&row[sub[q]], lcg_mul(s0[q], mul[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            __hip_atomic_store(&atg[sub[q] & (PART_ATAGS - 1)], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                            st[q] = s0[q];
+                            pend[q] = false;
+                        }
+                    }
+                    continue;
                 }
+                // a stream with many events in the phase (homopolymers, an adaptor every read carries): the whole stream in one
+                // round -- its events' dwells are scanned in order, event i starts a^(2 * samples before it) in
+                uint32_t key = 0xffffffffu;
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (pend[q]) key = min(key, (uint32_t)pri[q]);
+                for (int o = 32; o > 0; o >>= 1) key = min(key, (uint32_t)__shfl_xor((int)key, o));
+                const int ql = (int)(key >> 6), ll = (int)(key & 63u);
+                const uint32_t sub_sel = ql == 0 ? sub[0] : ql == 1 ? sub[1] : ql == 2 ? sub[2] : sub[3];
+                const uint32_t sstar = (uint32_t)__shfl((int)sub_sel, ll);
+                const uint32_t sv = __hip_atomic_load(&row[sstar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                uint32_t run = 0;                                    // samples of the stream's earlier events of the phase
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    if (pend[q] && ta[q] == (uint32_t)pri[q]) {
-                        __hip_atomic_store(&row[sub[q]], lcg_mul(s0[q], mul[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        __hip_atomic_store(&atg[sub[q] & (PART_ATAGS - 1)], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        st[q] = s0[q];
+                    const bool mem = pend[q] && sub[q] == sstar;
+                    const int dq = mem ? (int)dw[q] : 0;
+                    const int incl = wave_incl_scan_dpp(dq);
+                    const uint32_t before = run + (uint32_t)(incl - dq);
+                    if (mem) {
+                        st[q] = before ? lcg_mul(sv, before < PART_JT ? jt[before] : lcg_jump2(pw, before)) : sv;
                         pend[q] = false;
                     }
+                    run += (uint32_t)__shfl(incl, 63);
                 }
+                if (lane == 0) __hip_atomic_store(&row[sstar], lcg_mul(sv, run < PART_JT ? jt[run] : lcg_jump2(pw, run)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) out[4 * ph + q] = st[q];

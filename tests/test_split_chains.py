@@ -114,3 +114,24 @@ def test_very_ragged_batches(T):
     _check(prof, fl, 6, T, 11, batches, modes=(api.MODE_CERTIFIED,))
     prof, fl = profiles.get_profile("dna-r10-prom")
     _check(prof, fl, 9, T, 11, batches[:1], modes=(api.MODE_CERTIFIED,))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T", [("dna-r10-prom", 1), ("rna004-prom", 1), ("rna004-prom", 3)])
+def test_streams_with_many_events_in_a_row(name, T):
+    """homopolymers and a sequence every read carries (poly-A tail + adaptor with --prefix=yes): hundreds of consecutive events
+    of a batch fall on ONE k-mer stream -- the bucketed hand-out takes such a stream as a whole (k_part_hand)"""
+    rng = np.random.default_rng(123)
+    prof, fl = profiles.get_profile(name)
+    if fl & profiles.SQ_RNA:
+        fl |= profiles.SQ_PREFIX
+    common = bytes(rng.choice(list(b"ACGT"), 90).astype(np.uint8))
+    batches = []
+    for _ in range(2):
+        reads = []
+        for i in range(150):
+            body = bytes(rng.choice(list(b"ACGT"), int(rng.integers(100, 700))).astype(np.uint8))
+            reads.append(b"A" * int(rng.integers(50, 400)) + body + common + b"T" * int(rng.integers(0, 300)) + b"AC" * int(rng.integers(0, 60)))
+        batches.append(reads)
+    assert sum(len(r) for r in batches[0]) > 70000
+    _check(prof, fl, 9, T, 77, batches, modes=(api.MODE_CERTIFIED,))
