@@ -139,6 +139,11 @@ __global__ __launch_bounds__(256) void k_part_totals(const uint32_t* __restrict_
 #define PART_ATAGS 256
 #define PART_JT 256
 #define PART_STEP 1024
+#ifndef PART_ROW_CLAIMS
+#define PART_ROW_CLAIMS 1        // the first-try claims are written into the sub-row itself (no tag array: 18 instead of 26 KiB per wavefront)
+#endif
+#define PART_CLAIM 0x80000000u
+#define PART_CONTENDED 0xc0000000u
 #ifndef PART_ATOMIC_ROUNDS
 #define PART_ATOMIC_ROUNDS 2     // rounds of the earliest-wins protocol before the contended streams are taken one stream at a time
 #endif
@@ -147,8 +152,10 @@ template <bool BIGD>
 __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out,
                                                   const uint32_t* __restrict__ slice_lo, const uint32_t* __restrict__ slice_hi,
                                                   const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pw, const uint32_t dump) {
-    __shared__ uint32_t row[PART_SUB];
+    __shared__ uint32_t row[PART_SUB];                            // stream states (< 2^31); during a phase also claims: PART_CLAIM | position
+#if !PART_ROW_CLAIMS
     __shared__ uint16_t tg[PART_SUB];                             // position in the phase of the (last) event that took the tag; 0x100: contended
+#endif
     __shared__ uint32_t atg[PART_ATAGS];
     __shared__ uint32_t jt[PART_JT];                              // a^(2j)
     constexpr int NR = PART_STEP / 64;                            // records per lane and step
@@ -181,6 +188,28 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
                 mul[q] = jt[d & (PART_JT - 1)];
                 if (BIGD && d >= PART_JT) mul[q] = lcg_jump2(pw, d);
             }
+#if PART_ROW_CLAIMS
+            // the claims live in the sub-row itself (a state never has bit 31): every event reads its stream's state, THEN writes
+            // its claim over it; whoever still finds its own claim after the others marked theirs "contended" is alone
+#pragma unroll
+            for (int q = 0; q < 4; q++) st[q] = __hip_atomic_load(&row[sub[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (pend[q]) __hip_atomic_store(&row[sub[q]], PART_CLAIM | pri[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            uint32_t tc[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) tc[q] = __hip_atomic_load(&row[sub[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (pend[q] && tc[q] != (PART_CLAIM | pri[q])) __hip_atomic_store(&row[sub[q]], PART_CONTENDED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+            for (int q = 0; q < 4; q++) tc[q] = __hip_atomic_load(&row[sub[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (pend[q] && tc[q] == (PART_CLAIM | pri[q])) {     // alone on the stream in this phase
+                    __hip_atomic_store(&row[sub[q]], lcg_mul(st[q], mul[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    pend[q] = false;
+                }
+            }
+#else
 #pragma unroll
             for (int q = 0; q < 4; q++) if (pend[q]) __hip_atomic_store(&tg[sub[q]], pri[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             uint16_t t[4];
@@ -200,6 +229,7 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
                     pend[q] = false;
                 }
             }
+#endif
             int round = 0;
             while (__builtin_amdgcn_ballot_w64(pend[0] | pend[1] | pend[2] | pend[3])) {     // contended streams, in order
                 if (round++ < PART_ATOMIC_ROUNDS) {                  // two events on a stream (the usual case): the earliest wins a round
@@ -214,6 +244,9 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         if (pend[q] && ta[q] == (uint32_t)pri[q]) {
+#if PART_ROW_CLAIMS
+                            if (s0[q] & PART_CLAIM) s0[q] = st[q];  // the stream's first event of the phase: the row still holds a claim, the state is the one read before
+#endif
                             __hip_atomic_store(&row[sub[q]], lcg_mul(s0[q], mul[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             __hip_atomic_store(&atg[sub[q] & (PART_ATAGS - 1)], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             st[q] = s0[q];
@@ -231,7 +264,14 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
                 const int ql = (int)(key >> 6), ll = (int)(key & 63u);
                 const uint32_t sub_sel = ql == 0 ? sub[0] : ql == 1 ? sub[1] : ql == 2 ? sub[2] : sub[3];
                 const uint32_t sstar = (uint32_t)__shfl((int)sub_sel, ll);
-                const uint32_t sv = __hip_atomic_load(&row[sstar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                uint32_t sv = __hip_atomic_load(&row[sstar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#if PART_ROW_CLAIMS
+                {   // (the row may still hold a claim: the state is then the one the stream's events read before claiming)
+                    const uint32_t st_sel = ql == 0 ? st[0] : ql == 1 ? st[1] : ql == 2 ? st[2] : st[3];
+                    const uint32_t s_lead = (uint32_t)__shfl((int)st_sel, ll);
+                    if (sv & PART_CLAIM) sv = s_lead;
+                }
+#endif
                 uint32_t run = 0;                                    // samples of the stream's earlier events of the phase
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
