@@ -32,6 +32,15 @@ __device__ static inline uint32_t lcg_mul_lazy(uint32_t a, uint32_t b) {
     return (uint32_t)(p & LCG_M) + (uint32_t)(p >> 31);
 }
 
+// the same product with the multiplier handed over DOUBLED (b2 = 2*b < 2^32): the halves of the 64-bit product then are
+// p >> 31 and 2*(p & M) themselves -- no funnel shift, no mask -- and their sum r = (p >> 31) + (p & M) < 2M is reduced by one
+// conditional subtraction, min(r, r - M) in unsigned arithmetic.  5 VALU instead of 7; the sample loop's form.
+__device__ static inline uint32_t lcg_mul_dbl(uint32_t a, uint32_t b2) {
+    const unsigned long long p2 = (unsigned long long)a * b2;
+    const uint32_t r = (uint32_t)(p2 >> 32) + ((uint32_t)p2 >> 1);
+    return min(r, r - LCG_M);
+}
+
 // a^(2n) for any 32-bit n from three table levels
 __device__ static inline uint32_t lcg_jump2(const uint32_t* __restrict__ pw, uint32_t n) {
     uint32_t r = pw[2 * POW_N + (n & (POW_N - 1))];
@@ -58,7 +67,9 @@ __device__ static inline double box_muller_exact(uint32_t c1, uint32_t c2) {
 // resolution; the sweep (k_certify) prices it with everything else.
 __device__ static inline float box_muller_fast(uint32_t c1) {
     const float uf = (float)c1 * 4.656612873077393e-10f;                  // c1 * 2^-31 (exact scaling)
-    const float lg = __builtin_amdgcn_logf(uf);
+    const float lg = __builtin_amdgcn_logf(uf);                           // (log2 of the UNscaled c1 would save this multiplication, but
+                                                                          // v_log_f32's error grows with |log2|: near 2^30 the swept bound
+                                                                          // becomes 10x larger and 2e-3 of the samples fall back: measured)
     const float y = __builtin_fmaf(lg, -1.3862943611198906f, -9.313225750491594e-10f);   // -2 ln(c1/M)
     const float r = __builtin_amdgcn_sqrtf(y);
     // second uniform c2/M = frac(a*c1/M): four full-rate FP64/convert instructions instead of a modular
@@ -214,7 +225,9 @@ struct SigParams {
     int n_part;                  // partitions = num_kmer >> PART_SUB_BITS
 };
 
-#define PART_SUB_BITS 12         // a partition's sub-row: 4096 streams, 16 KiB of LDS (the size of a whole 6-mer row)
+#define PART_SUB_BITS 12         // a partition's sub-row: 4096 streams, 16 KiB of LDS (the size of a whole 6-mer row).  (2048-stream
+                                 // partitions were measured: k_part_hand runs 16 wavefronts per CU instead of 8, but the scatter's runs
+                                 // shrink to 16 B and the sample kernels' state gather spreads: no gain on the whole step)
 #define PART_SUB (1 << PART_SUB_BITS)
-#define PART_MAX 64              // partitions of a 9-mer table
+#define PART_MAX 64              // partitions of a 9-mer table: one per lane of a wavefront (k_events<PART> relies on it)
 

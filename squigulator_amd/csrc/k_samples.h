@@ -117,7 +117,7 @@ struct LeanWaveLds {
 };
 template <int EPL>
 struct LeanLds {
-    uint32_t mult[MULT_N];              // a^(2j+1): the first draw of an event's sample j is state * mult[j]
+    uint32_t mult[MULT_N];              // 2 * a^(2j+1): the first draw of an event's sample j is lcg_mul_dbl(state, mult[j])
     LeanWaveLds<EPL> w[4];
 };
 
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
     __shared__ LeanLds<LEAN_EPL> L;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < MULT_N; i += 256) L.mult[i] = P.pw[i];
+    for (int i = tid; i < MULT_N; i += 256) L.mult[i] = P.pw[i] << 1;        // doubled: lcg_mul_dbl
     __syncthreads();
     LeanWaveLds<LEAN_EPL>& W = L.w[wid];
     const float thr = P.thr_all;
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
 #if defined(SQG_ABL_NOARITH)
         #define LEAN_ARITH(RA, MU) const uint32_t c1 = (RA.x ^ MU) & 0x3fffffffu; const float x = __uint_as_float((RA.x + MU) & 0x3fffffffu);
 #else
-        #define LEAN_ARITH(RA, MU) const uint32_t c1 = lcg_mul(RA.x, MU); const float x = box_muller_fast(c1);
+        #define LEAN_ARITH(RA, MU) const uint32_t c1 = lcg_mul_dbl(RA.x, MU); const float x = box_muller_fast(c1);
 #endif
         uint4 ra, rb, tqa, tqb; uint32_t ma, mb; int eva, evb;
         const uint4* tbp = W.tb;                                        // table entry of the current pair's first step
