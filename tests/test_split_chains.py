@@ -135,3 +135,18 @@ def test_streams_with_many_events_in_a_row(name, T):
         batches.append(reads)
     assert sum(len(r) for r in batches[0]) > 70000
     _check(prof, fl, 9, T, 77, batches, modes=(api.MODE_CERTIFIED,))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dna-r10-prom", "rna004-prom"])
+@pytest.mark.parametrize("extra", [0, profiles.SQ_IDEAL_TIME, profiles.SQ_PREFIX, profiles.SQ_PREFIX | profiles.SQ_IDEAL_TIME],
+                         ids=["plain", "ideal_time", "prefix", "prefix_ideal_time"])
+@pytest.mark.parametrize("T", [1, 2])
+def test_bucketed_hand_out_with_every_option(name, extra, T):
+    """9-mer tables, chains cut by the default heuristic: constant dwell (--ideal-time), DNA/RNA prefixes (two segments per read),
+    both arithmetic modes, two batches"""
+    rng = np.random.default_rng(2024 + T)
+    prof, fl = profiles.get_profile(name)
+    batches = [_reads(rng, 170, 9, 3500) for _ in range(2)]
+    assert sum(max(len(r) - 8, 5) for r in batches[0]) > 66000
+    _check(prof, fl | extra, 9, T, 31, batches)
