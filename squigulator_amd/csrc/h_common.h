@@ -49,8 +49,8 @@ struct sqg_ctx {
     // k > 6, split chains (k_part.h), buffers of the running batch
     uint32_t* d_part = nullptr; size_t part_cap = 0;             // [n_events] bucketed events
     uint32_t* d_pcnt = nullptr; size_t pcnt_cap = 0;             // [n_links][n_part]
-    uint32_t* d_slice = nullptr; size_t slice_cap = 0;           // [2][n_groups][n_part] slice bounds
-    uint32_t* d_phist = nullptr; size_t phist_cap = 0;           // [n_groups][4^k]
+    uint32_t* d_slice = nullptr; size_t slice_cap = 0;           // {slice_lo, slice_hi}[max_slices], pfirst[n_pairs + 1], pstart, ptotal [n_pairs] (k_part.h)
+    uint32_t* d_phist = nullptr; size_t phist_cap = 0;           // [max_slices][PART_SUB]
     double row_bound = 0;                          // k > 6: upper bound of any sample count held in d_rows
     bool range_mode = false;                       // range sharding (sqg_set_range_mode): every batch is cut into links and run in two phases
     uint32_t* d_xcounts = nullptr; size_t xcounts_cap = 0;       // [nw][num_kmer] samples the running batch draws per stream (sqg_batch_run_begin)
@@ -74,6 +74,7 @@ struct sqg_ctx {
     int lean_epl = 4;                      // events per lane of the lean kernel (work item = 64*lean_epl events)
     double dwell_hi = 1;                   // hard upper bound of a dwell draw
     bool force_fix = false;
+    bool lds_ordered = false;             // k_lds_order_check passed on this device: k_part_hand_ord hands the streams out (k_part.h)
     uint8_t* d_genome = nullptr;                                // resident reference (sqg_genome_load)
     long long* d_contig_off = nullptr; long long* d_cum = nullptr;
     float* d_trans_csum = nullptr; int* d_trans_idx = nullptr;
@@ -115,9 +116,8 @@ struct sqg_batch {
     int* d_wlink_worker = nullptr;       // [n_wchains]
     long long max_wchain_ev = 0;         // events of the longest worker chain
     bool part = false;                   // k > 6, split: the hand-out runs over bucketed events (k_part.h)
-    int n_groups = 0;                    // groups of consecutive links (k_part.h)
-    int* d_link_group = nullptr;         // [n_chains] group of each link
-    int* d_wgroup_off = nullptr;         // [n_wchains+1] groups of each worker chain
+    uint32_t slice_len = 0;              // events per slice of a (worker chain, partition) (k_part.h)
+    long long max_slices = 0;            // bound on their number (the device counts them)
     uint32_t* d_cbase = nullptr;         // [n_wchains] first slot of each worker chain's region in the bucketed event array
     int* d_tile_read = nullptr;
     int* d_stile_read = nullptr;

@@ -142,6 +142,20 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
         CHK(hipEventCreateWithFlags(&S.sampled, hipEventDisableTiming));
         CHK(hipEventRecord(S.done, c->stream2));
     }
+    if (c->use_kmer_streams && c->num_kmer > 4096 && !getenv("SQG_PART_CLAIMS")) {
+        // the bucketed hand-out of k > 6 by ordered LDS atomics: measured on THIS device, not assumed (k_part.h); ~4 ms
+        unsigned int* d_bad = nullptr;
+        CHK(hipMalloc(&d_bad, sizeof(unsigned int)));
+        CHK(hipMemset(d_bad, 0, sizeof(unsigned int)));
+        hipLaunchKernelGGL(k_lds_order_check, dim3(256), dim3(64), 0, c->stream, 18, d_bad);
+        CHK(hipGetLastError());
+        unsigned int bad = 1;
+        CHK(hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+        CHK(hipStreamSynchronize(c->stream));
+        (void)hipFree(d_bad);
+        c->lds_ordered = bad == 0;
+        if (!c->lds_ordered) fprintf(stderr, "[sqg] LDS atomics are not served in lane order on this device (%u mismatches): the claim protocol hands the k-mer streams out\n", bad);
+    }
     if (cfg->mode == SQG_MODE_CERTIFIED) {
         // exhaustive sweep of the fp32 deviate against the FP64 one on THIS device (~25 ms):
         // the bound the acceptance test uses is measured, not assumed

@@ -51,11 +51,12 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     if (phase != 2 && b->split && !b->part && (rc = ensure(c, (void**)&c->d_link_rows, &c->link_rows_cap, (size_t)b->n_chains * (size_t)c->num_kmer, sizeof(uint32_t)))) return rc;
     const int n_part = (c->num_kmer + PART_SUB - 1) >> PART_SUB_BITS;
     const int kmer_pad = n_part * PART_SUB;
+    const size_t n_pairs = (size_t)b->n_wchains * (size_t)n_part;   // (worker chain, partition)
     if (phase != 2 && b->part) {
         if ((rc = ensure(c, (void**)&c->d_part, &c->part_cap, (size_t)b->n_events + PART_SLACK, sizeof(uint32_t)))) return rc;
         if ((rc = ensure(c, (void**)&c->d_pcnt, &c->pcnt_cap, (size_t)2 * b->n_chains * (size_t)n_part, sizeof(uint32_t)))) return rc;   // counts, offsets
-        if ((rc = ensure(c, (void**)&c->d_slice, &c->slice_cap, (size_t)2 * b->n_groups * (size_t)n_part, sizeof(uint32_t)))) return rc;
-        if ((rc = ensure(c, (void**)&c->d_phist, &c->phist_cap, (size_t)b->n_groups * (size_t)kmer_pad, sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(c, (void**)&c->d_slice, &c->slice_cap, (size_t)2 * (size_t)b->max_slices + (size_t)3 * n_pairs + 1, sizeof(uint32_t)))) return rc;
+        if ((rc = ensure(c, (void**)&c->d_phist, &c->phist_cap, (size_t)b->max_slices * (size_t)PART_SUB, sizeof(uint32_t)))) return rc;
     }
     const size_t n_rows = (size_t)c->nw * (size_t)c->num_kmer;
     if (phase == 1 && (rc = ensure(c, (void**)&c->d_xcounts, &c->xcounts_cap, n_rows, sizeof(uint32_t)))) return rc;
@@ -121,35 +122,40 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         const int dw = inline_dwell ? (certified && c->dwell_hi < 1.0e6 ? 1 : 2) : 0;
         const dim3 pg((unsigned)((c->num_kmer + 63) / 64), (unsigned)b->n_wchains);
         const dim3 sg((unsigned)((c->num_kmer + 255) / 256), (unsigned)b->n_wchains);
-        const unsigned pgrid = (unsigned)b->n_groups * (unsigned)n_part;
+        const unsigned pgrid = (unsigned)b->max_slices;
         uint32_t* const slice_lo = c->d_slice;
-        uint32_t* const slice_hi = c->d_slice ? c->d_slice + (size_t)b->n_groups * n_part : nullptr;
+        uint32_t* const slice_hi = slice_lo + (size_t)b->max_slices;
+        uint32_t* const pfirst = slice_hi + (size_t)b->max_slices;   // pfirst[n_pairs]: the number of slices
+        uint32_t* const pstart = pfirst + n_pairs + 1;
+        uint32_t* const ptotal = pstart + n_pairs;
         if (b->part) {
             // k > 6, split chains: the hand-out over events bucketed by the top bits of the rank (k_part.h)
             if (phase != 2) {
                 launch_events(dw, true);                          // dwell draws; events per (link, partition)
                 hipLaunchKernelGGL(k_part_offsets, dim3((unsigned)n_part, (unsigned)b->n_wchains), dim3(1024), 0, c->stream, c->d_pcnt,
-                                   c->d_pcnt + (size_t)b->n_chains * n_part, n_part, b->d_wlink_off, b->d_link_group, b->d_cbase, slice_lo, slice_hi);
+                                   c->d_pcnt + (size_t)b->n_chains * n_part, n_part, b->d_wlink_off, b->d_cbase, pstart, ptotal);
+                hipLaunchKernelGGL(k_part_slices, dim3(1), dim3(1024), 0, c->stream, pstart, ptotal, (int)n_pairs, b->slice_len, pfirst, slice_lo, slice_hi);
                 HIPCHK(c, hipGetLastError());
                 if ((rc = dbg_sync(c, "k_events<count>/k_part_offsets"))) return rc;
                 launch_events(0, false);                          // every event to its slot (the dwell is in memory now)
-                hipLaunchKernelGGL(k_part_hist, dim3(pgrid), dim3(256), 0, c->stream, c->d_part, slice_lo, slice_hi, c->d_phist);
+                hipLaunchKernelGGL(k_part_hist, dim3(pgrid), dim3(256), 0, c->stream, c->d_part, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist);
                 HIPCHK(c, hipGetLastError());
                 if ((rc = dbg_sync(c, "k_events<scatter>/k_part_hist"))) return rc;
                 if (phase == 1) {                                 // range sharding: what this range draws per stream, for the exchange
                     HIPCHK(c, hipMemsetAsync(c->d_xcounts, 0, n_rows * sizeof(uint32_t), c->stream));
-                    hipLaunchKernelGGL(k_part_totals, sg, dim3(256), 0, c->stream, c->d_phist, c->num_kmer, kmer_pad, b->d_wgroup_off, b->d_wlink_worker, c->d_xcounts);
+                    hipLaunchKernelGGL(k_part_totals, sg, dim3(256), 0, c->stream, c->d_phist, c->num_kmer, n_part, pfirst, b->d_wlink_worker, c->d_xcounts);
                     HIPCHK(c, hipGetLastError());
                 }
             }
             if (phase != 1) {
-                hipLaunchKernelGGL(k_part_scan, sg, dim3(256), 0, c->stream, c->d_phist, c->d_rows, c->num_kmer, kmer_pad, b->d_wgroup_off, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, b->d_err);
+                hipLaunchKernelGGL(k_part_scan, sg, dim3(256), 0, c->stream, c->d_phist, c->d_rows, c->num_kmer, n_part, pfirst, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, b->d_err);
                 if (before) {                                     // every worker's row moves past the whole batch, all ranges
                     const dim3 ag((unsigned)((n_rows + 255) / 256));
                     hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
                 }
-                if (c->dwell_hi >= (double)PART_JT) hipLaunchKernelGGL(k_part_hand<true>, dim3(pgrid), dim3(64), 0, c->stream, c->d_part, S.d_part_state, slice_lo, slice_hi, c->d_phist, c->d_pow, (uint32_t)b->n_events);
-                else hipLaunchKernelGGL(k_part_hand<false>, dim3(pgrid), dim3(64), 0, c->stream, c->d_part, S.d_part_state, slice_lo, slice_hi, c->d_phist, c->d_pow, (uint32_t)b->n_events);
+                if (c->lds_ordered) hipLaunchKernelGGL(k_part_hand_ord, dim3(pgrid), dim3(64), 0, c->stream, c->d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);
+                else if (c->dwell_hi >= (double)PART_JT) hipLaunchKernelGGL(k_part_hand<true>, dim3(pgrid), dim3(64), 0, c->stream, c->d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);
+                else hipLaunchKernelGGL(k_part_hand<false>, dim3(pgrid), dim3(64), 0, c->stream, c->d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);
                 HIPCHK(c, hipGetLastError());
                 if ((rc = dbg_sync(c, "k_part_scan/k_part_hand"))) return rc;
             }

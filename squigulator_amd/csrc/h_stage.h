@@ -204,37 +204,22 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     std::vector<long long> chain_ev((size_t)b->n_chains, 0);
     for (int q = 0; q < b->n_chains; q++)
         for (int ci = chain_off[(size_t)q]; ci < chain_off[(size_t)q + 1]; ci++) chain_ev[(size_t)q] += rd[(size_t)chain_reads[(size_t)ci]].ne0 + rd[(size_t)chain_reads[(size_t)ci]].ne1;
-    // k > 6, split chains: the hand-out runs over events bucketed by the top bits of the rank (k_part.h).  A worker chain's
-    // links are gathered into GROUPS of consecutive links; a (group, partition) is one workgroup of k_part_hist / k_part_hand,
-    // and the groups' 4^k-entry count tables are what k_part_scan sweeps (SQG_PART_GROUPS: target number, tests; SQG_NO_PART=1:
-    // the per-link rows of round 1, for A/B runs).
-    std::vector<int> link_group, wgroup_off(1, 0);
+    // k > 6, split chains: the hand-out runs over events bucketed by the top bits of the rank (k_part.h).  The events of a
+    // (worker chain, partition) are cut into slices of equal length, one workgroup of k_part_hist / k_part_hand each; the
+    // slices' 4096-entry tables are what k_part_scan sweeps (SQG_PART_SLICE: events per slice, tests; SQG_NO_PART=1: the
+    // per-link rows of round 1, for A/B runs).
     std::vector<uint32_t> cbase;
     if (b->split && c->num_kmer > 4096 && c->num_kmer <= PART_MAX * PART_SUB && nev < 4294967000LL && !getenv("SQG_NO_PART")) {   // (= part_ok above)
         const int n_part = (c->num_kmer + PART_SUB - 1) >> PART_SUB_BITS;
-        const char* genv = getenv("SQG_PART_GROUPS");
-        const long long tg = genv ? std::max(1, atoi(genv)) : std::max(1, 4096 / n_part);
-        link_group.assign((size_t)b->n_chains, 0);
         long long at = 0;
-        int g = 0;
-        for (int q = 0; q < n_wchains; q++) {
-            const int l0 = wlink_off[(size_t)q], l1 = wlink_off[(size_t)q + 1];
-            long long gq = nev > 0 ? (tg * wchain_ev[(size_t)q] + nev - 1) / nev : 1;
-            gq = std::max<long long>(1, std::min<long long>(gq, l1 - l0));
-            const long long per = (wchain_ev[(size_t)q] + gq - 1) / gq;
-            long long acc = 0;
-            for (int l = l0; l < l1; l++) {
-                link_group[(size_t)l] = g;
-                acc += chain_ev[(size_t)l];
-                // a group's per-stream sample counts are 32-bit
-                const long long nxt = l + 1 < l1 ? chain_ev[(size_t)l + 1] : 0;
-                if (l + 1 == l1 || acc >= per || (double)(acc + nxt) * c->dwell_hi >= 4.0e9) { g++; acc = 0; }
-            }
-            wgroup_off.push_back(g);
-            cbase.push_back((uint32_t)at);
-            at += wchain_ev[(size_t)q];
-        }
-        b->n_groups = g;
+        for (int q = 0; q < n_wchains; q++) { cbase.push_back((uint32_t)at); at += wchain_ev[(size_t)q]; }
+        const char* senv = getenv("SQG_PART_SLICE");
+        long long len = senv ? atoll(senv) : (nev + 4095) / 4096;                                 // about 4096 slices
+        // a slice's per-stream sample counts are 32-bit (a bucketed event carries its dwell in 16 bits)
+        len = std::min<long long>(len, (long long)(4.0e9 / std::min(std::max(c->dwell_hi, 1.0), 65535.0)));
+        len = std::max<long long>(PART_STEP, len / PART_STEP * PART_STEP);
+        b->slice_len = (uint32_t)len;
+        b->max_slices = (long long)(nev / len) + (long long)n_wchains * n_part;
         b->part = true;
     }
     if (c->use_kmer_streams && c->num_kmer > 4096 && !b->part && (double)b->max_wchain_ev * c->dwell_hi >= 4294967295.0 - (double)LCG_ORD2) {
@@ -313,7 +298,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     st_mark("chains+streams+blocks");
     auto bail = [&](int code) { c->time_c = snap_time; c->off_x = snap_off; c->med_x = snap_med; sqg_batch_free(c, b); return code; };
 #define CHKB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE); } } while (0)
-    size_t meta_bytes = 0, mo_err = 0, mo_reads = 0, mo_blk = 0, mo_coff = 0, mo_crd = 0, mo_ord = 0, mo_wlo = 0, mo_wlw = 0, mo_lg = 0, mo_wgo = 0, mo_cb = 0;
+    size_t meta_bytes = 0, mo_err = 0, mo_reads = 0, mo_blk = 0, mo_coff = 0, mo_crd = 0, mo_ord = 0, mo_wlo = 0, mo_wlw = 0, mo_cb = 0;
     {   // one device allocation per batch, carved into the batch's arrays (256-byte aligned)
         size_t off = 0;
         auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -324,12 +309,11 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
                      o_crd = carve(std::max<size_t>(1, chain_reads.size()) * sizeof(int)),
                      o_ord = carve(std::max<size_t>(1, chain_order.size()) * sizeof(int)),
                      o_wlo = carve(wlink_off.size() * sizeof(int)), o_wlw = carve(std::max<size_t>(1, wlink_worker.size()) * sizeof(int)),
-                     o_lg = carve(std::max<size_t>(1, link_group.size()) * sizeof(int)), o_wgo = carve(wgroup_off.size() * sizeof(int)),
                      o_cb = carve(std::max<size_t>(1, cbase.size()) * sizeof(uint32_t));
         meta_bytes = off;
         const size_t o_bases = carve((size_t)nb + 16),
                      o_st = carve((size_t)std::max<long long>(nst, 1) * sizeof(int)), o_t = carve((size_t)std::max<long long>(ntile, 1) * sizeof(int));
-        mo_err = o_err; mo_reads = o_reads; mo_blk = o_blk; mo_coff = o_coff; mo_crd = o_crd; mo_ord = o_ord; mo_wlo = o_wlo; mo_wlw = o_wlw; mo_lg = o_lg; mo_wgo = o_wgo; mo_cb = o_cb;
+        mo_err = o_err; mo_reads = o_reads; mo_blk = o_blk; mo_coff = o_coff; mo_crd = o_crd; mo_ord = o_ord; mo_wlo = o_wlo; mo_wlw = o_wlw; mo_cb = o_cb;
         // a freed batch's block, pinned offsets and events are reused when they are large enough
         for (size_t pi = 0; pi < c->pool.size(); pi++) {
             sqg_ctx::Recycled& r = c->pool[pi];
@@ -359,7 +343,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         b->d_chain_off = (int*)(base + o_coff); b->d_chain_reads = (int*)(base + o_crd); b->d_stile_read = (int*)(base + o_st);
         b->d_tile_read = (int*)(base + o_t); b->d_chain_order = (int*)(base + o_ord);
         b->d_wlink_off = (int*)(base + o_wlo); b->d_wlink_worker = (int*)(base + o_wlw);
-        b->d_link_group = (int*)(base + o_lg); b->d_wgroup_off = (int*)(base + o_wgo); b->d_cbase = (uint32_t*)(base + o_cb);
+        b->d_cbase = (uint32_t*)(base + o_cb);
     }
     {   // the host-built arrays -> pinned mirror -> one asynchronous copy
         uint8_t* m = b->h_meta;
@@ -374,8 +358,6 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
             memcpy(m + mo_wlw, wlink_worker.data(), wlink_worker.size() * sizeof(int));
         }
         if (b->part) {
-            memcpy(m + mo_lg, link_group.data(), link_group.size() * sizeof(int));
-            memcpy(m + mo_wgo, wgroup_off.data(), wgroup_off.size() * sizeof(int));
             memcpy(m + mo_cb, cbase.data(), cbase.size() * sizeof(uint32_t));
         }
         CHKB(hipMemcpyAsync(b->d_block, m, meta_bytes, hipMemcpyHostToDevice, c->stage_stream));

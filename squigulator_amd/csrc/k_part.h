@@ -8,13 +8,13 @@
 // rank >> 12, 64 of them for 9-mers), stably, and each bucket is walked against its own 4096-entry sub-row in LDS:
 //
 //   k_events<HIST, PART>  per link: dwell draws, ranks, events per (link, partition)                  -> pcnt
-//   k_part_offsets        per (worker chain, partition): pcnt -> first slot of every (link, partition) in part[], and the slices
-//                         [lo, hi) of part[] that belong to each (group of links, partition)
+//   k_part_offsets        per (worker chain, partition): pcnt -> first slot of every (link, partition) in part[]
+//   k_part_slices         the run of a (worker chain, partition) in part[] is cut into slices of equal length
 //   k_events<PART>        per link: every event to its slot, {dwell, low 12 bits of the rank}; evrec = {slot, rank}
-//   k_part_hist           per (group, partition): samples per stream over the slice                  -> phist
-//   k_part_scan           per (worker chain, rank): exclusive scan over the chain's groups on top of the worker's row:
-//                         phist = the streams' STATES as the group finds them; the worker's row moves past the batch
-//   k_part_hand           per (group, partition): the slice in order against the sub-row in LDS: state[slot] = the stream's
+//   k_part_hist           per slice: samples per stream over the slice                               -> phist
+//   k_part_scan           per (worker chain, rank): exclusive scan over the slices of the rank's partition on top of the
+//                         worker's row: phist = the streams' STATES as the slice finds them; the row moves past the batch
+//   k_part_hand           per slice: the slice in order against the sub-row in LDS: state[slot] = the stream's
 //                         state at the event's first draw; the sub-row advances by a^(2 * dwell)
 //   k_samples*            evrec.x is the slot: the sample kernels fetch state[slot]
 //
@@ -24,13 +24,11 @@
 
 // grid (partitions, worker chains), 1024 threads, each with a run of consecutive links of the chain.
 //   wlink_off[q]..wlink_off[q+1]   the links of worker chain q, in chain order
-//   link_group[l]                  the group a link belongs to (consecutive links of a chain, ascending)
 //   cbase[q]                       first slot of the chain's region in part[]; the region is partition-major
-// poff[l][p] <- first slot of link l's events of partition p; slice_lo/hi[g][p] <- the slots of group g's events of partition p
+// poff[l][p] <- first slot of link l's events of partition p; pstart/ptotal[q][p] <- the chain's events of partition p in part[]
 __global__ __launch_bounds__(1024) void k_part_offsets(const uint32_t* __restrict__ pcnt, uint32_t* __restrict__ poff, const int n_part,
-                                                       const int* __restrict__ wlink_off, const int* __restrict__ link_group,
-                                                       const uint32_t* __restrict__ cbase,
-                                                       uint32_t* __restrict__ slice_lo, uint32_t* __restrict__ slice_hi) {
+                                                       const int* __restrict__ wlink_off, const uint32_t* __restrict__ cbase,
+                                                       uint32_t* __restrict__ pstart, uint32_t* __restrict__ ptotal) {
     __shared__ uint32_t wsum[16], wlow[16];
     const int p = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l0 = wlink_off[q], l1 = wlink_off[q + 1];
@@ -52,21 +50,56 @@ __global__ __launch_bounds__(1024) void k_part_offsets(const uint32_t* __restric
     for (int l = la; l < lb; l++) {
         const uint32_t cnt = pcnt[(size_t)l * n_part + p];
         poff[(size_t)l * n_part + p] = at;
-        const int g = link_group[l];
-        if (l == l0 || link_group[l - 1] != g) {                  // the link opens a group
-            slice_lo[(size_t)g * n_part + p] = at;
-            if (l != l0) slice_hi[(size_t)(g - 1) * n_part + p] = at;
-        }
-        if (l == l1 - 1) slice_hi[(size_t)g * n_part + p] = start + total;
         at += cnt;
     }
+    if (tid == 0) { pstart[(size_t)q * n_part + p] = start; ptotal[(size_t)q * n_part + p] = total; }
 }
 
-// grid: groups x partitions (partition fastest), 256 threads.  phist[g][rank] <- samples the group's events draw from the stream
+// The events of a (worker chain, partition) lie in part[] in the order the chain produces them; the hand-out walks them in that
+// order, and any cut of the run is as good as any other: it is cut into SLICES of slice_len events (the last one shorter), so
+// that a partition with many events (k-mers of poly-A tails, adaptors, satellite repeats) is simply more slices, not a longer one.
+// One workgroup: pfirst[pair] <- the pair's first slice (pair = chain * n_part + partition; pfirst[n_pairs] = number of slices),
+// slice_lo/hi[s] <- the slots of slice s.  The host sized the tables for n_events / slice_len + n_pairs slices.
+__global__ __launch_bounds__(1024) void k_part_slices(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ ptotal, const int n_pairs,
+                                                      const uint32_t slice_len, uint32_t* __restrict__ pfirst,
+                                                      uint32_t* __restrict__ slice_lo, uint32_t* __restrict__ slice_hi) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_pairs; base += 1024) {
+        const int i = base + tid;
+        const uint32_t tot = i < n_pairs ? ptotal[i] : 0u;
+        const uint32_t ns = (tot + slice_len - 1) / slice_len;
+        const uint32_t incl = (uint32_t)wave_incl_scan_dpp((int)ns);
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        uint32_t first = carry;
+        for (int w = 0; w < wid; w++) first += wsum[w];
+        first += incl - ns;
+        if (i < n_pairs) {
+            pfirst[i] = first;
+            const uint32_t st = pstart[i];
+            for (uint32_t s = 0; s < ns; s++) {
+                slice_lo[first + s] = st + s * slice_len;
+                slice_hi[first + s] = st + min((s + 1) * slice_len, tot);
+            }
+        }
+        __syncthreads();
+        if (tid == 1023) carry = first + ns;
+        __syncthreads();
+    }
+    if (tid == 0) pfirst[n_pairs] = carry;
+}
+
+// grid: slices (the host's bound; the live ones are pfirst[n_pairs]), 256 threads.  phist[s][sub] <- samples the slice's events draw from the stream
 __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* __restrict__ part, const uint32_t* __restrict__ slice_lo,
-                                                   const uint32_t* __restrict__ slice_hi, uint32_t* __restrict__ phist) {
+                                                   const uint32_t* __restrict__ slice_hi, const uint32_t* __restrict__ n_slices,
+                                                   uint32_t* __restrict__ phist) {
     __shared__ uint32_t row[PART_SUB];
     const int tid = threadIdx.x;
+    if (blockIdx.x >= *n_slices) return;
     for (int i = tid; i < PART_SUB; i += 256) row[i] = 0u;
     __syncthreads();
     const uint32_t lo = slice_lo[blockIdx.x], hi = slice_hi[blockIdx.x];
@@ -75,21 +108,31 @@ __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* __restrict__ 
 #pragma unroll
         for (int q = 0; q < 4; q++) rec[q] = part[b + 256 * q + tid];        // (unconditional: PART_SLACK entries behind the last slice)
 #pragma unroll
-        for (int q = 0; q < 4; q++) if (b + 256 * q + tid < hi) atomicAdd(&row[rec[q] & (PART_SUB - 1)], rec[q] >> 16);
+        for (int q = 0; q < 4; q++) {
+            const bool live = b + 256 * q + tid < hi;
+            const uint32_t sub = rec[q] & (PART_SUB - 1);
+            // a wavefront whose events all fall on one stream (poly-A tails ...): one add of the wavefront's sum instead of 64
+            // adds to one address
+            if (__builtin_amdgcn_ballot_w64(live && sub == (uint32_t)__builtin_amdgcn_readfirstlane((int)sub)) == ~0ull) {
+                int sum = (int)(rec[q] >> 16);
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                if ((tid & 63) == 0) atomicAdd(&row[sub], (uint32_t)sum);
+            } else if (live) atomicAdd(&row[sub], rec[q] >> 16);
+        }
     }
     __syncthreads();
-    uint32_t* dst = phist + (size_t)blockIdx.x * PART_SUB;       // [g][p][sub] = [g][rank]
+    uint32_t* dst = phist + (size_t)blockIdx.x * PART_SUB;
     for (int i = tid; i < PART_SUB; i += 256) dst[i] = row[i];
 }
 
-// One thread per (worker chain, rank): exclusive scan of phist over the chain's groups, starting from the worker's row
-// (sample counts, reduced mod (M-1)/2: only that matters for a^(2n)) plus, with range sharding, what the ranges before this
-// one draw (`before`; the row itself is then left to k_rows_advance).  What a group gets is the stream's STATE as the
-// group finds it: seed(worker, rank) * a^(2 * samples before), the seed being (seed_base + worker*seed_step + rank) mod M
+// One thread per (worker chain, rank): exclusive scan of phist over the slices of the rank's partition, in chain order, starting
+// from the worker's row (sample counts, reduced mod (M-1)/2: only that matters for a^(2n)) plus, with range sharding, what the
+// ranges before this one draw (`before`; the row itself is then left to k_rows_advance).  What a slice gets is the stream's STATE
+// as the slice finds it: seed(worker, rank) * a^(2 * samples before), the seed being (seed_base + worker*seed_step + rank) mod M
 // (src/sim.c:249) -- from there on k_part_hand advances states, one modular multiplication per event, as the 6-mer path does.
 // grid (num_kmer / 256, worker chains).
-__global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ phist, uint32_t* __restrict__ rows, const int num_kmer, const int pad,
-                                                   const int* __restrict__ wgroup_off, const int* __restrict__ wlink_worker,
+__global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ phist, uint32_t* __restrict__ rows, const int num_kmer, const int n_part,
+                                                   const uint32_t* __restrict__ pfirst, const int* __restrict__ wlink_worker,
                                                    const uint32_t* __restrict__ before, const uint32_t* __restrict__ pw,
                                                    const uint32_t seed_base, const uint32_t seed_step, unsigned int* __restrict__ err) {
     const int q = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
@@ -100,9 +143,10 @@ __global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ phist,
     const uint32_t seed = (uint32_t)(sv >= LCG_M ? sv - LCG_M : sv);
     unsigned long long run = rows[wj] % LCG_ORD2;
     if (before) run += before[wj];
-    const int g0 = wgroup_off[q], g1 = wgroup_off[q + 1];
-    for (int g = g0; g < g1; g++) {
-        uint32_t* cell = phist + (size_t)g * pad + j;             // (a group's table is whole partitions: pad >= num_kmer)
+    const int pair = q * n_part + (j >> PART_SUB_BITS);
+    const uint32_t s0 = pfirst[pair], s1 = pfirst[pair + 1];
+    for (uint32_t s = s0; s < s1; s++) {
+        uint32_t* cell = phist + (size_t)s * PART_SUB + (j & (PART_SUB - 1));
         const uint32_t cnt = *cell;
         const uint32_t n = (uint32_t)run;                         // (an overflow is reported below; the batch fails)
         *cell = n ? lcg_mul(seed, lcg_jump2(pw, n)) : seed;
@@ -113,16 +157,17 @@ __global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ phist,
 }
 
 // range sharding: samples this batch's local reads draw from each (worker, rank) stream (counts zeroed beforehand)
-__global__ __launch_bounds__(256) void k_part_totals(const uint32_t* __restrict__ phist, const int num_kmer, const int pad, const int* __restrict__ wgroup_off,
+__global__ __launch_bounds__(256) void k_part_totals(const uint32_t* __restrict__ phist, const int num_kmer, const int n_part, const uint32_t* __restrict__ pfirst,
                                                      const int* __restrict__ wlink_worker, uint32_t* __restrict__ counts) {
     const int q = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
     if (j >= num_kmer) return;
     uint32_t sum = 0;
-    for (int g = wgroup_off[q]; g < wgroup_off[q + 1]; g++) sum += phist[(size_t)g * pad + j];
+    const int pair = q * n_part + (j >> PART_SUB_BITS);
+    for (uint32_t s = pfirst[pair]; s < pfirst[pair + 1]; s++) sum += phist[(size_t)s * PART_SUB + (j & (PART_SUB - 1))];
     counts[(size_t)wlink_worker[q] * num_kmer + j] = sum;
 }
 
-// grid: groups x partitions, ONE wavefront each (the sub-row of stream states, 16 KiB, is the workgroup's LDS: no sharing,
+// grid: slices, ONE wavefront each (the sub-row of stream states, 16 KiB, is the workgroup's LDS: no sharing,
 // every lane busy).  The slice is walked in order in steps of 1024 events: the step's 16 loads per lane are in flight while the
 // step before is handed out, its 16 stores go out together at the end (on gfx950 a wavefront that waits for a load also waits
 // for its own earlier stores: they are kept few and far from the loads).  A step is handed out in four phases of 256 events
@@ -147,10 +192,14 @@ __global__ __launch_bounds__(256) void k_part_totals(const uint32_t* __restrict_
 #ifndef PART_ATOMIC_ROUNDS
 #define PART_ATOMIC_ROUNDS 2     // rounds of the earliest-wins protocol before the contended streams are taken one stream at a time
 #endif
+#ifndef PART_MANY
+#define PART_MANY 24             // waiting events of a phase from which on the streams are taken one at a time straight away
+#endif
 #define PART_SLACK (2 * PART_STEP)   // entries behind the bucketed events: read ahead by the last step of a slice, and the dump of idle lanes' stores
 template <bool BIGD>
 __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out,
                                                   const uint32_t* __restrict__ slice_lo, const uint32_t* __restrict__ slice_hi,
+                                                  const uint32_t* __restrict__ n_slices,
                                                   const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pw, const uint32_t dump) {
     __shared__ uint32_t row[PART_SUB];                            // stream states (< 2^31); during a phase also claims: PART_CLAIM | position
 #if !PART_ROW_CLAIMS
@@ -158,14 +207,23 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
 #endif
     __shared__ uint32_t atg[PART_ATAGS];
     __shared__ uint32_t jt[PART_JT];                              // a^(2j)
+    __shared__ uint32_t jt1[PART_JT];                             // a^(2*256*j): with jt, any jump below 65536 samples without leaving LDS
     constexpr int NR = PART_STEP / 64;                            // records per lane and step
     const int lane = threadIdx.x;
+    if (blockIdx.x >= *n_slices) return;
     const uint4* src = reinterpret_cast<const uint4*>(phist + (size_t)blockIdx.x * PART_SUB);
     for (int i = lane; i < PART_SUB / 4; i += 64) reinterpret_cast<uint4*>(row)[i] = src[i];
     for (int i = lane; i < PART_ATAGS; i += 64) atg[i] = 0xffffffffu;
     for (int i = lane; i < PART_JT; i += 64) jt[i] = pw[2 * POW_N + i];
+    for (int i = lane; i < PART_JT; i += 64) jt1[i] = (i & 3) ? lcg_mul(pw[3 * POW_N + (i >> 2)], pw[2 * POW_N + 256 * (i & 3)]) : pw[3 * POW_N + (i >> 2)];
     const uint32_t lo = slice_lo[blockIdx.x], hi = slice_hi[blockIdx.x];
     uint32_t cur[NR], nxt[NR];
+    // a^(2n): two LDS look-ups and a multiplication below 65536 samples (a stream with hundreds of events in a phase), else the global tables
+    auto jump = [&](uint32_t n) -> uint32_t {
+        if (n < PART_JT) return jt[n];
+        if (n < PART_JT * PART_JT) return lcg_mul(jt[n & (PART_JT - 1)], jt1[n >> 8]);
+        return lcg_jump2(pw, n);
+    };
 #pragma unroll
     for (int r = 0; r < NR; r++) cur[r] = part[lo + 64 * r + lane];   // (unconditional: PART_SLACK entries behind the last slice)
     __syncthreads();
@@ -231,8 +289,13 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
             }
 #endif
             int round = 0;
-            while (__builtin_amdgcn_ballot_w64(pend[0] | pend[1] | pend[2] | pend[3])) {     // contended streams, in order
-                if (round++ < PART_ATOMIC_ROUNDS) {                  // two events on a stream (the usual case): the earliest wins a round
+            for (;;) {                                               // contended streams, in order
+                const int n_pend = __builtin_popcountll(__builtin_amdgcn_ballot_w64(pend[0])) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(pend[1])) +
+                                   __builtin_popcountll(__builtin_amdgcn_ballot_w64(pend[2])) + __builtin_popcountll(__builtin_amdgcn_ballot_w64(pend[3]));
+                if (n_pend == 0) break;
+                // two events on a stream (the usual case): the earliest wins a round.  Many waiting events mean a stream with many
+                // events (dozens of atomics on one LDS word serialise): such a phase goes stream by stream at once
+                if (n_pend < PART_MANY && round++ < PART_ATOMIC_ROUNDS) {
 #pragma unroll
                     for (int q = 0; q < 4; q++) if (pend[q]) atomicMin(&atg[sub[q] & (PART_ATAGS - 1)], (uint32_t)pri[q]);
                     uint32_t ta[4], s0[4];
@@ -280,12 +343,12 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
                     const int incl = wave_incl_scan_dpp(dq);
                     const uint32_t before = run + (uint32_t)(incl - dq);
                     if (mem) {
-                        st[q] = before ? lcg_mul(sv, before < PART_JT ? jt[before] : lcg_jump2(pw, before)) : sv;
+                        st[q] = before ? lcg_mul(sv, jump(before)) : sv;
                         pend[q] = false;
                     }
                     run += (uint32_t)__shfl(incl, 63);
                 }
-                if (lane == 0) __hip_atomic_store(&row[sstar], lcg_mul(sv, run < PART_JT ? jt[run] : lcg_jump2(pw, run)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+                if (lane == 0) __hip_atomic_store(&row[sstar], lcg_mul(sv, jump(run)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
             }
 #pragma unroll
             for (int q = 0; q < 4; q++) out[4 * ph + q] = st[q];
@@ -295,4 +358,112 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
 #pragma unroll
         for (int r = 0; r < NR; r++) cur[r] = nxt[r];
     }
+}
+
+// ---- the hand-out by ordered LDS atomics ----------------------------------------------------------------------------
+// What an event needs is the number of samples the slice's EARLIER events draw from its stream: with n of them the event starts
+// at base[stream] * a^(2n), base being the state the slice finds (k_part_scan).  `n = atomicAdd(&cnt[stream], dwell)` is that
+// number if the additions happen in event order -- and in one wavefront they do: LDS instructions of a wavefront execute in
+// program order, and the lanes of one LDS atomic that meet on an address are served in ascending lane order.  The second half
+// is a property of the LDS pipeline, not of the ISA manual: k_lds_order_check measures it on the device when the context is
+// created (random address patterns from all-distinct to all-equal, idle lanes), and a context whose device does not pass
+// uses k_part_hand, the claim protocol above, which assumes program order only.
+// No protocol, no divergence, and a stream with thousands of events in a slice (poly-A tails, adaptors) costs what its
+// atomics cost the LDS: one address, one lane after the other.
+// a^(2n) comes from three 256-entry tables in LDS (n < 2^24: a stream's samples in one slice; else the global tables).
+#define PART_LT 256
+__global__ __launch_bounds__(64) void k_part_hand_ord(const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out,
+                                                      const uint32_t* __restrict__ slice_lo, const uint32_t* __restrict__ slice_hi,
+                                                      const uint32_t* __restrict__ n_slices,
+                                                      const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pw, const uint32_t dump) {
+    __shared__ uint32_t base[PART_SUB];                           // the streams' states as the slice finds them
+    __shared__ uint32_t cnt[PART_SUB];                            // samples handed out so far
+    __shared__ uint32_t lt0[PART_LT], lt1[PART_LT], lt2[PART_LT]; // a^(2j), a^(2 * 256 j), a^(2 * 65536 j)
+    constexpr int NR = PART_STEP / 64;                            // records per lane and step
+    const int lane = threadIdx.x;
+    if (blockIdx.x >= *n_slices) return;
+    const uint4* src = reinterpret_cast<const uint4*>(phist + (size_t)blockIdx.x * PART_SUB);
+    for (int i = lane; i < PART_SUB / 4; i += 64) { reinterpret_cast<uint4*>(base)[i] = src[i]; reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0u, 0u, 0u, 0u); }
+    for (int i = lane; i < PART_LT; i += 64) {
+        lt0[i] = pw[2 * POW_N + i];
+        lt1[i] = (i & 3) ? lcg_mul(pw[3 * POW_N + (i >> 2)], pw[2 * POW_N + 256 * (i & 3)]) : pw[3 * POW_N + (i >> 2)];
+        lt2[i] = (i & 15) ? lcg_mul(pw[4 * POW_N + (i >> 4)], pw[3 * POW_N + 64 * (i & 15)]) : pw[4 * POW_N + (i >> 4)];
+    }
+    const uint32_t lo = slice_lo[blockIdx.x], hi = slice_hi[blockIdx.x];
+    uint32_t cur[NR], nxt[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) cur[r] = part[lo + 64 * r + lane];   // (unconditional: PART_SLACK entries behind the last slice)
+    __syncthreads();
+    for (uint32_t b = lo; b < hi; b += PART_STEP) {
+#pragma unroll
+        for (int r = 0; r < NR; r++) nxt[r] = part[b + PART_STEP + 64 * r + lane];
+        uint32_t n[NR], out[NR], any = 0;
+#pragma unroll
+        for (int r = 0; r < NR; r++) {                              // event 64 r + lane of the step: instruction order, then lane order
+            n[r] = 0;
+            if (b + 64 * r + lane < hi) n[r] = __hip_atomic_fetch_add(&cnt[cur[r] & (PART_SUB - 1)], cur[r] >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");                          // (the compiler keeps the atomics in this order)
+            any |= n[r];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const uint32_t m = lcg_mul(lt0[n[r] & (PART_LT - 1)], lt1[(n[r] >> 8) & (PART_LT - 1)]);
+            out[r] = lcg_mul(base[cur[r] & (PART_SUB - 1)], m);
+        }
+        if (__builtin_amdgcn_ballot_w64(any >= 65536u)) {           // a stream with tens of thousands of samples in this slice already
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+                const uint32_t h = n[r] >> 16;
+                if (h) out[r] = lcg_mul(out[r], h < PART_LT ? lt2[h] : lcg_jump2(pw, h << 16));
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; r++) { const uint32_t i = b + 64 * r + lane; state_out[i < hi ? i : dump + lane] = out[r]; }
+#pragma unroll
+        for (int r = 0; r < NR; r++) cur[r] = nxt[r];
+    }
+}
+
+// Are the lanes of one LDS atomic that meet on an address served in ascending lane order, and successive instructions in
+// program order?  Every wavefront plays rounds of 16 fetch-adds per lane against a small table, with addresses from one per
+// lane to one for all and some lanes idle, and compares what each returns with the sum over the earlier events (instruction,
+// lane) of the round on the same address.  bad <- number of mismatches.  grid: any, 64 threads.
+__global__ __launch_bounds__(64) void k_lds_order_check(const int rounds, unsigned int* __restrict__ bad) {
+    __shared__ uint32_t tab[256];
+    __shared__ uint32_t addr[16 * 64], val[16 * 64];
+    const int lane = threadIdx.x;
+    uint32_t s = (uint32_t)(blockIdx.x * 64 + lane) * 2654435761u + 12345u;
+    unsigned int wrong = 0;
+    for (int it = 0; it < rounds; it++) {
+        for (int i = lane; i < 256; i += 64) tab[i] = 0u;
+        const uint32_t spread = 1u << ((it + blockIdx.x) % 9);      // 1 .. 256 distinct addresses
+        uint32_t a[16], v[16], got[16];
+        bool on[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            s = s * 1664525u + 1013904223u;
+            a[r] = (s >> 20) & (spread - 1);
+            v[r] = ((s >> 8) & 1023u) + 1u;
+            on[r] = ((s >> 3) & 15u) != 0u || (it & 1);             // odd rounds: every lane; even: one in 16 idle
+            addr[64 * r + lane] = a[r];
+            val[64 * r + lane] = on[r] ? v[r] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            got[r] = 0;
+            if (on[r]) got[r] = __hip_atomic_fetch_add(&tab[a[r]], v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int r = 0; r < 16; r++) {
+            uint32_t want = 0;
+            const int me = 64 * r + lane;
+            for (int e = 0; e < me; e++) if (addr[e] == a[r]) want += val[e];
+            if (on[r] && got[r] != want) wrong++;
+        }
+        __syncthreads();
+    }
+    if (wrong) atomicAdd(bad, wrong);
 }

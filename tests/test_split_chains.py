@@ -117,10 +117,14 @@ def test_very_ragged_batches(T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("slice_len", [None, "1024", "5000"])
 @pytest.mark.parametrize("name,T", [("dna-r10-prom", 1), ("rna004-prom", 1), ("rna004-prom", 3)])
-def test_streams_with_many_events_in_a_row(name, T):
+def test_streams_with_many_events_in_a_row(name, T, slice_len, monkeypatch):
     """homopolymers and a sequence every read carries (poly-A tail + adaptor with --prefix=yes): hundreds of consecutive events
-    of a batch fall on ONE k-mer stream -- the bucketed hand-out takes such a stream as a whole (k_part_hand)"""
+    of a batch fall on ONE k-mer stream -- the bucketed hand-out takes such a stream as a whole (k_part_hand), and a partition
+    of the ranks that holds many events is cut into more slices than the others (k_part_slices; any slice length must do)"""
+    if slice_len:
+        monkeypatch.setenv("SQG_PART_SLICE", slice_len)
     rng = np.random.default_rng(123)
     prof, fl = profiles.get_profile(name)
     if fl & profiles.SQ_RNA:
@@ -142,9 +146,13 @@ def test_streams_with_many_events_in_a_row(name, T):
 @pytest.mark.parametrize("extra", [0, profiles.SQ_IDEAL_TIME, profiles.SQ_PREFIX, profiles.SQ_PREFIX | profiles.SQ_IDEAL_TIME],
                          ids=["plain", "ideal_time", "prefix", "prefix_ideal_time"])
 @pytest.mark.parametrize("T", [1, 2])
-def test_bucketed_hand_out_with_every_option(name, extra, T):
+@pytest.mark.parametrize("hand", ["ordered", "claims"])
+def test_bucketed_hand_out_with_every_option(name, extra, T, hand, monkeypatch):
     """9-mer tables, chains cut by the default heuristic: constant dwell (--ideal-time), DNA/RNA prefixes (two segments per read),
-    both arithmetic modes, two batches"""
+    both arithmetic modes, two batches; the hand-out by ordered LDS atomics (k_part_hand_ord, what a device that passes
+    k_lds_order_check runs) and by the claim protocol (k_part_hand, the fall-back)"""
+    if hand == "claims":
+        monkeypatch.setenv("SQG_PART_CLAIMS", "1")
     rng = np.random.default_rng(2024 + T)
     prof, fl = profiles.get_profile(name)
     batches = [_reads(rng, 170, 9, 3500) for _ in range(2)]
