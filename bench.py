@@ -163,7 +163,7 @@ WORKLOADS = {
                  "configs[3] at N=8)"),
     "ncov-r9": ("dna-r9-prom", 0, "dna", 0, 32768, "nCoV-2019.reference.fasta -x dna-r9-prom (BASELINE.json configs[1])"),
     "synth-r10": ("dna-r10-prom", 0, "dna", 1, 8192, "small synthetic hg38-proportioned genome (--genome-mb) -x dna-r10-prom"),
-    "sequin-rna004": ("rna004-prom", profiles.SQ_PREFIX, "rna", 0, 32768,
+    "sequin-rna004": ("rna004-prom", profiles.SQ_PREFIX, "rna", 1, 32768,
                       "rnasequin_sequences_2.4.fa -x rna004-prom --prefix=yes, whole transcripts (configs[4])"),
 }
 

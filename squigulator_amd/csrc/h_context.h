@@ -143,11 +143,11 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
         CHK(hipEventRecord(S.done, c->stream2));
     }
     if (c->use_kmer_streams && c->num_kmer > 4096 && !getenv("SQG_PART_CLAIMS")) {
-        // the bucketed hand-out of k > 6 by ordered LDS atomics: measured on THIS device, not assumed (k_part.h); ~4 ms
+        // the bucketed hand-out of k > 6 by ordered LDS atomics: measured on THIS device, not assumed (k_part.h); ~1 ms
         unsigned int* d_bad = nullptr;
         CHK(hipMalloc(&d_bad, sizeof(unsigned int)));
         CHK(hipMemset(d_bad, 0, sizeof(unsigned int)));
-        hipLaunchKernelGGL(k_lds_order_check, dim3(256), dim3(64), 0, c->stream, 18, d_bad);
+        hipLaunchKernelGGL(k_lds_order_check, dim3(256), dim3(64), 0, c->stream, 9, d_bad);
         CHK(hipGetLastError());
         unsigned int bad = 1;
         CHK(hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, c->stream));

@@ -214,7 +214,9 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         long long at = 0;
         for (int q = 0; q < n_wchains; q++) { cbase.push_back((uint32_t)at); at += wchain_ev[(size_t)q]; }
         const char* senv = getenv("SQG_PART_SLICE");
-        long long len = senv ? atoll(senv) : (nev + 4095) / 4096;                                 // about 4096 slices
+        // at most 4096 slices (a whole number of rounds of 4 wavefronts per CU for k_part_hand_ord), whole steps of the hand-out
+        const long long n_pairs = (long long)n_wchains * n_part, want = std::max<long long>(1024, 4096 - n_pairs);
+        long long len = senv ? atoll(senv) : ((nev + want - 1) / want + PART_STEP - 1) / PART_STEP * PART_STEP;
         // a slice's per-stream sample counts are 32-bit (a bucketed event carries its dwell in 16 bits)
         len = std::min<long long>(len, (long long)(4.0e9 / std::min(std::max(c->dwell_hi, 1.0), 65535.0)));
         len = std::max<long long>(PART_STEP, len / PART_STEP * PART_STEP);

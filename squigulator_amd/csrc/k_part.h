@@ -375,53 +375,57 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
 __global__ __launch_bounds__(64) void k_part_hand_ord(const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out,
                                                       const uint32_t* __restrict__ slice_lo, const uint32_t* __restrict__ slice_hi,
                                                       const uint32_t* __restrict__ n_slices,
-                                                      const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pw, const uint32_t dump) {
+                                                      const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pw) {
     __shared__ uint32_t base[PART_SUB];                           // the streams' states as the slice finds them
     __shared__ uint32_t cnt[PART_SUB];                            // samples handed out so far
-    __shared__ uint32_t lt0[PART_LT], lt1[PART_LT], lt2[PART_LT]; // a^(2j), a^(2 * 256 j), a^(2 * 65536 j)
+    __shared__ uint32_t lt0[PART_LT], lt1[PART_LT], lt2[PART_LT]; // a^(2j), a^(2 * 256 j), a^(2 * 65536 j), DOUBLED (lcg_mul_dbl)
     constexpr int NR = PART_STEP / 64;                            // records per lane and step
     const int lane = threadIdx.x;
     if (blockIdx.x >= *n_slices) return;
     const uint4* src = reinterpret_cast<const uint4*>(phist + (size_t)blockIdx.x * PART_SUB);
     for (int i = lane; i < PART_SUB / 4; i += 64) { reinterpret_cast<uint4*>(base)[i] = src[i]; reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0u, 0u, 0u, 0u); }
     for (int i = lane; i < PART_LT; i += 64) {
-        lt0[i] = pw[2 * POW_N + i];
-        lt1[i] = (i & 3) ? lcg_mul(pw[3 * POW_N + (i >> 2)], pw[2 * POW_N + 256 * (i & 3)]) : pw[3 * POW_N + (i >> 2)];
-        lt2[i] = (i & 15) ? lcg_mul(pw[4 * POW_N + (i >> 4)], pw[3 * POW_N + 64 * (i & 15)]) : pw[4 * POW_N + (i >> 4)];
+        lt0[i] = pw[2 * POW_N + i] << 1;
+        lt1[i] = ((i & 3) ? lcg_mul(pw[3 * POW_N + (i >> 2)], pw[2 * POW_N + 256 * (i & 3)]) : pw[3 * POW_N + (i >> 2)]) << 1;
+        lt2[i] = ((i & 15) ? lcg_mul(pw[4 * POW_N + (i >> 4)], pw[3 * POW_N + 64 * (i & 15)]) : pw[4 * POW_N + (i >> 4)]) << 1;
     }
     const uint32_t lo = slice_lo[blockIdx.x], hi = slice_hi[blockIdx.x];
+    const uint32_t* in = part + lo + lane;                          // (one address register; the records of a step sit at constant offsets)
+    uint32_t* out_p = state_out + lo + lane;
     uint32_t cur[NR], nxt[NR];
 #pragma unroll
-    for (int r = 0; r < NR; r++) cur[r] = part[lo + 64 * r + lane];   // (unconditional: PART_SLACK entries behind the last slice)
+    for (int r = 0; r < NR; r++) cur[r] = in[64 * r];               // (unconditional: PART_SLACK entries behind the last slice)
     __syncthreads();
-    for (uint32_t b = lo; b < hi; b += PART_STEP) {
+    // one step: event 64 r + lane is the lane's r-th -- instruction order, then lane order
+    auto step = [&](auto full_tag, const uint32_t left) {
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int r = 0; r < NR; r++) nxt[r] = part[b + PART_STEP + 64 * r + lane];
-        uint32_t n[NR], out[NR], any = 0;
+        for (int r = 0; r < NR; r++) nxt[r] = in[PART_STEP + 64 * r];
+        uint32_t n[NR], out[NR];
 #pragma unroll
-        for (int r = 0; r < NR; r++) {                              // event 64 r + lane of the step: instruction order, then lane order
+        for (int r = 0; r < NR; r++) {
             n[r] = 0;
-            if (b + 64 * r + lane < hi) n[r] = __hip_atomic_fetch_add(&cnt[cur[r] & (PART_SUB - 1)], cur[r] >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (FULL || (uint32_t)(64 * r + lane) < left) n[r] = __hip_atomic_fetch_add(&cnt[cur[r] & (PART_SUB - 1)], cur[r] >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");                          // (the compiler keeps the atomics in this order)
-            any |= n[r];
         }
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            const uint32_t m = lcg_mul(lt0[n[r] & (PART_LT - 1)], lt1[(n[r] >> 8) & (PART_LT - 1)]);
-            out[r] = lcg_mul(base[cur[r] & (PART_SUB - 1)], m);
-        }
-        if (__builtin_amdgcn_ballot_w64(any >= 65536u)) {           // a stream with tens of thousands of samples in this slice already
-#pragma unroll
-            for (int r = 0; r < NR; r++) {
+            out[r] = lcg_mul_dbl(base[cur[r] & (PART_SUB - 1)], lt0[n[r] & (PART_LT - 1)]);
+            if (__builtin_amdgcn_ballot_w64(n[r] >= (uint32_t)PART_LT)) {                       // (seldom: a dozen events on one stream before this one)
+                out[r] = lcg_mul_dbl(out[r], lt1[(n[r] >> 8) & (PART_LT - 1)]);
                 const uint32_t h = n[r] >> 16;
-                if (h) out[r] = lcg_mul(out[r], h < PART_LT ? lt2[h] : lcg_jump2(pw, h << 16));
+                if (h) out[r] = h < PART_LT ? lcg_mul_dbl(out[r], lt2[h]) : lcg_mul(out[r], lcg_jump2(pw, h << 16));
             }
         }
 #pragma unroll
-        for (int r = 0; r < NR; r++) { const uint32_t i = b + 64 * r + lane; state_out[i < hi ? i : dump + lane] = out[r]; }
+        for (int r = 0; r < NR; r++) if (FULL || (uint32_t)(64 * r + lane) < left) out_p[64 * r] = out[r];
 #pragma unroll
         for (int r = 0; r < NR; r++) cur[r] = nxt[r];
-    }
+        in += PART_STEP; out_p += PART_STEP;
+    };
+    uint32_t b = lo;
+    for (; b + PART_STEP <= hi; b += PART_STEP) step(std::true_type{}, 0u);
+    if (b < hi) step(std::false_type{}, hi - b);
 }
 
 // Are the lanes of one LDS atomic that meet on an address served in ascending lane order, and successive instructions in
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(64) void k_part_hand_ord(const uint32_t* __restrict
 // lane) of the round on the same address.  bad <- number of mismatches.  grid: any, 64 threads.
 __global__ __launch_bounds__(64) void k_lds_order_check(const int rounds, unsigned int* __restrict__ bad) {
     __shared__ uint32_t tab[256];
-    __shared__ uint32_t addr[16 * 64], val[16 * 64];
+    __shared__ uint4 ev[16 * 64 / 4];                             // the round's events in order: address << 16 | value (0: idle lane)
     const int lane = threadIdx.x;
     uint32_t s = (uint32_t)(blockIdx.x * 64 + lane) * 2654435761u + 12345u;
     unsigned int wrong = 0;
@@ -445,8 +449,7 @@ __global__ __launch_bounds__(64) void k_lds_order_check(const int rounds, unsign
             a[r] = (s >> 20) & (spread - 1);
             v[r] = ((s >> 8) & 1023u) + 1u;
             on[r] = ((s >> 3) & 15u) != 0u || (it & 1);             // odd rounds: every lane; even: one in 16 idle
-            addr[64 * r + lane] = a[r];
-            val[64 * r + lane] = on[r] ? v[r] : 0u;
+            reinterpret_cast<uint32_t*>(ev)[64 * r + lane] = a[r] << 16 | (on[r] ? v[r] : 0u);
         }
         __syncthreads();
 #pragma unroll
@@ -460,7 +463,17 @@ __global__ __launch_bounds__(64) void k_lds_order_check(const int rounds, unsign
         for (int r = 0; r < 16; r++) {
             uint32_t want = 0;
             const int me = 64 * r + lane;
-            for (int e = 0; e < me; e++) if (addr[e] == a[r]) want += val[e];
+            for (int e0 = 0; e0 < me; e0 += 16) {
+                uint4 x[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[i] = ev[e0 / 4 + i];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const uint32_t w[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) if (e0 + 4 * i + j < me && (w[j] >> 16) == a[r]) want += w[j] & 0xffffu;
+                }
+            }
             if (on[r] && got[r] != want) wrong++;
         }
         __syncthreads();
