@@ -118,7 +118,7 @@ struct sqg_batch {
     bool part = false;                   // k > 6, split: the hand-out runs over bucketed events (k_part.h)
     uint32_t slice_len = 0;              // events per slice of a (worker chain, partition) (k_part.h)
     long long max_slices = 0;            // bound on their number (the device counts them)
-    uint32_t* d_cbase = nullptr;         // [n_wchains] first slot of each worker chain's region in the bucketed event array
+    int* d_link_q = nullptr;             // [n_chains] the worker chain of every link (k_part.h)
     int* d_tile_read = nullptr;
     int* d_stile_read = nullptr;
     long long n_tiles = 0, n_stiles = 0;

@@ -64,6 +64,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     memset(&P, 0, sizeof P);
     P.link_rows = (b->split && !b->part) ? c->d_link_rows : nullptr;
     P.part = c->d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = c->d_pcnt; P.poff = c->d_pcnt ? c->d_pcnt + (size_t)b->n_chains * n_part : nullptr; P.n_part = n_part;
+    P.link_q = b->d_link_q;
     P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
     P.dwell = c->use_dwell_stream ? S.d_dwell : nullptr; P.dwell_out = S.d_dwell; P.seglen_out = S.d_seglen;
     P.dmean = p.dwell_mean; P.dstd = p.dwell_std;
@@ -128,16 +129,28 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         uint32_t* const pfirst = slice_hi + (size_t)b->max_slices;   // pfirst[n_pairs]: the number of slices
         uint32_t* const pstart = pfirst + n_pairs + 1;
         uint32_t* const ptotal = pstart + n_pairs;
+        P.pstart = pstart;
+        // one wavefront per link, ordered LDS atomics (k_part_events.h); the workgroup-per-link passes of k_events stay for the
+        // 5-letter alphabet and for devices that do not pass the order check
+        const bool wave_links = b->part && c->lds_ordered && !(c->cfg.flags & SQG_METH) && !getenv("SQG_PART_WG_EVENTS");
+        auto launch_part_events = [&](int dwm, bool count) {
+            if (!wave_links) { launch_events(dwm, count); return; }
+            const dim3 g((unsigned)((b->n_chains + PEV_WAVES - 1) / PEV_WAVES)), t(64 * PEV_WAVES);
+            if (!count) hipLaunchKernelGGL((k_part_events<0, true>), dim3((unsigned)((b->n_chains + PEV_WAVES_SCATTER - 1) / PEV_WAVES_SCATTER)), dim3(64 * PEV_WAVES_SCATTER), 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
+            else if (dwm == 0) hipLaunchKernelGGL((k_part_events<0, false>), g, t, 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
+            else if (dwm == 1) hipLaunchKernelGGL((k_part_events<1, false>), g, t, 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
+            else hipLaunchKernelGGL((k_part_events<2, false>), g, t, 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
+        };
         if (b->part) {
             // k > 6, split chains: the hand-out over events bucketed by the top bits of the rank (k_part.h)
             if (phase != 2) {
-                launch_events(dw, true);                          // dwell draws; events per (link, partition)
+                launch_part_events(dw, true);                     // dwell draws; events per (link, partition)
                 hipLaunchKernelGGL(k_part_offsets, dim3((unsigned)n_part, (unsigned)b->n_wchains), dim3(1024), 0, c->stream, c->d_pcnt,
-                                   c->d_pcnt + (size_t)b->n_chains * n_part, n_part, b->d_wlink_off, b->d_cbase, pstart, ptotal);
+                                   c->d_pcnt + (size_t)b->n_chains * n_part, n_part, b->d_wlink_off, ptotal);
                 hipLaunchKernelGGL(k_part_slices, dim3(1), dim3(1024), 0, c->stream, pstart, ptotal, (int)n_pairs, b->slice_len, pfirst, slice_lo, slice_hi);
                 HIPCHK(c, hipGetLastError());
                 if ((rc = dbg_sync(c, "k_events<count>/k_part_offsets"))) return rc;
-                launch_events(0, false);                          // every event to its slot (the dwell is in memory now)
+                launch_part_events(0, false);                     // every event to its slot (the dwell is in memory now)
                 hipLaunchKernelGGL(k_part_hist, dim3(pgrid), dim3(256), 0, c->stream, c->d_part, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist);
                 HIPCHK(c, hipGetLastError());
                 if ((rc = dbg_sync(c, "k_events<scatter>/k_part_hist"))) return rc;

@@ -43,7 +43,7 @@ static int grow_slot(sqg_ctx* c, sqg_ctx::Slot& Z, const sqg_batch* b, bool with
         HIPCHK(c, hipMalloc(&Z.d_sigoff, cap * sizeof(long long)));
         Z.reads_cap = cap;
     }
-    if ((rc2 = ensure(c, (void**)&Z.d_dwell, &Z.dwell_cap, (size_t)b->n_events + 64, sizeof(uint16_t)))) return rc2;
+    if ((rc2 = ensure(c, (void**)&Z.d_dwell, &Z.dwell_cap, (size_t)b->n_events + 1024, sizeof(uint16_t)))) return rc2;
     if ((rc2 = ensure(c, (void**)&Z.d_evrec, &Z.evrec_cap, (size_t)b->n_events + 64, sizeof(uint2)))) return rc2;
     if (b->part && (rc2 = ensure(c, (void**)&Z.d_part_state, &Z.part_state_cap, (size_t)b->n_events + PART_SLACK, sizeof(uint32_t)))) return rc2;
     if ((rc2 = ensure(c, (void**)&Z.d_tile_so, &Z.tile_cap, (size_t)b->n_tiles + 64, sizeof(uint32_t)))) return rc2;
@@ -176,7 +176,9 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         if (c->use_kmer_streams && want) {
             const size_t row_bytes = (size_t)c->num_kmer * sizeof(uint32_t);
             const bool part_ok = c->num_kmer > 4096 && c->num_kmer <= PART_MAX * PART_SUB && nev < 4294967000LL && !getenv("SQG_NO_PART");   // bucketed hand-out (below): no per-link rows
-            long long target = forced > 0 ? forced : part_ok ? 4096 : 2048;
+            // (bucketed hand-out: a link is one wavefront of k_part_events -- 8 per SIMD; one workgroup of k_events otherwise)
+            const bool wave_links = part_ok && c->lds_ordered && !(c->cfg.flags & SQG_METH);
+            long long target = forced > 0 ? forced : wave_links ? 8192 : part_ok ? 4096 : 2048;
             if (!part_ok) target = std::min<long long>(target, std::max<long long>(8, (long long)(((size_t)1 << 30) / row_bytes)));
             std::vector<int> link_off(1, 0);
             for (int q = 0; q < n_wchains; q++) {
@@ -208,11 +210,11 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     // (worker chain, partition) are cut into slices of equal length, one workgroup of k_part_hist / k_part_hand each; the
     // slices' 4096-entry tables are what k_part_scan sweeps (SQG_PART_SLICE: events per slice, tests; SQG_NO_PART=1: the
     // per-link rows of round 1, for A/B runs).
-    std::vector<uint32_t> cbase;
+    std::vector<int> link_q;                                     // the worker chain of every link
     if (b->split && c->num_kmer > 4096 && c->num_kmer <= PART_MAX * PART_SUB && nev < 4294967000LL && !getenv("SQG_NO_PART")) {   // (= part_ok above)
         const int n_part = (c->num_kmer + PART_SUB - 1) >> PART_SUB_BITS;
-        long long at = 0;
-        for (int q = 0; q < n_wchains; q++) { cbase.push_back((uint32_t)at); at += wchain_ev[(size_t)q]; }
+        link_q.assign((size_t)b->n_chains, 0);
+        for (int q = 0; q < n_wchains; q++) for (int l = wlink_off[(size_t)q]; l < wlink_off[(size_t)q + 1]; l++) link_q[(size_t)l] = q;
         const char* senv = getenv("SQG_PART_SLICE");
         // at most 4096 slices (a whole number of rounds of 4 wavefronts per CU for k_part_hand_ord), whole steps of the hand-out
         const long long n_pairs = (long long)n_wchains * n_part, want = std::max<long long>(1024, 4096 - n_pairs);
@@ -311,9 +313,9 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
                      o_crd = carve(std::max<size_t>(1, chain_reads.size()) * sizeof(int)),
                      o_ord = carve(std::max<size_t>(1, chain_order.size()) * sizeof(int)),
                      o_wlo = carve(wlink_off.size() * sizeof(int)), o_wlw = carve(std::max<size_t>(1, wlink_worker.size()) * sizeof(int)),
-                     o_cb = carve(std::max<size_t>(1, cbase.size()) * sizeof(uint32_t));
+                     o_cb = carve(std::max<size_t>(1, link_q.size()) * sizeof(int));
         meta_bytes = off;
-        const size_t o_bases = carve((size_t)nb + 16),
+        const size_t o_bases = carve((size_t)nb + 1024),        // (k_part_events reads a whole segment + halo from a read's last segment on)
                      o_st = carve((size_t)std::max<long long>(nst, 1) * sizeof(int)), o_t = carve((size_t)std::max<long long>(ntile, 1) * sizeof(int));
         mo_err = o_err; mo_reads = o_reads; mo_blk = o_blk; mo_coff = o_coff; mo_crd = o_crd; mo_ord = o_ord; mo_wlo = o_wlo; mo_wlw = o_wlw; mo_cb = o_cb;
         // a freed batch's block, pinned offsets and events are reused when they are large enough
@@ -345,7 +347,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         b->d_chain_off = (int*)(base + o_coff); b->d_chain_reads = (int*)(base + o_crd); b->d_stile_read = (int*)(base + o_st);
         b->d_tile_read = (int*)(base + o_t); b->d_chain_order = (int*)(base + o_ord);
         b->d_wlink_off = (int*)(base + o_wlo); b->d_wlink_worker = (int*)(base + o_wlw);
-        b->d_cbase = (uint32_t*)(base + o_cb);
+        b->d_link_q = (int*)(base + o_cb);
     }
     {   // the host-built arrays -> pinned mirror -> one asynchronous copy
         uint8_t* m = b->h_meta;
@@ -360,7 +362,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
             memcpy(m + mo_wlw, wlink_worker.data(), wlink_worker.size() * sizeof(int));
         }
         if (b->part) {
-            memcpy(m + mo_cb, cbase.data(), cbase.size() * sizeof(uint32_t));
+            memcpy(m + mo_cb, link_q.data(), link_q.size() * sizeof(int));
         }
         CHKB(hipMemcpyAsync(b->d_block, m, meta_bytes, hipMemcpyHostToDevice, c->stage_stream));
     }

@@ -221,7 +221,9 @@ struct SigParams {
     uint32_t* part_state;        // [n_events] same slots (k_part_hand): the stream's state at the event's first draw; non-null tells
                                  // the sample kernels that evrec.x is a slot, not a state
     uint32_t* pcnt;              // [n_links][n_part] events per (link, partition)
-    const uint32_t* poff;        // [n_links][n_part] first slot in part[] of the link's events of the partition (k_part_offsets)
+    const uint32_t* poff;        // [n_links][n_part] first slot in part[] of the link's events of the partition, relative to pstart (k_part_offsets)
+    const uint32_t* pstart;      // [n_wchains][n_part] first slot of the (worker chain, partition) (k_part_slices): poff is relative to it
+    const int* link_q;           // [n_links] the worker chain a link belongs to
     int n_part;                  // partitions = num_kmer >> PART_SUB_BITS
 };
 

@@ -24,70 +24,62 @@
 
 // grid (partitions, worker chains), 1024 threads, each with a run of consecutive links of the chain.
 //   wlink_off[q]..wlink_off[q+1]   the links of worker chain q, in chain order
-//   cbase[q]                       first slot of the chain's region in part[]; the region is partition-major
-// poff[l][p] <- first slot of link l's events of partition p; pstart/ptotal[q][p] <- the chain's events of partition p in part[]
+// poff[l][p] <- the chain's events of partition p before link l; ptotal[q][p] <- all of them
 __global__ __launch_bounds__(1024) void k_part_offsets(const uint32_t* __restrict__ pcnt, uint32_t* __restrict__ poff, const int n_part,
-                                                       const int* __restrict__ wlink_off, const uint32_t* __restrict__ cbase,
-                                                       uint32_t* __restrict__ pstart, uint32_t* __restrict__ ptotal) {
-    __shared__ uint32_t wsum[16], wlow[16];
+                                                       const int* __restrict__ wlink_off, uint32_t* __restrict__ ptotal) {
+    __shared__ uint32_t wsum[16];
     const int p = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l0 = wlink_off[q], l1 = wlink_off[q + 1];
     const int per = (l1 - l0 + 1023) / 1024, la = min(l0 + tid * per, l1), lb = min(la + per, l1);
-    uint32_t own = 0, lower = 0;                                  // my links' events of partition p / of the partitions below p
-    for (int l = la; l < lb; l++) {
-        const uint32_t* row = pcnt + (size_t)l * n_part;
-        own += row[p];
-        for (int pp = 0; pp < p; pp++) lower += row[pp];
-    }
-    uint32_t incl = (uint32_t)wave_incl_scan_dpp((int)own);
-    for (int o = 32; o > 0; o >>= 1) lower += __shfl_xor(lower, o);
+    uint32_t own = 0;                                             // my links' events of partition p
+    for (int l = la; l < lb; l++) own += pcnt[(size_t)l * n_part + p];
+    const uint32_t incl = (uint32_t)wave_incl_scan_dpp((int)own);
     if (lane == 63) wsum[wid] = incl;
-    if (lane == 0) wlow[wid] = lower;
     __syncthreads();
-    uint32_t start = cbase[q], before = 0, total = 0;             // start: first slot of (chain, partition)
-    for (int w = 0; w < 16; w++) { start += wlow[w]; if (w < wid) before += wsum[w]; total += wsum[w]; }
-    uint32_t at = start + before + incl - own;
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < 16; w++) { if (w < wid) before += wsum[w]; total += wsum[w]; }
+    uint32_t at = before + incl - own;
     for (int l = la; l < lb; l++) {
         const uint32_t cnt = pcnt[(size_t)l * n_part + p];
         poff[(size_t)l * n_part + p] = at;
         at += cnt;
     }
-    if (tid == 0) { pstart[(size_t)q * n_part + p] = start; ptotal[(size_t)q * n_part + p] = total; }
+    if (tid == 0) ptotal[(size_t)q * n_part + p] = total;
 }
 
 // The events of a (worker chain, partition) lie in part[] in the order the chain produces them; the hand-out walks them in that
 // order, and any cut of the run is as good as any other: it is cut into SLICES of slice_len events (the last one shorter), so
 // that a partition with many events (k-mers of poly-A tails, adaptors, satellite repeats) is simply more slices, not a longer one.
-// One workgroup: pfirst[pair] <- the pair's first slice (pair = chain * n_part + partition; pfirst[n_pairs] = number of slices),
-// slice_lo/hi[s] <- the slots of slice s.  The host sized the tables for n_events / slice_len + n_pairs slices.
-__global__ __launch_bounds__(1024) void k_part_slices(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ ptotal, const int n_pairs,
+// One workgroup: pstart[pair] <- the pair's first slot in part[] (pair = chain * n_part + partition: part[] is chain-major, then
+// partition-major), pfirst[pair] <- its first slice (pfirst[n_pairs] = number of slices), slice_lo/hi[s] <- the slots of slice s.  The host sized the tables for n_events / slice_len + n_pairs slices.
+__global__ __launch_bounds__(1024) void k_part_slices(uint32_t* __restrict__ pstart, const uint32_t* __restrict__ ptotal, const int n_pairs,
                                                       const uint32_t slice_len, uint32_t* __restrict__ pfirst,
                                                       uint32_t* __restrict__ slice_lo, uint32_t* __restrict__ slice_hi) {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry;
+    __shared__ uint32_t wsum[16], wtot[16];
+    __shared__ uint32_t carry, carry_ev;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry = 0;
+    if (tid == 0) { carry = 0; carry_ev = 0; }
     __syncthreads();
     for (int base = 0; base < n_pairs; base += 1024) {
         const int i = base + tid;
         const uint32_t tot = i < n_pairs ? ptotal[i] : 0u;
         const uint32_t ns = (tot + slice_len - 1) / slice_len;
-        const uint32_t incl = (uint32_t)wave_incl_scan_dpp((int)ns);
-        if (lane == 63) wsum[wid] = incl;
+        const uint32_t incl = (uint32_t)wave_incl_scan_dpp((int)ns), incl_ev = (uint32_t)wave_incl_scan_dpp((int)tot);
+        if (lane == 63) { wsum[wid] = incl; wtot[wid] = incl_ev; }
         __syncthreads();
-        uint32_t first = carry;
-        for (int w = 0; w < wid; w++) first += wsum[w];
-        first += incl - ns;
+        uint32_t first = carry, st = carry_ev;                     // the pair's first slice / first slot: the pairs lie in part[] in pair order
+        for (int w = 0; w < wid; w++) { first += wsum[w]; st += wtot[w]; }
+        first += incl - ns; st += incl_ev - tot;
         if (i < n_pairs) {
             pfirst[i] = first;
-            const uint32_t st = pstart[i];
+            pstart[i] = st;
             for (uint32_t s = 0; s < ns; s++) {
                 slice_lo[first + s] = st + s * slice_len;
                 slice_hi[first + s] = st + min((s + 1) * slice_len, tot);
             }
         }
         __syncthreads();
-        if (tid == 1023) carry = first + ns;
+        if (tid == 1023) { carry = first + ns; carry_ev = st + tot; }
         __syncthreads();
     }
     if (tid == 0) pfirst[n_pairs] = carry;

@@ -1,0 +1,292 @@
+// k_part_events.h -- k > 6 (7- to 9-mer tables), few workers: the two event passes of the bucketed hand-out, one wavefront per link
+// Part of the device code of the per-read signal path; included through sqg_kernels.h (see there for the overview).
+//
+// With the hand-out left to k_part_hist / k_part_scan / k_part_hand (k_part.h) an event pass has nothing sequential left but
+// the sample offsets inside a read: a link (a few whole reads of a worker chain) is walked by ONE wavefront, the links of a
+// workgroup share nothing but two read-only tables, and there is no workgroup barrier after the set-up.  A read is walked in
+// segments of 512 events; event 64 q + lane of the segment is the lane's q-th, so that an LDS atomic issued per q sees the
+// segment's events in event order (instruction order, then lane order: what k_lds_order_check certifies on the device).
+//
+//   COUNT   (first pass)  dwell draws (src/gensig.c:254-257) -> dwell[], per-read sample totals, first sample of every 64-event
+//           tile; k-mer ranks; events per (link, partition) -> pcnt
+//   SCATTER (second pass) ranks again, dwell from memory; slot = fetch-add on the (link, partition)'s next slot -- stable by the
+//           order above; the records {dwell, low 12 bits of the rank} wait in per-partition rings in LDS until a whole 64-B line
+//           of part[] can be written (a partition gets 8 of a segment's 512 events: written as they come, every line of part[]
+//           would be written in pieces, which costs the memory system 1.5x the time: measured); evrec = {slot, rank}
+//
+// The k-mer ranks come from the segment's bases packed two bits each, first base in the top bits of a 32-bit word (src/seq.h:31-42
+// puts the first base in the top digits of the rank): an event's rank is a 2k-bit window of two consecutive words -- one
+// two-word LDS read, one 64-bit shift.
+// k_events<.., PART> (k_events.h) does the same with a workgroup per link and lane masks instead of ordered atomics; it stays for
+// the 5-letter methylation alphabet and for devices that do not pass the order check.
+#pragma once
+
+#ifndef PEV_EPL
+#define PEV_EPL 8                        // events per lane and segment (a multiple of 4)
+#endif
+#define PEV_SEG (64 * PEV_EPL)           // events per segment
+#define PEV_WAVES 4                      // links (wavefronts) per workgroup, first pass
+#define PEV_WAVES_SCATTER 2              // ... second pass (10 KiB of LDS per link)
+#define PEV_HALO 24                      // bases behind the segment's own: 2 (k - 1) <= 16 (the k-mers of the RNA stall start k - 1 bases further on)
+#define PEV_WORDS ((PEV_SEG + PEV_HALO) / 16 + 2)
+
+#define PEV_RING 32                      // slots a partition's ring holds: two 64-B lines of part[]
+#define PEV_LINE 16                      // slots per 64-B line
+#define PEV_TASKS (3 * PART_MAX)
+#define PEV_FLUSH_IT 10                  // lines / 4 a segment's flush always writes (more: a loop)
+template <bool SCATTER>
+struct PevWave {
+    uint32_t codes[PEV_WORDS];           // the segment's 2-bit base codes, 16 per word, first base in the top bits
+    uint32_t wslot[PART_MAX];            // COUNT: the link's events per partition so far; SCATTER: the partition's next slot in part[]
+    // SCATTER: a partition's records wait in its ring (slot s at ring[p][s % 32]) until a whole 64-B line of part[] can be written
+    uint32_t flu[SCATTER ? PART_MAX : 1];                // first slot of the partition not yet written to part[]
+    uint32_t ring[SCATTER ? PART_MAX * PEV_RING : 1];    // (a segment that does not fit the rings borrows them as its sort buffer)
+    uint2 tasks[SCATTER ? PEV_TASKS : 1];                // lines to write: {line, partition | first element << 8 | end element << 16}
+};
+template <bool SCATTER>
+struct PevLds {
+    uint32_t jump[256];                  // a^(2j)
+    uint8_t lut[256];                    // base -> 2-bit code (src/seq.h:14-27)
+    PevWave<SCATTER> w[SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES];
+};
+
+// sum over the wavefront, in every lane's SGPR-to-be
+__device__ static inline int pev_wave_sum(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_dpp(v), 63); }
+
+// DW as in k_events: 0 = dwell from memory (or constant), 1 = drawn here, certified fp32 path, 2 = drawn here in FP64.
+// grid: ceil(links / waves per workgroup).  dump: first of 64 slots behind part[]'s last (a flush without a line writes there)
+template <int DW, bool SCATTER>
+__global__ __launch_bounds__(64 * (SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES)) void k_part_events(const SigParams P, const int n_links, const uint32_t dump) {
+    constexpr int NWV = SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES;
+    static_assert(!SCATTER || DW == 0, "the second pass reads the dwells the first one drew");
+    __shared__ PevLds<SCATTER> L;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < 256; i += 64 * NWV) { L.jump[i] = P.pw[2 * POW_N + i]; L.lut[i] = (uint8_t)base_code((uint8_t)i); }
+    __syncthreads();
+    const int li = blockIdx.x * NWV + wid;
+    if (li >= n_links) return;                                    // (no barrier below)
+    PevWave<SCATTER>& W = L.w[wid];
+    const int chain = P.chain_order[li];
+    const int c_lo = P.chain_off[chain], c_hi = P.chain_off[chain + 1];
+    const int k = P.k;
+    const uint32_t kmask = (1u << (2 * k)) - 1u;                  // (k <= 9 here)
+    W.wslot[lane] = (SCATTER && lane < P.n_part) ? P.poff[(size_t)chain * P.n_part + lane] + P.pstart[(size_t)P.link_q[chain] * P.n_part + lane] : 0u;
+    if (SCATTER) W.flu[lane] = W.wslot[lane];
+    // SCATTER: the slots [a, b) of lane p's partition go from the ring to part[], 64-B line by line (whole lines but for a link's
+    // first and last): every lane lists its lines, then 16 lanes write one line each
+    auto flush = [&](const uint32_t a, const uint32_t b) {
+        const int nl = b > a ? (int)(((b - 1) >> 4) - (a >> 4)) + 1 : 0;      // <= 3: the ring holds 32 slots
+        const int incl = wave_incl_scan_dpp(nl);
+        const int n_task = __builtin_amdgcn_readlane(incl, 63);
+        const int at = incl - nl;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (i < nl) {
+                const uint32_t line = (a >> 4) + (uint32_t)i;
+                const uint32_t lo_e = i == 0 ? (a & 15u) : 0u, hi_e = i == nl - 1 ? ((b - 1) & 15u) + 1u : 16u;
+                W.tasks[at + i] = make_uint2(line, (uint32_t)lane | lo_e << 8 | hi_e << 16);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        // PEV_FLUSH_IT store instructions whatever the number of lines (a segment completes 32 on average): the compiler can then
+        // count the stores between a prefetch and its use, and waits for the prefetch only (a wavefront's loads and stores retire in
+        // order).  A lane without an element of its own repeats a neighbour's store (same address, same value).
+        auto put = [&](const int t) {
+            const uint2 tk = W.tasks[max(min(t, n_task - 1), 0)];
+            const uint32_t e = min(max((uint32_t)lane & 15u, (tk.y >> 8) & 0xffu), (tk.y >> 16) - 1u), sl = tk.x * PEV_LINE + e;
+            const uint32_t v = W.ring[(tk.y & (PART_MAX - 1)) * PEV_RING + (sl & (PEV_RING - 1))];
+            P.part[n_task > 0 ? sl : dump + (uint32_t)lane] = v;
+        };
+#pragma unroll
+        for (int it = 0; it < PEV_FLUSH_IT; it++) put(4 * it + (lane >> 4));
+        for (int t0 = 4 * PEV_FLUSH_IT; t0 < n_task; t0 += 4) put(t0 + (lane >> 4));
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    };
+    const uint32_t a2seg = DW ? lcg_jump2(P.pw, (uint32_t)PEV_SEG) : 0u, a2half = DW ? lcg_jump2(P.pw, 256u) : 0u;
+    const float dw_sf = (float)P.dstd, dw_mf = (float)P.dmean;
+    const float dw_eps = P.delta_x * fabsf(dw_sf) + 4.0f * 5.9604645e-8f * (fabsf(dw_mf) + 7.0f * fabsf(dw_sf) + 1.0f) + 1e-6f;   // as in k_events
+
+    for (int ci = c_lo; ci < c_hi; ci++) {
+        const int r = P.chain_reads[ci];
+        const ReadDesc rd = P.reads[r];
+        const int ne = rd.ne0 + rd.ne1;
+        const uint8_t* rbases = P.bases + rd.base_off;
+        const int shift1 = rd.len0 - rd.ne0;                      // base of event e >= ne0: e + shift1 (src/genread.c:87-88)
+        unsigned long long done = 0;                              // samples before this segment
+        long long n1 = -1;                                        // samples of the read's first part (read + prefix), once known
+        uint32_t c_seg = DW ? (uint32_t)__builtin_amdgcn_readfirstlane((int)lcg_mul(rd.time_c0, LCG_A)) : 0u;   // a * (time-stream state at the segment's first event)
+        // a segment's inputs: 8 base bytes per lane (+ the halo in three lanes), SCATTER: 8 dwells per lane.  The next segment's are
+        // requested BEFORE this segment's stores are issued: a wavefront's loads and stores retire in order (one vmcnt), so a load
+        // issued behind the stores would wait for them as well
+        // (unconditional: the batch's base buffer ends with 1 KiB of slack; what lies behind a read's last base only reaches the
+        // ranks of events that do not exist)
+        auto load8 = [&](const int bi) -> unsigned long long {
+            unsigned long long v;
+            __builtin_memcpy(&v, rbases + bi, 8);
+            return v;
+        };
+        unsigned long long b_cur = 0, b_halo = 0;
+        uint16_t d_cur[PEV_EPL];
+        auto fetch = [&](const int s) {
+            const int bs = s + (s >= rd.ne0 ? shift1 : 0);
+            b_cur = load8(bs + 8 * lane);
+            if (lane < PEV_HALO / 8) b_halo = load8(bs + PEV_SEG + 8 * lane);
+            if (DW == 0 && P.dwell) {
+#pragma unroll
+                for (int q = 0; q < PEV_EPL; q++) d_cur[q] = P.dwell[rd.ev_off + s + 64 * q + lane];   // (unconditional: the array ends with slack)
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < PEV_EPL; q++) d_cur[q] = 0;
+        if (ne > 0) fetch(0);
+        // (these loads have landed before the loop: a use inside it then only waits for the prefetch of the iteration before, which
+        // has this segment's stores behind it -- the compiler counts them -- instead of for everything in flight)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
+        // One segment.  FULL: every event of the segment exists (all but a read's last segment): no per-lane tests, no masked stores
+        #define PEV_IN(j_) (FULL || (j_) < n_seg)
+        auto segment = [&](auto full_tag, const int s0) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            const int n_seg = FULL ? PEV_SEG : ne - s0;
+            const bool second = s0 >= rd.ne0;                     // the whole segment lies in the read's second part
+            // ---- the segment's bases, packed
+            {
+                auto pack8 = [&](const unsigned long long v) -> uint32_t {
+                    uint32_t h = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) h = (h << 2) | L.lut[(uint32_t)(v >> (8 * i)) & 0xffu];
+                    return h;
+                };
+                // lane l: bases 8l .. 8l+7 -> one 16-bit half; the first of two halves is the word's upper one
+                reinterpret_cast<uint16_t*>(W.codes)[lane ^ 1] = (uint16_t)pack8(b_cur);
+                if (lane < PEV_HALO / 8) reinterpret_cast<uint16_t*>(W.codes)[(64 + lane) ^ 1] = (uint16_t)pack8(b_halo);
+            }
+            int sps[PEV_EPL];
+#pragma unroll
+            for (int q = 0; q < PEV_EPL; q++) sps[q] = (DW == 0) ? (PEV_IN(64 * q + lane) ? (P.dwell ? (int)d_cur[q] : P.const_sps) : 0) : 0;
+            if (s0 + PEV_SEG < ne) fetch(s0 + PEV_SEG);
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            // ---- ranks
+            uint32_t rank[PEV_EPL];
+#pragma unroll
+            for (int q = 0; q < PEV_EPL; q++) {
+                const int j = 64 * q + lane;
+                const int cb = j + ((!second && s0 + j >= rd.ne0) ? shift1 : 0);
+                const uint32_t hi = W.codes[cb >> 4], lo = W.codes[(cb >> 4) + 1];
+                rank[q] = (uint32_t)(((unsigned long long)hi << 32 | lo) >> (64 - 2 * (cb & 15) - 2 * k)) & kmask;
+            }
+            // ---- dwells
+            uint32_t c_blk[PEV_EPL / 4];                              // ... at the segment's 256th, 512th, ... event (scalar)
+            c_blk[0] = c_seg;
+#pragma unroll
+            for (int h = 1; h < PEV_EPL / 4; h++) c_blk[h] = DW ? (uint32_t)__builtin_amdgcn_readfirstlane((int)lcg_mul(c_blk[h - 1], a2half)) : 0u;
+#pragma unroll
+            for (int q = 0; q < PEV_EPL; q++) {
+                const int j = 64 * q + lane;
+                const bool valid = PEV_IN(j);
+                if (DW != 0 && valid) {
+                    // event s0 + j uses draws 2j+1, 2j+2 of the time stream after the segment's first state
+                    const uint32_t c1 = lcg_mul(c_blk[q >> 2], L.jump[64 * (q & 3) + lane]);
+                    bool decided = false;
+                    int v = 0;
+                    if (DW == 1) {
+                        const float x = box_muller_fast(c1);
+                        const float g = __builtin_fmaf(x, dw_sf, dw_mf);
+                        const float t = g + LEAN_MAGIC;              // |g| < 2^22: the host takes the FP64 variant (DW 2) when dwell_hi >= 1e6
+                        const float fl = t - LEAN_MAGIC;
+                        if (fabsf(g - fl) < 0.5f - dw_eps && c1 <= LCG_M - (1u << NEAR_ONE_BITS)) { v = (int)__float_as_uint(t) - 0x4b400000; decided = true; }
+                    }
+                    if (!decided) v = dwell_exact(c1, P.dstd, P.dmean);      // src/gensig.c:255
+                    v = max(v, 1 - v);                                       // src/gensig.c:256
+                    if (P.dwell_unbounded && v > 65535) { atomicOr(P.err, 1u); v = 65535; }
+                    sps[q] = v;
+                    P.dwell_out[rd.ev_off + s0 + j] = (uint16_t)v;
+                }
+            }
+            if (DW) c_seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)lcg_mul(c_seg, a2seg));
+            if (!SCATTER) {
+                // ---- first sample of every 64-event tile, the read's totals, events per partition
+                uint32_t run = 0;
+#pragma unroll
+                for (int q = 0; q < PEV_EPL; q++) {
+                    const int e_q = s0 + 64 * q;                      // (wave-uniform)
+                    if (e_q < ne) {
+                        if (lane == 0) P.tile_so[rd.tile_off + (e_q >> 6)] = (uint32_t)done + run;
+                        if (rd.ne1 > 0 && rd.ne0 >= e_q && rd.ne0 < e_q + 64)       // the second part starts in this tile
+                            n1 = (long long)done + run + pev_wave_sum(lane < rd.ne0 - e_q ? sps[q] : 0);
+                        run += (uint32_t)pev_wave_sum(sps[q]);
+                        if (PEV_IN(64 * q + lane)) atomicAdd(&W.wslot[rank[q] >> PART_SUB_BITS], 1u);
+                    }
+                }
+                done += run;
+            } else {
+                // ---- slots, stable in event order
+                const uint32_t start = W.wslot[lane], flu = W.flu[lane];
+                uint32_t slot[PEV_EPL];
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < PEV_EPL; q++) {
+                    slot[q] = 0;
+                    if (PEV_IN(64 * q + lane)) slot[q] = __hip_atomic_fetch_add(&W.wslot[rank[q] >> PART_SUB_BITS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    asm volatile("" ::: "memory");                    // (the compiler keeps the atomics in this order)
+                }
+                const uint32_t end = W.wslot[lane];
+#pragma unroll
+                for (int q = 0; q < PEV_EPL; q++) {
+                    if (PEV_IN(64 * q + lane))
+                        __builtin_nontemporal_store(((unsigned long long)rank[q] << 32) | slot[q], reinterpret_cast<unsigned long long*>(P.evrec + rd.ev_off + s0 + 64 * q + lane));
+                }
+                if (__builtin_amdgcn_ballot_w64(end - flu > (uint32_t)PEV_RING) == 0ull) {
+                    // the records join their partitions' rings; what completes a line of part[] goes out
+#pragma unroll
+                    for (int q = 0; q < PEV_EPL; q++) {
+                        if (PEV_IN(64 * q + lane))
+                            W.ring[(rank[q] >> PART_SUB_BITS) * PEV_RING + (slot[q] & (PEV_RING - 1))] = (rank[q] & (PART_SUB - 1)) | ((uint32_t)sps[q] << 16);
+                    }
+                    const uint32_t upto = max(flu, end & ~(uint32_t)(PEV_LINE - 1));
+                    W.flu[lane] = upto;
+                    flush(flu, upto);
+                } else {
+                    // a partition with more events in this segment than its ring holds (homopolymers, adaptors): the rings are
+                    // written out as they stand, and the segment's records go out sorted by partition, a run per partition
+                    flush(flu, start);
+                    W.flu[lane] = end;
+                    uint2* const sorted = reinterpret_cast<uint2*>(W.ring);      // {slot, record}, PEV_SEG of them
+                    uint2* const segbase = W.tasks;                               // per partition: {first slot in this segment, position of its run}
+                    const uint32_t cnt = end - start;
+                    segbase[lane] = make_uint2(start, (uint32_t)wave_incl_scan_dpp((int)cnt) - cnt);
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < PEV_EPL; q++) {
+                        if (PEV_IN(64 * q + lane)) {
+                            const uint2 sb = segbase[rank[q] >> PART_SUB_BITS];
+                            sorted[sb.y + (slot[q] - sb.x)] = make_uint2(slot[q], (rank[q] & (PART_SUB - 1)) | ((uint32_t)sps[q] << 16));
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int q = 0; q < PEV_EPL; q++) {
+                        if (PEV_IN(64 * q + lane)) { const uint2 v = sorted[64 * q + lane]; P.part[v.x] = v.y; }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    asm volatile("" ::: "memory");
+                }
+            }
+        };
+        #undef PEV_IN
+        for (int s0 = 0; s0 < ne; s0 += PEV_SEG) {
+            if (s0 + PEV_SEG <= ne) segment(std::true_type{}, s0); else segment(std::false_type{}, s0);
+        }
+        if (!SCATTER && lane == 0 && DW) {
+            const long long tot = (long long)done;
+            P.seglen_out[2 * r] = (unsigned long long)(n1 >= 0 ? n1 : tot);
+            P.seglen_out[2 * r + 1] = (unsigned long long)(tot - (n1 >= 0 ? n1 : tot));
+        }
+    }
+    if (SCATTER) flush(W.flu[lane], W.wslot[lane]);                 // what is left in the rings: each partition's last, partial line
+    if (!SCATTER && lane < P.n_part) P.pcnt[(size_t)chain * P.n_part + lane] = W.wslot[lane];
+}

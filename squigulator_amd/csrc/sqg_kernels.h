@@ -1,5 +1,5 @@
 // sqg_kernels.h -- gfx950 device code of the per-read signal path (included by sqg_hip.hip); the kernels live in
-// k_common.h, k_events.h, k_samples.h, k_sampler.h and k_svb.h.
+// k_common.h, k_events.h, k_part.h, k_part_events.h, k_samples.h, k_sampler.h and k_svb.h.
 //
 //   k_init_rows   per-(worker,k-mer) stream seeds                       (src/sim.c:238-257)
 //   k_dwell       per-event dwell draw from the worker's time stream   (src/gensig.c:254-257)
@@ -29,6 +29,7 @@
 #include "k_common.h"
 #include "k_events.h"
 #include "k_part.h"
+#include "k_part_events.h"
 #include "k_samples.h"
 #include "k_sampler.h"
 #include "k_svb.h"
