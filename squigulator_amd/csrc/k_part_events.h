@@ -26,6 +26,9 @@
 #endif
 #define PEV_SEG (64 * PEV_EPL)           // events per segment
 #define PEV_WAVES 4                      // links (wavefronts) per workgroup, first pass
+#ifndef PEV_COUNT_OCC
+#define PEV_COUNT_OCC 1                  // first pass: wavefronts per SIMD the register allocation aims at
+#endif
 #define PEV_WAVES_SCATTER 2              // ... second pass (10 KiB of LDS per link)
 #define PEV_HALO 24                      // bases behind the segment's own: 2 (k - 1) <= 16 (the k-mers of the RNA stall start k - 1 bases further on)
 #define PEV_WORDS ((PEV_SEG + PEV_HALO) / 16 + 2)
@@ -56,7 +59,7 @@ __device__ static inline int pev_wave_sum(int v) { return __builtin_amdgcn_readl
 // DW as in k_events: 0 = dwell from memory (or constant), 1 = drawn here, certified fp32 path, 2 = drawn here in FP64.
 // grid: ceil(links / waves per workgroup).  dump: first of 64 slots behind part[]'s last (a flush without a line writes there)
 template <int DW, bool SCATTER>
-__global__ __launch_bounds__(64 * (SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES)) void k_part_events(const SigParams P, const int n_links, const uint32_t dump) {
+__global__ __launch_bounds__(64 * (SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES), SCATTER ? 1 : PEV_COUNT_OCC) void k_part_events(const SigParams P, const int n_links, const uint32_t dump) {
     constexpr int NWV = SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES;
     static_assert(!SCATTER || DW == 0, "the second pass reads the dwells the first one drew");
     __shared__ PevLds<SCATTER> L;

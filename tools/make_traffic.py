@@ -32,7 +32,7 @@ for kn, d in acc.items():
     short = kn.split("(")[0].split("<")[0].replace("void ", "").strip()
     if not short.startswith("k_"):
         continue
-    if short == "k_events":                                # several instantiations per batch (count / scatter passes): keep them apart
+    if short in ("k_events", "k_part_events"):             # several instantiations per batch (count / scatter passes): keep them apart
         short = kn.split("(")[0].replace("void ", "").strip()
     f = sum(d.get("FETCH_SIZE", [0])) / max(len(d.get("FETCH_SIZE", [0])), 1)
     w = sum(d.get("WRITE_SIZE", [0])) / max(len(d.get("WRITE_SIZE", [0])), 1)

@@ -22,9 +22,9 @@ tr = os.path.join(src, "trace_kernel_trace.csv")
 if os.path.exists(tr):
     per = collections.defaultdict(list)
     for r in csv.DictReader(open(tr)):
-        for key in ("k_samples_lean", "k_events", "k_part_hand", "k_part_hist"):
+        for key in ("k_samples_lean", "k_events", "k_part_events", "k_part_hand", "k_part_hist"):
             if key in r["Kernel_Name"]:
-                if key == "k_events":                      # the counting and the scatter pass are two instantiations
+                if key in ("k_events", "k_part_events"):   # the counting and the scatter pass are two instantiations
                     key = r["Kernel_Name"].split("(")[0].replace("void ", "")
                 per[key].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     bench_line = None
