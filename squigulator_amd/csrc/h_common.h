@@ -116,6 +116,9 @@ struct sqg_batch {
     int* d_wlink_worker = nullptr;       // [n_wchains]
     long long max_wchain_ev = 0;         // events of the longest worker chain
     bool part = false;                   // k > 6, split: the hand-out runs over bucketed events (k_part.h)
+    bool one = false;                    // ... with ONE partition (k <= 6): the events stay in chain order, no counting and no scatter pass
+    uint32_t* d_link_slot = nullptr;     // one: [n_chains] first slot of every link in part[]
+    uint32_t* d_wchain_total = nullptr;  // one: [n_wchains] events of every worker chain
     uint32_t slice_len = 0;              // events per slice of a (worker chain, partition) (k_part.h)
     long long max_slices = 0;            // bound on their number (the device counts them)
     int* d_link_q = nullptr;             // [n_chains] the worker chain of every link (k_part.h)

@@ -142,8 +142,8 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
         CHK(hipEventCreateWithFlags(&S.sampled, hipEventDisableTiming));
         CHK(hipEventRecord(S.done, c->stream2));
     }
-    if (c->use_kmer_streams && c->num_kmer > 4096 && !getenv("SQG_PART_CLAIMS")) {
-        // the bucketed hand-out of k > 6 by ordered LDS atomics: measured on THIS device, not assumed (k_part.h); ~1 ms
+    if (c->use_kmer_streams && !getenv("SQG_PART_CLAIMS")) {
+        // the hand-out over bucketed events by ordered LDS atomics (few workers): measured on THIS device, not assumed (k_part.h); ~1 ms
         unsigned int* d_bad = nullptr;
         CHK(hipMalloc(&d_bad, sizeof(unsigned int)));
         CHK(hipMemset(d_bad, 0, sizeof(unsigned int)));

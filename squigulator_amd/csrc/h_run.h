@@ -63,7 +63,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     SigParams P;
     memset(&P, 0, sizeof P);
     P.link_rows = (b->split && !b->part) ? c->d_link_rows : nullptr;
-    P.part = c->d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = c->d_pcnt; P.poff = c->d_pcnt ? c->d_pcnt + (size_t)b->n_chains * n_part : nullptr; P.n_part = n_part;
+    P.part = c->d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = c->d_pcnt; P.poff = b->one ? b->d_link_slot : c->d_pcnt ? c->d_pcnt + (size_t)b->n_chains * n_part : nullptr; P.n_part = n_part;
     P.link_q = b->d_link_q;
     P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
     P.dwell = c->use_dwell_stream ? S.d_dwell : nullptr; P.dwell_out = S.d_dwell; P.seglen_out = S.d_seglen;
@@ -136,21 +136,35 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         auto launch_part_events = [&](int dwm, bool count) {
             if (!wave_links) { launch_events(dwm, count); return; }
             const dim3 g((unsigned)((b->n_chains + PEV_WAVES - 1) / PEV_WAVES)), t(64 * PEV_WAVES);
-            if (!count) hipLaunchKernelGGL((k_part_events<0, true>), dim3((unsigned)((b->n_chains + PEV_WAVES_SCATTER - 1) / PEV_WAVES_SCATTER)), dim3(64 * PEV_WAVES_SCATTER), 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
-            else if (dwm == 0) hipLaunchKernelGGL((k_part_events<0, false>), g, t, 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
-            else if (dwm == 1) hipLaunchKernelGGL((k_part_events<1, false>), g, t, 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
-            else hipLaunchKernelGGL((k_part_events<2, false>), g, t, 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
+            if (!count) hipLaunchKernelGGL((k_part_events<0, PEV_SCATTER>), dim3((unsigned)((b->n_chains + PEV_WAVES_SCATTER - 1) / PEV_WAVES_SCATTER)), dim3(64 * PEV_WAVES_SCATTER), 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
+            else if (b->one) {                                    // one partition: the only event pass
+                if (dwm == 0) hipLaunchKernelGGL((k_part_events<0, PEV_ONE>), g, t, 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
+                else if (dwm == 1) hipLaunchKernelGGL((k_part_events<1, PEV_ONE>), g, t, 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
+                else hipLaunchKernelGGL((k_part_events<2, PEV_ONE>), g, t, 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
+            }
+            else if (dwm == 0) hipLaunchKernelGGL((k_part_events<0, PEV_COUNT>), g, t, 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
+            else if (dwm == 1) hipLaunchKernelGGL((k_part_events<1, PEV_COUNT>), g, t, 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
+            else hipLaunchKernelGGL((k_part_events<2, PEV_COUNT>), g, t, 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
         };
         if (b->part) {
             // k > 6, split chains: the hand-out over events bucketed by the top bits of the rank (k_part.h)
             if (phase != 2) {
                 launch_part_events(dw, true);                     // dwell draws; events per (link, partition)
-                hipLaunchKernelGGL(k_part_offsets, dim3((unsigned)n_part, (unsigned)b->n_wchains), dim3(1024), 0, c->stream, c->d_pcnt,
-                                   c->d_pcnt + (size_t)b->n_chains * n_part, n_part, b->d_wlink_off, ptotal);
-                hipLaunchKernelGGL(k_part_slices, dim3(1), dim3(1024), 0, c->stream, pstart, ptotal, (int)n_pairs, b->slice_len, pfirst, slice_lo, slice_hi);
-                HIPCHK(c, hipGetLastError());
-                if ((rc = dbg_sync(c, "k_events<count>/k_part_offsets"))) return rc;
-                launch_part_events(0, false);                     // every event to its slot (the dwell is in memory now)
+                if (b->one) {
+                    // one partition: the pass above has written part[] in chain order; the slices of every worker chain's events
+                    hipLaunchKernelGGL(k_part_slices, dim3(1), dim3(1024), 0, c->stream, pstart, b->d_wchain_total, (int)n_pairs, b->slice_len, pfirst);
+                    hipLaunchKernelGGL(k_part_slice_bounds, dim3((pgrid + 255) / 256), dim3(256), 0, c->stream, pstart, b->d_wchain_total, (int)n_pairs, b->slice_len, pfirst, slice_lo, slice_hi);
+                    HIPCHK(c, hipGetLastError());
+                    if ((rc = dbg_sync(c, "k_part_events<one>/k_part_slices"))) return rc;
+                } else {
+                    hipLaunchKernelGGL(k_part_offsets, dim3((unsigned)n_part, (unsigned)b->n_wchains), dim3(1024), 0, c->stream, c->d_pcnt,
+                                       c->d_pcnt + (size_t)b->n_chains * n_part, n_part, b->d_wlink_off, ptotal);
+                    hipLaunchKernelGGL(k_part_slices, dim3(1), dim3(1024), 0, c->stream, pstart, ptotal, (int)n_pairs, b->slice_len, pfirst);
+                    hipLaunchKernelGGL(k_part_slice_bounds, dim3((pgrid + 255) / 256), dim3(256), 0, c->stream, pstart, ptotal, (int)n_pairs, b->slice_len, pfirst, slice_lo, slice_hi);
+                    HIPCHK(c, hipGetLastError());
+                    if ((rc = dbg_sync(c, "k_events<count>/k_part_offsets"))) return rc;
+                    launch_part_events(0, false);                 // every event to its slot (the dwell is in memory now)
+                }
                 hipLaunchKernelGGL(k_part_hist, dim3(pgrid), dim3(256), 0, c->stream, c->d_part, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist);
                 HIPCHK(c, hipGetLastError());
                 if ((rc = dbg_sync(c, "k_events<scatter>/k_part_hist"))) return rc;
@@ -161,10 +175,12 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 }
             }
             if (phase != 1) {
-                hipLaunchKernelGGL(k_part_scan, sg, dim3(256), 0, c->stream, c->d_phist, c->d_rows, c->num_kmer, n_part, pfirst, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, b->d_err);
+                if ((size_t)pg.x * pg.y >= 512) hipLaunchKernelGGL(k_part_scan<64>, pg, dim3(1024), 0, c->stream, c->d_phist, c->d_rows, c->num_kmer, n_part, pfirst, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, direct ? 1 : 0, b->d_err);
+                else hipLaunchKernelGGL(k_part_scan<16>, dim3((unsigned)((c->num_kmer + 15) / 16), (unsigned)b->n_wchains), dim3(1024), 0, c->stream, c->d_phist, c->d_rows, c->num_kmer, n_part, pfirst, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, direct ? 1 : 0, b->d_err);
                 if (before) {                                     // every worker's row moves past the whole batch, all ranges
                     const dim3 ag((unsigned)((n_rows + 255) / 256));
-                    hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
+                    if (direct) hipLaunchKernelGGL(k_rows_advance<true>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
+                    else hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
                 }
                 if (c->lds_ordered) hipLaunchKernelGGL(k_part_hand_ord, dim3(pgrid), dim3(64), 0, c->stream, c->d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow);
                 else if (c->dwell_hi >= (double)PART_JT) hipLaunchKernelGGL(k_part_hand<true>, dim3(pgrid), dim3(64), 0, c->stream, c->d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);

@@ -168,6 +168,10 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     for (int i = 0; i < n; i++) wchain_ev[(size_t)chain_of[(size_t)wk[(size_t)i]]] += rd[(size_t)i].ne0 + rd[(size_t)i].ne1;
     for (long long v : wchain_ev) b->max_wchain_ev = std::max(b->max_wchain_ev, v);
     std::vector<int> wlink_off(1, 0), wlink_worker;
+    // the hand-out over bucketed events (k_part.h) instead of per-link rows: k > 6 (up to PART_MAX partitions of 4096 streams), and
+    // k <= 6 as its one-partition case -- nothing to bucket, the events stay in chain order -- on devices with ordered LDS atomics
+    const bool part_one = c->num_kmer <= PART_SUB && c->lds_ordered && !(c->cfg.flags & SQG_METH) && !getenv("SQG_PART_WG_EVENTS");
+    const bool part_ok = ((c->num_kmer > PART_SUB && c->num_kmer <= PART_MAX * PART_SUB) || part_one) && nev < 4294967000LL && !getenv("SQG_NO_PART");
     {
         const char* env = getenv("SQG_SPLIT_CHAINS");
         const int forced = env ? atoi(env) : -1;
@@ -175,7 +179,6 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         const bool want = c->range_mode ? n > 0 : forced >= 0 ? (forced > 0 && multi) : (multi && n_wchains < 1024 && nev >= 65536);
         if (c->use_kmer_streams && want) {
             const size_t row_bytes = (size_t)c->num_kmer * sizeof(uint32_t);
-            const bool part_ok = c->num_kmer > 4096 && c->num_kmer <= PART_MAX * PART_SUB && nev < 4294967000LL && !getenv("SQG_NO_PART");   // bucketed hand-out (below): no per-link rows
             // (bucketed hand-out: a link is one wavefront of k_part_events -- 8 per SIMD; one workgroup of k_events otherwise)
             const bool wave_links = part_ok && c->lds_ordered && !(c->cfg.flags & SQG_METH);
             long long target = forced > 0 ? forced : wave_links ? 8192 : part_ok ? 4096 : 2048;
@@ -211,7 +214,8 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     // slices' 4096-entry tables are what k_part_scan sweeps (SQG_PART_SLICE: events per slice, tests; SQG_NO_PART=1: the
     // per-link rows of round 1, for A/B runs).
     std::vector<int> link_q;                                     // the worker chain of every link
-    if (b->split && c->num_kmer > 4096 && c->num_kmer <= PART_MAX * PART_SUB && nev < 4294967000LL && !getenv("SQG_NO_PART")) {   // (= part_ok above)
+    std::vector<uint32_t> link_slot, wchain_total;               // one partition: every link's first slot, every worker chain's events
+    if (b->split && part_ok) {
         const int n_part = (c->num_kmer + PART_SUB - 1) >> PART_SUB_BITS;
         link_q.assign((size_t)b->n_chains, 0);
         for (int q = 0; q < n_wchains; q++) for (int l = wlink_off[(size_t)q]; l < wlink_off[(size_t)q + 1]; l++) link_q[(size_t)l] = q;
@@ -225,6 +229,13 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         b->slice_len = (uint32_t)len;
         b->max_slices = (long long)(nev / len) + (long long)n_wchains * n_part;
         b->part = true;
+        b->one = part_one;
+        if (b->one) {                                             // part[] is the worker chains one after the other, each in chain order
+            link_slot.assign((size_t)b->n_chains, 0u);
+            long long at = 0;
+            for (int l = 0; l < b->n_chains; l++) { link_slot[(size_t)l] = (uint32_t)at; at += chain_ev[(size_t)l]; }
+            for (int q = 0; q < n_wchains; q++) wchain_total.push_back((uint32_t)wchain_ev[(size_t)q]);
+        }
     }
     if (c->use_kmer_streams && c->num_kmer > 4096 && !b->part && (double)b->max_wchain_ev * c->dwell_hi >= 4294967295.0 - (double)LCG_ORD2) {
         delete b; c->err = "one worker's reads of a batch may draw more than 3.2e9 samples (k > 6): use smaller batches"; return SQG_EINVAL;
@@ -302,7 +313,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     st_mark("chains+streams+blocks");
     auto bail = [&](int code) { c->time_c = snap_time; c->off_x = snap_off; c->med_x = snap_med; sqg_batch_free(c, b); return code; };
 #define CHKB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE); } } while (0)
-    size_t meta_bytes = 0, mo_err = 0, mo_reads = 0, mo_blk = 0, mo_coff = 0, mo_crd = 0, mo_ord = 0, mo_wlo = 0, mo_wlw = 0, mo_cb = 0;
+    size_t meta_bytes = 0, mo_err = 0, mo_reads = 0, mo_blk = 0, mo_coff = 0, mo_crd = 0, mo_ord = 0, mo_wlo = 0, mo_wlw = 0, mo_cb = 0, mo_ls = 0, mo_wt = 0;
     {   // one device allocation per batch, carved into the batch's arrays (256-byte aligned)
         size_t off = 0;
         auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -313,11 +324,12 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
                      o_crd = carve(std::max<size_t>(1, chain_reads.size()) * sizeof(int)),
                      o_ord = carve(std::max<size_t>(1, chain_order.size()) * sizeof(int)),
                      o_wlo = carve(wlink_off.size() * sizeof(int)), o_wlw = carve(std::max<size_t>(1, wlink_worker.size()) * sizeof(int)),
-                     o_cb = carve(std::max<size_t>(1, link_q.size()) * sizeof(int));
+                     o_cb = carve(std::max<size_t>(1, link_q.size()) * sizeof(int)),
+                     o_ls = carve(std::max<size_t>(1, link_slot.size()) * sizeof(uint32_t)), o_wt = carve(std::max<size_t>(1, wchain_total.size()) * sizeof(uint32_t));
         meta_bytes = off;
         const size_t o_bases = carve((size_t)nb + 1024),        // (k_part_events reads a whole segment + halo from a read's last segment on)
                      o_st = carve((size_t)std::max<long long>(nst, 1) * sizeof(int)), o_t = carve((size_t)std::max<long long>(ntile, 1) * sizeof(int));
-        mo_err = o_err; mo_reads = o_reads; mo_blk = o_blk; mo_coff = o_coff; mo_crd = o_crd; mo_ord = o_ord; mo_wlo = o_wlo; mo_wlw = o_wlw; mo_cb = o_cb;
+        mo_err = o_err; mo_reads = o_reads; mo_blk = o_blk; mo_coff = o_coff; mo_crd = o_crd; mo_ord = o_ord; mo_wlo = o_wlo; mo_wlw = o_wlw; mo_cb = o_cb; mo_ls = o_ls; mo_wt = o_wt;
         // a freed batch's block, pinned offsets and events are reused when they are large enough
         for (size_t pi = 0; pi < c->pool.size(); pi++) {
             sqg_ctx::Recycled& r = c->pool[pi];
@@ -347,7 +359,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         b->d_chain_off = (int*)(base + o_coff); b->d_chain_reads = (int*)(base + o_crd); b->d_stile_read = (int*)(base + o_st);
         b->d_tile_read = (int*)(base + o_t); b->d_chain_order = (int*)(base + o_ord);
         b->d_wlink_off = (int*)(base + o_wlo); b->d_wlink_worker = (int*)(base + o_wlw);
-        b->d_link_q = (int*)(base + o_cb);
+        b->d_link_q = (int*)(base + o_cb); b->d_link_slot = (uint32_t*)(base + o_ls); b->d_wchain_total = (uint32_t*)(base + o_wt);
     }
     {   // the host-built arrays -> pinned mirror -> one asynchronous copy
         uint8_t* m = b->h_meta;
@@ -363,6 +375,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         }
         if (b->part) {
             memcpy(m + mo_cb, link_q.data(), link_q.size() * sizeof(int));
+            if (b->one) { memcpy(m + mo_ls, link_slot.data(), link_slot.size() * sizeof(uint32_t)); memcpy(m + mo_wt, wchain_total.data(), wchain_total.size() * sizeof(uint32_t)); }
         }
         CHKB(hipMemcpyAsync(b->d_block, m, meta_bytes, hipMemcpyHostToDevice, c->stage_stream));
     }

@@ -51,10 +51,9 @@ __global__ __launch_bounds__(1024) void k_part_offsets(const uint32_t* __restric
 // order, and any cut of the run is as good as any other: it is cut into SLICES of slice_len events (the last one shorter), so
 // that a partition with many events (k-mers of poly-A tails, adaptors, satellite repeats) is simply more slices, not a longer one.
 // One workgroup: pstart[pair] <- the pair's first slot in part[] (pair = chain * n_part + partition: part[] is chain-major, then
-// partition-major), pfirst[pair] <- its first slice (pfirst[n_pairs] = number of slices), slice_lo/hi[s] <- the slots of slice s.  The host sized the tables for n_events / slice_len + n_pairs slices.
+// partition-major), pfirst[pair] <- its first slice (pfirst[n_pairs] = number of slices); k_part_slice_bounds: the slots of slice s.  The host sized the tables for n_events / slice_len + n_pairs slices.
 __global__ __launch_bounds__(1024) void k_part_slices(uint32_t* __restrict__ pstart, const uint32_t* __restrict__ ptotal, const int n_pairs,
-                                                      const uint32_t slice_len, uint32_t* __restrict__ pfirst,
-                                                      uint32_t* __restrict__ slice_lo, uint32_t* __restrict__ slice_hi) {
+                                                      const uint32_t slice_len, uint32_t* __restrict__ pfirst) {
     __shared__ uint32_t wsum[16], wtot[16];
     __shared__ uint32_t carry, carry_ev;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -70,19 +69,25 @@ __global__ __launch_bounds__(1024) void k_part_slices(uint32_t* __restrict__ pst
         uint32_t first = carry, st = carry_ev;                     // the pair's first slice / first slot: the pairs lie in part[] in pair order
         for (int w = 0; w < wid; w++) { first += wsum[w]; st += wtot[w]; }
         first += incl - ns; st += incl_ev - tot;
-        if (i < n_pairs) {
-            pfirst[i] = first;
-            pstart[i] = st;
-            for (uint32_t s = 0; s < ns; s++) {
-                slice_lo[first + s] = st + s * slice_len;
-                slice_hi[first + s] = st + min((s + 1) * slice_len, tot);
-            }
-        }
+        if (i < n_pairs) { pfirst[i] = first; pstart[i] = st; }
         __syncthreads();
         if (tid == 1023) { carry = first + ns; carry_ev = st + tot; }
         __syncthreads();
     }
     if (tid == 0) pfirst[n_pairs] = carry;
+}
+
+// one thread per slice (the host's bound): the pair it belongs to by bisection of pfirst, then its slots
+__global__ __launch_bounds__(256) void k_part_slice_bounds(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ ptotal, const int n_pairs,
+                                                           const uint32_t slice_len, const uint32_t* __restrict__ pfirst,
+                                                           uint32_t* __restrict__ slice_lo, uint32_t* __restrict__ slice_hi) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= pfirst[n_pairs]) return;
+    int lo = 0, hi = n_pairs;                                      // the last pair with pfirst <= s (pairs without events share their successor's)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pfirst[mid] <= s) lo = mid; else hi = mid; }
+    const uint32_t k = s - pfirst[lo], st = pstart[lo];
+    slice_lo[s] = st + k * slice_len;
+    slice_hi[s] = st + min((k + 1) * slice_len, ptotal[lo]);
 }
 
 // grid: slices (the host's bound; the live ones are pfirst[n_pairs]), 256 threads.  phist[s][sub] <- samples the slice's events draw from the stream
@@ -95,10 +100,13 @@ __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* __restrict__ 
     for (int i = tid; i < PART_SUB; i += 256) row[i] = 0u;
     __syncthreads();
     const uint32_t lo = slice_lo[blockIdx.x], hi = slice_hi[blockIdx.x];
-    for (uint32_t b = lo; b < hi; b += 1024) {
-        uint32_t rec[4];
+    const uint32_t* in = part + lo + tid;
+    uint32_t rec[4], nxt[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) rec[q] = part[b + 256 * q + tid];        // (unconditional: PART_SLACK entries behind the last slice)
+    for (int q = 0; q < 4; q++) rec[q] = in[256 * q];                        // (unconditional: PART_SLACK entries behind the last slice)
+    for (uint32_t b = lo; b < hi; b += 1024) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) nxt[q] = in[1024 + 256 * q];             // the next step's records are in flight during this one's atomics
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const bool live = b + 256 * q + tid < hi;
@@ -111,41 +119,68 @@ __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* __restrict__ 
                 if ((tid & 63) == 0) atomicAdd(&row[sub], (uint32_t)sum);
             } else if (live) atomicAdd(&row[sub], rec[q] >> 16);
         }
+#pragma unroll
+        for (int q = 0; q < 4; q++) rec[q] = nxt[q];
+        in += 1024;
     }
     __syncthreads();
     uint32_t* dst = phist + (size_t)blockIdx.x * PART_SUB;
     for (int i = tid; i < PART_SUB; i += 256) dst[i] = row[i];
 }
 
-// One thread per (worker chain, rank): exclusive scan of phist over the slices of the rank's partition, in chain order, starting
+// Per (worker chain, rank): exclusive scan of phist over the slices of the rank's partition, in chain order, starting
 // from the worker's row (sample counts, reduced mod (M-1)/2: only that matters for a^(2n)) plus, with range sharding, what the
 // ranges before this one draw (`before`; the row itself is then left to k_rows_advance).  What a slice gets is the stream's STATE
 // as the slice finds it: seed(worker, rank) * a^(2 * samples before), the seed being (seed_base + worker*seed_step + rank) mod M
-// (src/sim.c:249) -- from there on k_part_hand advances states, one modular multiplication per event, as the 6-mer path does.
-// grid (num_kmer / 256, worker chains).
-__global__ __launch_bounds__(256) void k_part_scan(uint32_t* __restrict__ phist, uint32_t* __restrict__ rows, const int num_kmer, const int n_part,
-                                                   const uint32_t* __restrict__ pfirst, const int* __restrict__ wlink_worker,
-                                                   const uint32_t* __restrict__ before, const uint32_t* __restrict__ pw,
-                                                   const uint32_t seed_base, const uint32_t seed_step, unsigned int* __restrict__ err) {
-    const int q = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= num_kmer) return;
+// (src/sim.c:249).  states != 0 (k <= 6): the worker's row holds the streams' states themselves, as every other path of k <= 6
+// keeps them, and moves on by a^(2 * samples of the batch).
+// grid (num_kmer / R, worker chains), 1024 threads: R ranks x 1024 / R runs of consecutive slices (R = 64: 256-B rows of cells per
+// wavefront; R = 16 when that would leave CUs without a workgroup -- one partition with thousands of slices, k <= 6).
+template <int R>
+__global__ __launch_bounds__(1024) void k_part_scan(uint32_t* __restrict__ phist, uint32_t* __restrict__ rows, const int num_kmer, const int n_part,
+                                                    const uint32_t* __restrict__ pfirst, const int* __restrict__ wlink_worker,
+                                                    const uint32_t* __restrict__ before, const uint32_t* __restrict__ pw,
+                                                    const uint32_t seed_base, const uint32_t seed_step, const int states, unsigned int* __restrict__ err) {
+    constexpr int G = 1024 / R;
+    __shared__ unsigned long long sums[G][R];
+    const int lane = threadIdx.x % R, g = threadIdx.x / R, q = blockIdx.y;
+    const int j = blockIdx.x * R + lane;
+    const bool live = j < num_kmer;
+    const int pair = q * n_part + ((blockIdx.x * R) >> PART_SUB_BITS);          // (R consecutive ranks: one partition)
+    const uint32_t s0 = pfirst[pair], s1 = pfirst[pair + 1];
+    const uint32_t per = (s1 - s0 + G - 1) / G, sa = min(s0 + (uint32_t)g * per, s1), sb = min(sa + per, s1);
+    uint32_t* col = phist + (j & (PART_SUB - 1));
+    unsigned long long sum = 0;
+    if (live) for (uint32_t s = sa; s < sb; s++) sum += col[(size_t)s * PART_SUB];
+    sums[g][lane] = sum;
     const int w = wlink_worker[q];
     const size_t wj = (size_t)w * num_kmer + j;
-    const unsigned long long sv = ((unsigned long long)seed_base + (unsigned long long)w * seed_step) % LCG_M + (unsigned long long)j;
-    const uint32_t seed = (uint32_t)(sv >= LCG_M ? sv - LCG_M : sv);
-    unsigned long long run = rows[wj] % LCG_ORD2;
+    const uint32_t row = live ? rows[wj] : 0u;                     // (read by every run before the barrier, rewritten by run 0 behind it)
+    __syncthreads();
+    unsigned long long excl = 0, total = 0;
+    for (int w2 = 0; w2 < G; w2++) { const unsigned long long x = sums[w2][lane]; if (w2 < g) excl += x; total += x; }
+    if (!live) return;
+    auto jump = [&](const unsigned long long n) -> uint32_t { return lcg_jump2(pw, n < 4294967296ull ? (uint32_t)n : (uint32_t)(n % LCG_ORD2)); };
+    uint32_t origin;                                               // the state `run` samples are counted from
+    unsigned long long run = excl;
+    if (states) origin = row;
+    else {
+        const unsigned long long sv = ((unsigned long long)seed_base + (unsigned long long)w * seed_step) % LCG_M + (unsigned long long)j;
+        origin = (uint32_t)(sv >= LCG_M ? sv - LCG_M : sv);
+        run += row % LCG_ORD2;
+    }
     if (before) run += before[wj];
-    const int pair = q * n_part + (j >> PART_SUB_BITS);
-    const uint32_t s0 = pfirst[pair], s1 = pfirst[pair + 1];
-    for (uint32_t s = s0; s < s1; s++) {
-        uint32_t* cell = phist + (size_t)s * PART_SUB + (j & (PART_SUB - 1));
+    const unsigned long long run0 = run - excl;
+    for (uint32_t s = sa; s < sb; s++) {
+        uint32_t* cell = col + (size_t)s * PART_SUB;
         const uint32_t cnt = *cell;
-        const uint32_t n = (uint32_t)run;                         // (an overflow is reported below; the batch fails)
-        *cell = n ? lcg_mul(seed, lcg_jump2(pw, n)) : seed;
+        *cell = run ? lcg_mul(origin, jump(run)) : origin;
         run += cnt;
     }
-    if (run > 0xffffffffull) atomicOr(err, 32u);                  // one stream asked for >= 2^32 samples by one batch
-    if (!before) rows[wj] = (uint32_t)run;
+    if (g == 0) {
+        if (!states && run0 + total > 0xffffffffull) atomicOr(err, 32u);       // one stream asked for >= 2^32 samples by one batch
+        if (!before) rows[wj] = states ? (total ? lcg_mul(origin, jump(total)) : origin) : (uint32_t)(run0 + total);
+    }
 }
 
 // range sharding: samples this batch's local reads draw from each (worker, rank) stream (counts zeroed beforehand)

@@ -58,8 +58,12 @@ __device__ static inline int pev_wave_sum(int v) { return __builtin_amdgcn_readl
 
 // DW as in k_events: 0 = dwell from memory (or constant), 1 = drawn here, certified fp32 path, 2 = drawn here in FP64.
 // grid: ceil(links / waves per workgroup).  dump: first of 64 slots behind part[]'s last (a flush without a line writes there)
-template <int DW, bool SCATTER>
-__global__ __launch_bounds__(64 * (SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES), SCATTER ? 1 : PEV_COUNT_OCC) void k_part_events(const SigParams P, const int n_links, const uint32_t dump) {
+#define PEV_COUNT 0
+#define PEV_SCATTER 1
+#define PEV_ONE 2                        // k <= 6: one partition, the events stay in chain order -- the only pass: COUNT's work, and part[] / evrec written straight away
+template <int DW, int MODE>
+__global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES), MODE == PEV_SCATTER ? 1 : PEV_COUNT_OCC) void k_part_events(const SigParams P, const int n_links, const uint32_t dump) {
+    constexpr bool SCATTER = MODE == PEV_SCATTER, ONE = MODE == PEV_ONE;
     constexpr int NWV = SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES;
     static_assert(!SCATTER || DW == 0, "the second pass reads the dwells the first one drew");
     __shared__ PevLds<SCATTER> L;
@@ -74,6 +78,7 @@ __global__ __launch_bounds__(64 * (SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES), SCA
     const int k = P.k;
     const uint32_t kmask = (1u << (2 * k)) - 1u;                  // (k <= 9 here)
     W.wslot[lane] = (SCATTER && lane < P.n_part) ? P.poff[(size_t)chain * P.n_part + lane] + P.pstart[(size_t)P.link_q[chain] * P.n_part + lane] : 0u;
+    uint32_t slot0 = ONE ? P.poff[chain] : 0u;                     // ONE: the link's first slot (absolute: staging knows every link's events); then the read's
     if (SCATTER) W.flu[lane] = W.wslot[lane];
     // SCATTER: the slots [a, b) of lane p's partition go from the ring to part[], 64-B line by line (whole lines but for a link's
     // first and last): every lane lists its lines, then 16 lanes write one line each
@@ -220,7 +225,13 @@ __global__ __launch_bounds__(64 * (SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES), SCA
                         if (rd.ne1 > 0 && rd.ne0 >= e_q && rd.ne0 < e_q + 64)       // the second part starts in this tile
                             n1 = (long long)done + run + pev_wave_sum(lane < rd.ne0 - e_q ? sps[q] : 0);
                         run += (uint32_t)pev_wave_sum(sps[q]);
-                        if (PEV_IN(64 * q + lane)) atomicAdd(&W.wslot[rank[q] >> PART_SUB_BITS], 1u);
+                        if (ONE) {
+                            if (PEV_IN(64 * q + lane)) {
+                                const uint32_t sl = slot0 + (uint32_t)(s0 + 64 * q + lane);
+                                P.part[sl] = rank[q] | ((uint32_t)sps[q] << 16);
+                                __builtin_nontemporal_store(((unsigned long long)rank[q] << 32) | sl, reinterpret_cast<unsigned long long*>(P.evrec + rd.ev_off + s0 + 64 * q + lane));
+                            }
+                        } else if (PEV_IN(64 * q + lane)) atomicAdd(&W.wslot[rank[q] >> PART_SUB_BITS], 1u);
                     }
                 }
                 done += run;
@@ -284,6 +295,7 @@ __global__ __launch_bounds__(64 * (SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES), SCA
         for (int s0 = 0; s0 < ne; s0 += PEV_SEG) {
             if (s0 + PEV_SEG <= ne) segment(std::true_type{}, s0); else segment(std::false_type{}, s0);
         }
+        slot0 += (uint32_t)ne;
         if (!SCATTER && lane == 0 && DW) {
             const long long tot = (long long)done;
             P.seglen_out[2 * r] = (unsigned long long)(n1 >= 0 ? n1 : tot);
@@ -291,5 +303,5 @@ __global__ __launch_bounds__(64 * (SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES), SCA
         }
     }
     if (SCATTER) flush(W.flu[lane], W.wslot[lane]);                 // what is left in the rings: each partition's last, partial line
-    if (!SCATTER && lane < P.n_part) P.pcnt[(size_t)chain * P.n_part + lane] = W.wslot[lane];
+    if (MODE == PEV_COUNT && lane < P.n_part) P.pcnt[(size_t)chain * P.n_part + lane] = W.wslot[lane];
 }
