@@ -276,6 +276,12 @@ void  sqg_host_free(void *p);
  * times and returns the average milliseconds per pass. */
 int  sqg_probe_store_bandwidth(sqg_ctx_t *ctx, size_t bytes, int iters, float *ms_per_pass);
 
+/* The few-worker paths hand the k-mer streams out with LDS atomics whose lanes are served in lane order (Kernels);
+ * sqg_create measures that on the device and falls back to order-free kernels when it does not hold.  This entry repeats the
+ * measurement at any size (`workgroups` wavefronts of `rounds` rounds of 1024 fetch-adds each): *mismatches <- fetch-adds whose
+ * result differs from the serial one, *in_use <- 1 when the context's kernels rely on the property. */
+int  sqg_probe_lds_order(sqg_ctx_t *ctx, int workgroups, int rounds, unsigned int *mismatches, int *in_use);
+
 #ifdef __cplusplus
 }
 #endif

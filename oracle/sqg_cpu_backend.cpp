@@ -295,6 +295,7 @@ extern "C" int sqg_batch_sample_range(sqg_ctx_t* c, int32_t, const int32_t*, int
 extern "C" int sqg_batch_run_begin(sqg_ctx_t* c, sqg_batch_t*, const uint32_t**) { return no(c, "sqg_batch_run_begin"); }
 extern "C" int sqg_batch_run_end(sqg_ctx_t* c, sqg_batch_t*, const uint32_t*, const uint32_t*) { return no(c, "sqg_batch_run_end"); }
 extern "C" int sqg_probe_store_bandwidth(sqg_ctx_t* c, size_t, int, float*) { return no(c, "sqg_probe_store_bandwidth"); }
+extern "C" int sqg_probe_lds_order(sqg_ctx_t* c, int, int, unsigned int*, int*) { return no(c, "sqg_probe_lds_order"); }
 
 extern "C" void* sqg_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
 extern "C" void sqg_host_free(void* p) { free(p); }

@@ -75,7 +75,7 @@ SAMPLE_DNA, SAMPLE_RNA, SAMPLE_CDNA, SAMPLE_TRUNC, SAMPLE_FULL = 0, 1, 2, 4, 8
 
 EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_device_count",
            "sqg_batch_stage", "sqg_batch_run", "sqg_batch_wait", "sqg_fetch_signal", "sqg_fetch_dwell",
-           "sqg_batch_free", "sqg_get_timing", "sqg_submit", "sqg_worker_of", "sqg_probe_store_bandwidth",
+           "sqg_batch_free", "sqg_get_timing", "sqg_submit", "sqg_worker_of", "sqg_probe_store_bandwidth", "sqg_probe_lds_order",
            "sqg_batch_compress", "sqg_fetch_svb", "sqg_genome_load", "sqg_batch_sample", "sqg_fetch_reads",
            "sqg_host_alloc", "sqg_host_free", "sqg_set_range_mode", "sqg_skip_reads", "sqg_batch_sample_range",
            "sqg_batch_run_begin", "sqg_batch_run_end", "sqg_genome_load_device",
@@ -125,6 +125,8 @@ def load_library(path: str | None = None):
     L.sqg_worker_of.argtypes = [i32, i32, i32]
     L.sqg_probe_store_bandwidth.restype = C.c_int
     L.sqg_probe_store_bandwidth.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(C.c_float)]
+    L.sqg_probe_lds_order.restype = C.c_int
+    L.sqg_probe_lds_order.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_int)]
     L.sqg_batch_compress.restype = C.c_int
     L.sqg_batch_compress.argtypes = [vp, vp, C.POINTER(CSvb)]
     L.sqg_fetch_svb.restype = C.c_int
@@ -455,6 +457,12 @@ class SignalGenerator:
         ms = C.c_float()
         self._chk(self.L.sqg_probe_store_bandwidth(self.ctx, nbytes, iters, C.byref(ms)), "sqg_probe_store_bandwidth")
         return nbytes / (ms.value * 1e-3)
+
+    def probe_lds_order(self, workgroups=1024, rounds=16):
+        """(mismatches, in_use): the device's LDS atomics against their serial result; whether this context relies on them"""
+        bad, used = C.c_uint(), C.c_int()
+        self._chk(self.L.sqg_probe_lds_order(self.ctx, workgroups, rounds, C.byref(bad), C.byref(used)), "sqg_probe_lds_order")
+        return bad.value, bool(used.value)
 
     def close(self):
         if self.ctx:

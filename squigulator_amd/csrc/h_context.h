@@ -147,7 +147,7 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
         unsigned int* d_bad = nullptr;
         CHK(hipMalloc(&d_bad, sizeof(unsigned int)));
         CHK(hipMemset(d_bad, 0, sizeof(unsigned int)));
-        hipLaunchKernelGGL(k_lds_order_check, dim3(256), dim3(64), 0, c->stream, 9, d_bad);
+        hipLaunchKernelGGL(k_lds_order_check, dim3(1024), dim3(64), 0, c->stream, 4, d_bad);   // (four wavefronts per CU: the LDS pipeline is shared, as in the kernels)
         CHK(hipGetLastError());
         unsigned int bad = 1;
         CHK(hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, c->stream));

@@ -165,3 +165,18 @@ extern "C" int sqg_probe_store_bandwidth(sqg_ctx_t* c, size_t bytes, int iters, 
     return SQG_OK;
 }
 
+
+extern "C" int sqg_probe_lds_order(sqg_ctx_t* c, int workgroups, int rounds, unsigned int* mismatches, int* in_use) {
+    if (!c || !mismatches || workgroups < 1 || rounds < 1) return SQG_EINVAL;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    unsigned int* d_bad = nullptr;
+    HIPCHK(c, hipMalloc(&d_bad, sizeof(unsigned int)));
+    HIPCHK(c, hipMemsetAsync(d_bad, 0, sizeof(unsigned int), c->stream));
+    hipLaunchKernelGGL(k_lds_order_check, dim3((unsigned)workgroups), dim3(64), 0, c->stream, rounds, d_bad);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(mismatches, d_bad, sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(d_bad);
+    if (in_use) *in_use = c->lds_ordered ? 1 : 0;
+    return SQG_OK;
+}

@@ -158,3 +158,21 @@ def test_bucketed_hand_out_with_every_option(name, extra, T, hand, monkeypatch):
     batches = [_reads(rng, 170, 9, 3500) for _ in range(2)]
     assert sum(max(len(r) - 8, 5) for r in batches[0]) > 66000
     _check(prof, fl | extra, 9, T, 31, batches)
+
+
+@pytest.mark.gpu
+def test_lds_atomics_are_served_in_lane_order(monkeypatch):
+    """the property the few-worker hand-out rests on (Kernels): measured at create, and here at a larger size with eight
+    wavefronts per CU competing for the LDS: 2*10^8 fetch-adds, not one out of order.  SQG_PART_CLAIMS=1: the context does not
+    rely on it (and the kernels it then uses are what the `claims` cases of this file run)"""
+    prof, fl = profiles.get_profile("dna-r10-prom")
+    mean, stdv = model.synthetic_model(9)
+    gen = api.SignalGenerator(prof, fl, 9, mean, stdv, 1, num_workers=1)
+    bad, used = gen.probe_lds_order(workgroups=2048, rounds=96)
+    gen.close()
+    assert bad == 0 and used
+    monkeypatch.setenv("SQG_PART_CLAIMS", "1")
+    gen = api.SignalGenerator(prof, fl, 9, mean, stdv, 1, num_workers=1)
+    bad, used = gen.probe_lds_order(workgroups=64, rounds=4)
+    gen.close()
+    assert bad == 0 and not used
