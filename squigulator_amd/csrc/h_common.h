@@ -116,6 +116,11 @@ struct sqg_batch {
     int* d_wlink_worker = nullptr;       // [n_wchains]
     long long max_wchain_ev = 0;         // events of the longest worker chain
     bool part = false;                   // k > 6, split: the hand-out runs over bucketed events (k_part.h)
+    bool pieces = false;                 // the links are runs of pieces of reads (k_part_events), not of whole reads
+    bool split_reads = false;            // ... and some read is cut into several pieces
+    int4* d_pieces = nullptr;            // [n_pieces] {read, first event, end event, -}
+    uint32_t* d_piece_total = nullptr;   // [n_pieces] samples of each piece (written by the first event pass)
+    int n_pieces = 0;
     bool one = false;                    // ... with ONE partition (k <= 6): the events stay in chain order, no counting and no scatter pass
     uint32_t* d_link_slot = nullptr;     // one: [n_chains] first slot of every link in part[]
     uint32_t* d_wchain_total = nullptr;  // one: [n_wchains] events of every worker chain

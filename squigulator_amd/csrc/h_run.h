@@ -64,7 +64,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     memset(&P, 0, sizeof P);
     P.link_rows = (b->split && !b->part) ? c->d_link_rows : nullptr;
     P.part = c->d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = c->d_pcnt; P.poff = b->one ? b->d_link_slot : c->d_pcnt ? c->d_pcnt + (size_t)b->n_chains * n_part : nullptr; P.n_part = n_part;
-    P.link_q = b->d_link_q;
+    P.link_q = b->d_link_q; P.pieces = b->d_pieces; P.piece_total = b->d_piece_total;
     P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
     P.dwell = c->use_dwell_stream ? S.d_dwell : nullptr; P.dwell_out = S.d_dwell; P.seglen_out = S.d_seglen;
     P.dmean = p.dwell_mean; P.dstd = p.dwell_std;
@@ -132,7 +132,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         P.pstart = pstart;
         // one wavefront per link, ordered LDS atomics (k_part_events.h); the workgroup-per-link passes of k_events stay for the
         // 5-letter alphabet and for devices that do not pass the order check
-        const bool wave_links = b->part && c->lds_ordered && !(c->cfg.flags & SQG_METH) && !getenv("SQG_PART_WG_EVENTS");
+        const bool wave_links = b->pieces;                       // (decided at staging: the links are then runs of pieces of reads)
         auto launch_part_events = [&](int dwm, bool count) {
             if (!wave_links) { launch_events(dwm, count); return; }
             const dim3 g((unsigned)((b->n_chains + PEV_WAVES - 1) / PEV_WAVES)), t(64 * PEV_WAVES);
@@ -149,7 +149,9 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         if (b->part) {
             // k > 6, split chains: the hand-out over events bucketed by the top bits of the rank (k_part.h)
             if (phase != 2) {
+                if (b->split_reads && dw) HIPCHK(c, hipMemsetAsync(S.d_seglen, 0, (size_t)2 * n * sizeof(unsigned long long), c->stream));   // pieces add up
                 launch_part_events(dw, true);                     // dwell draws; events per (link, partition)
+                if (b->split_reads) hipLaunchKernelGGL(k_part_tile_bases, dim3((unsigned)b->n_pieces), dim3(64), 0, c->stream, P);
                 if (b->one) {
                     // one partition: the pass above has written part[] in chain order; the slices of every worker chain's events
                     hipLaunchKernelGGL(k_part_slices, dim3(1), dim3(1024), 0, c->stream, pstart, b->d_wchain_total, (int)n_pairs, b->slice_len, pfirst);

@@ -168,6 +168,8 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     for (int i = 0; i < n; i++) wchain_ev[(size_t)chain_of[(size_t)wk[(size_t)i]]] += rd[(size_t)i].ne0 + rd[(size_t)i].ne1;
     for (long long v : wchain_ev) b->max_wchain_ev = std::max(b->max_wchain_ev, v);
     std::vector<int> wlink_off(1, 0), wlink_worker;
+    struct Piece { int read, e_lo, e_hi, pad; };                 // events [e_lo, e_hi) of a read (k_part_events)
+    std::vector<Piece> pieces;
     // the hand-out over bucketed events (k_part.h) instead of per-link rows: k > 6 (up to PART_MAX partitions of 4096 streams), and
     // k <= 6 as its one-partition case -- nothing to bucket, the events stay in chain order -- on devices with ordered LDS atomics
     const bool part_one = c->num_kmer <= PART_SUB && c->lds_ordered && !(c->cfg.flags & SQG_METH) && !getenv("SQG_PART_WG_EVENTS");
@@ -180,11 +182,43 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         if (c->use_kmer_streams && want) {
             const size_t row_bytes = (size_t)c->num_kmer * sizeof(uint32_t);
             // (bucketed hand-out: a link is one wavefront of k_part_events -- 8 per SIMD; one workgroup of k_events otherwise)
-            const bool wave_links = part_ok && c->lds_ordered && !(c->cfg.flags & SQG_METH);
+            const bool wave_links = part_ok && c->lds_ordered && !(c->cfg.flags & SQG_METH) && !getenv("SQG_PART_WG_EVENTS");
             long long target = forced > 0 ? forced : wave_links ? 8192 : part_ok ? 4096 : 2048;
             if (!part_ok) target = std::min<long long>(target, std::max<long long>(8, (long long)(((size_t)1 << 30) / row_bytes)));
             std::vector<int> link_off(1, 0);
-            for (int q = 0; q < n_wchains; q++) {
+            b->pieces = wave_links;
+            for (int q = 0; q < n_wchains && wave_links; q++) {
+                // a link of k_part_events is a run of PIECES: whole reads, and the pieces (whole 512-event segments) of reads longer
+                // than a link should be -- one wavefront walks a link, and a read of 10^5 events would keep it busy ten times as
+                // long as the others (k_part_events.h: what a piece needs from the pieces before it)
+                const int lo = wchain_off[(size_t)q], hi = wchain_off[(size_t)q + 1];
+                const long long lq = std::max<long long>(1, nev > 0 ? (target * wchain_ev[(size_t)q] + nev - 1) / nev : 1);
+                const long long per = std::max<long long>(1, (wchain_ev[(size_t)q] + lq - 1) / lq);
+                const long long chunk = std::max<long long>(PEV_SEG, per / PEV_SEG * PEV_SEG);
+                long long acc = 0;
+                auto close = [&]() { link_off.push_back((int)pieces.size()); acc = 0; };
+                for (int ci = lo; ci < hi; ci++) {
+                    const int r = chain_reads[(size_t)ci];
+                    const long long ne = rd[(size_t)r].ne0 + rd[(size_t)r].ne1;
+                    if (ne <= 0) continue;
+                    if (ne <= per + per / 4 || ne <= PEV_SEG) {
+                        pieces.push_back(Piece{r, 0, (int)ne, 0});
+                        if ((acc += ne) >= per) close();
+                    } else {
+                        for (long long e = 0; e < ne; e += chunk) {
+                            const long long e_hi = std::min(e + chunk, ne);
+                            if (acc > 0 && acc + (e_hi - e) > per + per / 4) close();
+                            if (e > 0) b->split_reads = true;
+                            pieces.push_back(Piece{r, (int)e, (int)e_hi, 0});
+                            if ((acc += e_hi - e) >= per) close();
+                        }
+                    }
+                }
+                if (acc > 0) close();
+                wlink_off.push_back((int)link_off.size() - 1);
+                wlink_worker.push_back(rd[(size_t)chain_reads[(size_t)lo]].worker);
+            }
+            for (int q = 0; q < n_wchains && !wave_links; q++) {
                 const int lo = wchain_off[(size_t)q], hi = wchain_off[(size_t)q + 1];
                 long long lq = nev > 0 ? (target * wchain_ev[(size_t)q] + nev - 1) / nev : 1;
                 lq = std::max<long long>(1, std::min<long long>(lq, hi - lo));
@@ -208,7 +242,8 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     // launch order: longest chain first, so the tail of the grid is made of short chains
     std::vector<long long> chain_ev((size_t)b->n_chains, 0);
     for (int q = 0; q < b->n_chains; q++)
-        for (int ci = chain_off[(size_t)q]; ci < chain_off[(size_t)q + 1]; ci++) chain_ev[(size_t)q] += rd[(size_t)chain_reads[(size_t)ci]].ne0 + rd[(size_t)chain_reads[(size_t)ci]].ne1;
+        for (int ci = chain_off[(size_t)q]; ci < chain_off[(size_t)q + 1]; ci++)
+            chain_ev[(size_t)q] += b->pieces ? pieces[(size_t)ci].e_hi - pieces[(size_t)ci].e_lo : rd[(size_t)chain_reads[(size_t)ci]].ne0 + rd[(size_t)chain_reads[(size_t)ci]].ne1;
     // k > 6, split chains: the hand-out runs over events bucketed by the top bits of the rank (k_part.h).  The events of a
     // (worker chain, partition) are cut into slices of equal length, one workgroup of k_part_hist / k_part_hand each; the
     // slices' 4096-entry tables are what k_part_scan sweeps (SQG_PART_SLICE: events per slice, tests; SQG_NO_PART=1: the
@@ -313,7 +348,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     st_mark("chains+streams+blocks");
     auto bail = [&](int code) { c->time_c = snap_time; c->off_x = snap_off; c->med_x = snap_med; sqg_batch_free(c, b); return code; };
 #define CHKB(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); return bail(e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE); } } while (0)
-    size_t meta_bytes = 0, mo_err = 0, mo_reads = 0, mo_blk = 0, mo_coff = 0, mo_crd = 0, mo_ord = 0, mo_wlo = 0, mo_wlw = 0, mo_cb = 0, mo_ls = 0, mo_wt = 0;
+    size_t meta_bytes = 0, mo_err = 0, mo_reads = 0, mo_blk = 0, mo_coff = 0, mo_crd = 0, mo_ord = 0, mo_wlo = 0, mo_wlw = 0, mo_cb = 0, mo_ls = 0, mo_wt = 0, mo_pc = 0;
     {   // one device allocation per batch, carved into the batch's arrays (256-byte aligned)
         size_t off = 0;
         auto carve = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -325,11 +360,13 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
                      o_ord = carve(std::max<size_t>(1, chain_order.size()) * sizeof(int)),
                      o_wlo = carve(wlink_off.size() * sizeof(int)), o_wlw = carve(std::max<size_t>(1, wlink_worker.size()) * sizeof(int)),
                      o_cb = carve(std::max<size_t>(1, link_q.size()) * sizeof(int)),
-                     o_ls = carve(std::max<size_t>(1, link_slot.size()) * sizeof(uint32_t)), o_wt = carve(std::max<size_t>(1, wchain_total.size()) * sizeof(uint32_t));
+                     o_ls = carve(std::max<size_t>(1, link_slot.size()) * sizeof(uint32_t)), o_wt = carve(std::max<size_t>(1, wchain_total.size()) * sizeof(uint32_t)),
+                     o_pc = carve(std::max<size_t>(1, pieces.size()) * sizeof(Piece));
         meta_bytes = off;
+        const size_t o_ptot = carve(std::max<size_t>(1, pieces.size()) * sizeof(uint32_t));
         const size_t o_bases = carve((size_t)nb + 1024),        // (k_part_events reads a whole segment + halo from a read's last segment on)
                      o_st = carve((size_t)std::max<long long>(nst, 1) * sizeof(int)), o_t = carve((size_t)std::max<long long>(ntile, 1) * sizeof(int));
-        mo_err = o_err; mo_reads = o_reads; mo_blk = o_blk; mo_coff = o_coff; mo_crd = o_crd; mo_ord = o_ord; mo_wlo = o_wlo; mo_wlw = o_wlw; mo_cb = o_cb; mo_ls = o_ls; mo_wt = o_wt;
+        mo_err = o_err; mo_reads = o_reads; mo_blk = o_blk; mo_coff = o_coff; mo_crd = o_crd; mo_ord = o_ord; mo_wlo = o_wlo; mo_wlw = o_wlw; mo_cb = o_cb; mo_ls = o_ls; mo_wt = o_wt; mo_pc = o_pc;
         // a freed batch's block, pinned offsets and events are reused when they are large enough
         for (size_t pi = 0; pi < c->pool.size(); pi++) {
             sqg_ctx::Recycled& r = c->pool[pi];
@@ -360,6 +397,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         b->d_tile_read = (int*)(base + o_t); b->d_chain_order = (int*)(base + o_ord);
         b->d_wlink_off = (int*)(base + o_wlo); b->d_wlink_worker = (int*)(base + o_wlw);
         b->d_link_q = (int*)(base + o_cb); b->d_link_slot = (uint32_t*)(base + o_ls); b->d_wchain_total = (uint32_t*)(base + o_wt);
+        b->d_pieces = (int4*)(base + o_pc); b->d_piece_total = (uint32_t*)(base + o_ptot); b->n_pieces = (int)pieces.size();
     }
     {   // the host-built arrays -> pinned mirror -> one asynchronous copy
         uint8_t* m = b->h_meta;
@@ -373,6 +411,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
             memcpy(m + mo_wlo, wlink_off.data(), wlink_off.size() * sizeof(int));
             memcpy(m + mo_wlw, wlink_worker.data(), wlink_worker.size() * sizeof(int));
         }
+        if (b->pieces && !pieces.empty()) memcpy(m + mo_pc, pieces.data(), pieces.size() * sizeof(Piece));
         if (b->part) {
             memcpy(m + mo_cb, link_q.data(), link_q.size() * sizeof(int));
             if (b->one) { memcpy(m + mo_ls, link_slot.data(), link_slot.size() * sizeof(uint32_t)); memcpy(m + mo_wt, wchain_total.data(), wchain_total.size() * sizeof(uint32_t)); }

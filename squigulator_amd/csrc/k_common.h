@@ -224,6 +224,8 @@ struct SigParams {
     const uint32_t* poff;        // [n_links][n_part] first slot in part[] of the link's events of the partition, relative to pstart (k_part_offsets)
     const uint32_t* pstart;      // [n_wchains][n_part] first slot of the (worker chain, partition) (k_part_slices): poff is relative to it
     const int* link_q;           // [n_links] the worker chain a link belongs to
+    const int4* pieces;          // k_part_events: the links are runs of pieces {read, first event, end event, -}; chain_off indexes them
+    uint32_t* piece_total;       // [n_pieces] samples of each piece (first event pass; k_part_tile_bases)
     int n_part;                  // partitions = num_kmer >> PART_SUB_BITS
 };
 

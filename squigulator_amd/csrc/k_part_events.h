@@ -117,14 +117,20 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
     const float dw_eps = P.delta_x * fabsf(dw_sf) + 4.0f * 5.9604645e-8f * (fabsf(dw_mf) + 7.0f * fabsf(dw_sf) + 1.0f) + 1e-6f;   // as in k_events
 
     for (int ci = c_lo; ci < c_hi; ci++) {
-        const int r = P.chain_reads[ci];
+        // a piece: the events [e_lo, ne) of read r -- a whole read, or whole segments of a read too long for one link.  What a piece
+        // needs from the pieces before it: the time stream's position (arithmetic), and the samples before its first event, which
+        // only the tile offsets and the read's totals contain: those are written relative to the piece, the totals added up with
+        // atomics, and k_part_tile_bases shifts the tile offsets of the later pieces
+        const int4 pc = P.pieces[ci];
+        const int r = pc.x, e_lo = pc.y;
         const ReadDesc rd = P.reads[r];
-        const int ne = rd.ne0 + rd.ne1;
+        const int ne = pc.z;                                       // (the piece's end: "the read's end" for everything below)
+        const bool whole = e_lo == 0 && ne == rd.ne0 + rd.ne1;
         const uint8_t* rbases = P.bases + rd.base_off;
         const int shift1 = rd.len0 - rd.ne0;                      // base of event e >= ne0: e + shift1 (src/genread.c:87-88)
         unsigned long long done = 0;                              // samples before this segment
         long long n1 = -1;                                        // samples of the read's first part (read + prefix), once known
-        uint32_t c_seg = DW ? (uint32_t)__builtin_amdgcn_readfirstlane((int)lcg_mul(rd.time_c0, LCG_A)) : 0u;   // a * (time-stream state at the segment's first event)
+        uint32_t c_seg = DW ? (uint32_t)__builtin_amdgcn_readfirstlane((int)lcg_mul(lcg_mul(rd.time_c0, LCG_A), e_lo ? lcg_jump2(P.pw, (uint32_t)e_lo) : 1u)) : 0u;   // a * (time-stream state at the segment's first event)
         // a segment's inputs: 8 base bytes per lane (+ the halo in three lanes), SCATTER: 8 dwells per lane.  The next segment's are
         // requested BEFORE this segment's stores are issued: a wavefront's loads and stores retire in order (one vmcnt), so a load
         // issued behind the stores would wait for them as well
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
         };
 #pragma unroll
         for (int q = 0; q < PEV_EPL; q++) d_cur[q] = 0;
-        if (ne > 0) fetch(0);
+        if (ne > e_lo) fetch(e_lo);
         // (these loads have landed before the loop: a use inside it then only waits for the prefetch of the iteration before, which
         // has this segment's stores behind it -- the compiler counts them -- instead of for everything in flight)
         __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0)
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
                         run += (uint32_t)pev_wave_sum(sps[q]);
                         if (ONE) {
                             if (PEV_IN(64 * q + lane)) {
-                                const uint32_t sl = slot0 + (uint32_t)(s0 + 64 * q + lane);
+                                const uint32_t sl = slot0 + (uint32_t)(s0 - e_lo + 64 * q + lane);
                                 P.part[sl] = rank[q] | ((uint32_t)sps[q] << 16);
                                 __builtin_nontemporal_store(((unsigned long long)rank[q] << 32) | sl, reinterpret_cast<unsigned long long*>(P.evrec + rd.ev_off + s0 + 64 * q + lane));
                             }
@@ -292,16 +298,38 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
             }
         };
         #undef PEV_IN
-        for (int s0 = 0; s0 < ne; s0 += PEV_SEG) {
+        for (int s0 = e_lo; s0 < ne; s0 += PEV_SEG) {
             if (s0 + PEV_SEG <= ne) segment(std::true_type{}, s0); else segment(std::false_type{}, s0);
         }
-        slot0 += (uint32_t)ne;
-        if (!SCATTER && lane == 0 && DW) {
-            const long long tot = (long long)done;
-            P.seglen_out[2 * r] = (unsigned long long)(n1 >= 0 ? n1 : tot);
-            P.seglen_out[2 * r + 1] = (unsigned long long)(tot - (n1 >= 0 ? n1 : tot));
+        slot0 += (uint32_t)(ne - e_lo);
+        if (!SCATTER && lane == 0) {
+            // samples of the piece's events before / from the read's second part (n1: known when the second part starts inside the piece)
+            const long long tot = (long long)done, first = n1 >= 0 ? n1 : (rd.ne0 >= ne ? tot : 0);
+            if (DW) {
+                if (whole) { P.seglen_out[2 * r] = (unsigned long long)first; P.seglen_out[2 * r + 1] = (unsigned long long)(tot - first); }
+                else { atomicAdd(&P.seglen_out[2 * r], (unsigned long long)first); atomicAdd(&P.seglen_out[2 * r + 1], (unsigned long long)(tot - first)); }
+            }
+            P.piece_total[ci] = (uint32_t)done;
         }
     }
     if (SCATTER) flush(W.flu[lane], W.wslot[lane]);                 // what is left in the rings: each partition's last, partial line
     if (MODE == PEV_COUNT && lane < P.n_part) P.pcnt[(size_t)chain * P.n_part + lane] = W.wslot[lane];
+}
+
+// Reads cut into several pieces: the first pass wrote every piece's tile offsets relative to the piece's own first sample; the pieces
+// behind a read's first get the samples of the pieces before them added.  A read's pieces are consecutive in P.pieces.
+// grid: pieces, 64 threads.
+__global__ __launch_bounds__(64) void k_part_tile_bases(const SigParams P) {
+    const int pi = blockIdx.x;
+    const int4 pc = P.pieces[pi];
+    if (pc.y == 0) return;
+    uint32_t base = 0;
+    for (int i = pi - 1; i >= 0; i--) {
+        const int4 o = P.pieces[i];
+        if (o.x != pc.x) break;
+        base += P.piece_total[i];
+        if (o.y == 0) break;
+    }
+    const ReadDesc rd = P.reads[pc.x];
+    for (int t = (pc.y >> 6) + (int)threadIdx.x; t < (pc.z + 63) >> 6; t += 64) P.tile_so[rd.tile_off + t] += base;
 }
