@@ -1,24 +1,26 @@
-// k_part_events.h -- k > 6 (7- to 9-mer tables), few workers: the two event passes of the bucketed hand-out, one wavefront per link
+// k_part_events.h -- few workers (the reference's `-t 1`, `-t 8`): the event passes of the hand-out over bucketed events, one wavefront per link
 // Part of the device code of the per-read signal path; included through sqg_kernels.h (see there for the overview).
 //
 // With the hand-out left to k_part_hist / k_part_scan / k_part_hand (k_part.h) an event pass has nothing sequential left but
-// the sample offsets inside a read: a link (a few whole reads of a worker chain) is walked by ONE wavefront, the links of a
-// workgroup share nothing but two read-only tables, and there is no workgroup barrier after the set-up.  A read is walked in
-// segments of 512 events; event 64 q + lane of the segment is the lane's q-th, so that an LDS atomic issued per q sees the
-// segment's events in event order (instruction order, then lane order: what k_lds_order_check certifies on the device).
+// the sample offsets inside a read: a link (a few whole reads of a worker chain, or pieces of long ones) is walked by ONE
+// wavefront, the links of a workgroup share nothing but two read-only tables, and there is no workgroup barrier after the set-up.
+// A read is walked in segments of 512 events; event 64 q + lane of the segment is the lane's q-th, so that an LDS atomic issued per q
+// sees the segment's events in event order (instruction order, then lane order: what k_lds_order_check certifies on the device).
 //
-//   COUNT   (first pass)  dwell draws (src/gensig.c:254-257) -> dwell[], per-read sample totals, first sample of every 64-event
-//           tile; k-mer ranks; events per (link, partition) -> pcnt
-//   SCATTER (second pass) ranks again, dwell from memory; slot = fetch-add on the (link, partition)'s next slot -- stable by the
-//           order above; the records {dwell, low 12 bits of the rank} wait in per-partition rings in LDS until a whole 64-B line
+//   COUNT   (k > 6, first pass)  dwell draws (src/gensig.c:254-257) -> dwell[], per-read sample totals, first sample of every
+//           64-event tile; k-mer ranks; events per (link, partition) -> pcnt
+//   SCATTER (k > 6, second pass) ranks again, dwell from memory; slot = fetch-add on the (link, partition)'s next slot -- stable by
+//           the order above; the records {dwell, low 12 bits of the rank} wait in per-partition rings in LDS until a whole 64-B line
 //           of part[] can be written (a partition gets 8 of a segment's 512 events: written as they come, every line of part[]
 //           would be written in pieces, which costs the memory system 1.5x the time: measured); evrec = {slot, rank}
+//   ONE     (k <= 6: one partition, the only pass) COUNT's work; an event's slot is its position in the worker chain, which staging
+//           knows for every link: part[] and evrec are written straight away
 //
 // The k-mer ranks come from the segment's bases packed two bits each, first base in the top bits of a 32-bit word (src/seq.h:31-42
 // puts the first base in the top digits of the rank): an event's rank is a 2k-bit window of two consecutive words -- one
 // two-word LDS read, one 64-bit shift.
-// k_events<.., PART> (k_events.h) does the same with a workgroup per link and lane masks instead of ordered atomics; it stays for
-// the 5-letter methylation alphabet and for devices that do not pass the order check.
+// k_events<.., PART> (k_events.h) does COUNT and SCATTER with a workgroup per link and lane masks instead of ordered atomics; it
+// stays for the 5-letter methylation alphabet and for devices that do not pass the order check.
 #pragma once
 
 #ifndef PEV_EPL
@@ -60,7 +62,7 @@ __device__ static inline int pev_wave_sum(int v) { return __builtin_amdgcn_readl
 // grid: ceil(links / waves per workgroup).  dump: first of 64 slots behind part[]'s last (a flush without a line writes there)
 #define PEV_COUNT 0
 #define PEV_SCATTER 1
-#define PEV_ONE 2                        // k <= 6: one partition, the events stay in chain order -- the only pass: COUNT's work, and part[] / evrec written straight away
+#define PEV_ONE 2
 template <int DW, int MODE>
 __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES), MODE == PEV_SCATTER ? 1 : PEV_COUNT_OCC) void k_part_events(const SigParams P, const int n_links, const uint32_t dump) {
     constexpr bool SCATTER = MODE == PEV_SCATTER, ONE = MODE == PEV_ONE;
