@@ -282,6 +282,7 @@ __global__ __launch_bounds__(256) void k_copy_reads(const GenomeParams G, const 
                                                     const uint32_t* __restrict__ mstate) {
     __shared__ int wcnt[4];
     __shared__ int carry;
+    __shared__ uint8_t comp[256];
     const int r = blockIdx.x;
     if (r >= n_reads) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -305,8 +306,36 @@ __global__ __launch_bounds__(256) void k_copy_reads(const GenomeParams G, const 
     const uint8_t* src = G.seq + rec.src;
     const bool rev = rec.strand == '-';
     if (tid == 0) carry = 0;
+    {   // complement table of src/seq.h:78-112 (anything that is not ACGT/acgt -> 'T')
+        uint8_t o;
+        switch (tid) {
+        case 'A': case 'a': o = 'T'; break;
+        case 'C': case 'c': o = 'G'; break;
+        case 'G': case 'g': o = 'C'; break;
+        case 'T': case 't': o = 'A'; break;
+        default: o = 'T'; break;
+        }
+        comp[tid] = o;
+    }
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += 256) {
+    int i_from = 0;
+    if (!rec.n_N) {
+        // no 'N' to substitute (almost every read): eight bases per thread and step, the reverse strand through the table and a
+        // byte swap; the last n % 8 bases take the byte path below
+        const int n8 = n & ~7;
+        for (int i = tid * 8; i < n8; i += 2048) {
+            unsigned long long v;
+            __builtin_memcpy(&v, src + i, 8);
+            if (rev) {
+                unsigned long long w = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) w = (w << 8) | comp[(uint32_t)(v >> (8 * q)) & 0xffu];   // complemented, last base first
+                __builtin_memcpy(dst + read_at + n - 8 - i, &w, 8);
+            } else __builtin_memcpy(dst + read_at + i, &v, 8);
+        }
+        i_from = n8;
+    }
+    for (int i0 = i_from; i0 < n; i0 += 256) {
         const int i = i0 + tid;
         uint8_t c = i < n ? src[i] : (uint8_t)'A';
         if (rec.n_N) {                                                // ordinal of every 'N' in forward order
@@ -328,17 +357,8 @@ __global__ __launch_bounds__(256) void k_copy_reads(const GenomeParams G, const 
             __syncthreads();
         }
         if (i < n) {
-            if (rev) {
-                uint8_t o;
-                switch (c) {
-                case 'A': case 'a': o = 'T'; break;
-                case 'C': case 'c': o = 'G'; break;
-                case 'G': case 'g': o = 'C'; break;
-                case 'T': case 't': o = 'A'; break;
-                default: o = 'T'; break;
-                }
-                dst[read_at + n - 1 - i] = o;
-            } else dst[read_at + i] = c;
+            if (rev) dst[read_at + n - 1 - i] = comp[c];
+            else dst[read_at + i] = c;
         }
     }
     if (mstate && G.meth && G.meth_has[rec.ref_idx]) {               // methylate_dna, src/genread.c:207-241
