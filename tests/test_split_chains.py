@@ -176,3 +176,29 @@ def test_lds_atomics_are_served_in_lane_order(monkeypatch):
     bad, used = gen.probe_lds_order(workgroups=64, rounds=4)
     gen.close()
     assert bad == 0 and not used
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("links", [None, "100000"])
+@pytest.mark.parametrize("name", ["rna004-prom", "rna-r9-prom"])
+def test_second_part_starts_at_every_position_of_a_segment(name, links, monkeypatch):
+    """RNA with --prefix=yes: a read is [transcript + poly-A + adaptor] then the stall, whose k-mers start k - 1 bases further on
+    (src/genread.c:87-88).  Read lengths chosen so that the first event of the second part falls on, just before and just behind the
+    512-event segment boundaries of k_part_events -- which are also where long reads are cut into pieces (forced here: one piece per
+    segment) -- and on the 64-event tile boundaries in between"""
+    if links:
+        monkeypatch.setenv("SQG_SPLIT_CHAINS", links)
+    rng = np.random.default_rng(4242)
+    prof, fl = profiles.get_profile(name)
+    fl |= profiles.SQ_PREFIX
+    k = profiles.default_kmer_size(fl)
+    tail = 158 + 79 - (k - 1)                      # events the poly-A and the adaptor add to the first part
+    lens = []
+    for m in (1, 2, 3, 5):
+        for d in (-2, -1, 0, 1, 2, 63, 64, 65):
+            lens.append(512 * m - tail + d)
+    lens = [n for n in lens if n >= k] * 3
+    batches = [[bytes(rng.choice(list(b"ACGT"), n).astype(np.uint8)) for n in rng.permutation(lens)] for _ in range(2)]
+    assert sum(len(r) + 237 for r in batches[0]) > 70000
+    _check(prof, fl, k, 1, 99, batches, modes=(api.MODE_CERTIFIED,))
+    _check(prof, fl, k, 2, 99, batches[:1], modes=(api.MODE_EXACT,))
