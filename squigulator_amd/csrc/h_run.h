@@ -65,6 +65,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     P.link_rows = (b->split && !b->part) ? c->d_link_rows : nullptr;
     P.part = c->d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = c->d_pcnt; P.poff = b->one ? b->d_link_slot : c->d_pcnt ? c->d_pcnt + (size_t)b->n_chains * n_part : nullptr; P.n_part = n_part;
     P.link_q = b->d_link_q; P.pieces = b->d_pieces; P.piece_total = b->d_piece_total;
+    P.one = b->one ? 1 : 0;
     P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
     P.dwell = c->use_dwell_stream ? S.d_dwell : nullptr; P.dwell_out = S.d_dwell; P.seglen_out = S.d_seglen;
     P.dmean = p.dwell_mean; P.dstd = p.dwell_std;

@@ -110,12 +110,12 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     b->ev_off[(size_t)n] = nev; b->n_events = nev; b->n_bases = nb;
     // 64-event tiles (the work unit of k_samples); a tile never spans two reads
     long long ntile = 0;
-    for (int i = 0; i < n; i++) { rd[(size_t)i].tile_off = (int)ntile; rd[(size_t)i].fast = 0; rd[(size_t)i].stile_off = 0; rd[(size_t)i].pad = 0; ntile += (rd[(size_t)i].ne0 + rd[(size_t)i].ne1 + 63) / 64; }
+    for (int i = 0; i < n; i++) { rd[(size_t)i].tile_off = (int)ntile; rd[(size_t)i].fast = 0; rd[(size_t)i].stile_off = 0; rd[(size_t)i].slot0 = 0; ntile += (rd[(size_t)i].ne0 + rd[(size_t)i].ne1 + 63) / 64; }
     if (ntile > 2000000000LL) { delete b; c->err = "batch too large"; return SQG_EINVAL; }
     b->n_tiles = ntile;
     const int lean_ev = 64 * c->lean_epl;
     long long nst = 0;                                        // super tiles of 64*lean_epl events (work items of k_samples_lean)
-    for (int i = 0; i < n; i++) { rd[(size_t)i].stile_off = (int)nst; rd[(size_t)i].pad = 0; nst += (rd[(size_t)i].ne0 + rd[(size_t)i].ne1 + lean_ev - 1) / lean_ev; }
+    for (int i = 0; i < n; i++) { rd[(size_t)i].stile_off = (int)nst; rd[(size_t)i].slot0 = 0; nst += (rd[(size_t)i].ne0 + rd[(size_t)i].ne1 + lean_ev - 1) / lean_ev; }
     b->n_stiles = nst;
     // the tile -> read maps are filled on the device (k_fill_tiles) once the descriptors are there
 
@@ -270,6 +270,13 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
             long long at = 0;
             for (int l = 0; l < b->n_chains; l++) { link_slot[(size_t)l] = (uint32_t)at; at += chain_ev[(size_t)l]; }
             for (int q = 0; q < n_wchains; q++) wchain_total.push_back((uint32_t)wchain_ev[(size_t)q]);
+            at = 0;                                               // ... and every read's first slot: a read's events are consecutive slots
+            for (int q = 0; q < n_wchains; q++)
+                for (int ci = wchain_off[(size_t)q]; ci < wchain_off[(size_t)q + 1]; ci++) {
+                    ReadDesc& d = rd[(size_t)chain_reads[(size_t)ci]];
+                    d.slot0 = (int)(uint32_t)at;
+                    at += d.ne0 + d.ne1;
+                }
         }
     }
     if (c->use_kmer_streams && c->num_kmer > 4096 && !b->part && (double)b->max_wchain_ev * c->dwell_hi >= 4294967295.0 - (double)LCG_ORD2) {

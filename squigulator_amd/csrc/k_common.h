@@ -141,7 +141,7 @@ struct ReadDesc {
     int tile_off;         // first 64-event tile of this read in the batch's tile arrays
     int fast;             // certified mode: every ADC value of this read is provably in (2, 65000) -> lean kernel
     int stile_off;        // first 256-event super tile of this read
-    int pad;
+    int slot0;            // one-partition hand-out (k <= 6, few workers; k_part.h): slot in part[] of the read's first event
 };
 
 struct FixEntry {         // one sample handed to the FP64 path
@@ -165,7 +165,7 @@ struct ItemDesc {
     int read;                    // read index (fix-up overflow path)
     int shift_lo, shift_hi;      // RNA adaptor level-shift window (src/genread.c:79-86) as sample indices within the item
                                  // (generation order): samples lo <= i < hi get -shift; hi <= lo: none
-    int pad;
+    int slot_first;              // one-partition hand-out: slot in part[] of the item's first event (else 0)
 };
 
 struct SigParams {
@@ -224,6 +224,8 @@ struct SigParams {
     const uint32_t* poff;        // [n_links][n_part] first slot in part[] of the link's events of the partition, relative to pstart (k_part_offsets)
     const uint32_t* pstart;      // [n_wchains][n_part] first slot of the (worker chain, partition) (k_part_slices): poff is relative to it
     const int* link_q;           // [n_links] the worker chain a link belongs to
+    int one;                     // one-partition hand-out (k <= 6): part[slot] = rank | dwell << 16 and part_state[slot], slots in event order from
+                                 // ReadDesc.slot0 on, are what the sample kernels read -- no evrec
     const int4* pieces;          // k_part_events: the links are runs of pieces {read, first event, end event, -}; chain_off indexes them
     uint32_t* piece_total;       // [n_pieces] samples of each piece (first event pass; k_part_tile_bases)
     int n_part;                  // partitions = num_kmer >> PART_SUB_BITS

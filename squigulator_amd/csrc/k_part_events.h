@@ -14,7 +14,7 @@
 //           of part[] can be written (a partition gets 8 of a segment's 512 events: written as they come, every line of part[]
 //           would be written in pieces, which costs the memory system 1.5x the time: measured); evrec = {slot, rank}
 //   ONE     (k <= 6: one partition, the only pass) COUNT's work; an event's slot is its position in the worker chain, which staging
-//           knows for every link: part[] and evrec are written straight away
+//           knows for every link and read: part[slot] = {dwell, rank} is written straight away, and the sample kernels need no evrec
 //
 // The k-mer ranks come from the segment's bases packed two bits each, first base in the top bits of a 32-bit word (src/seq.h:31-42
 // puts the first base in the top digits of the rank): an event's rank is a 2k-bit window of two consecutive words -- one
@@ -236,8 +236,7 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
                         if (ONE) {
                             if (PEV_IN(64 * q + lane)) {
                                 const uint32_t sl = slot0 + (uint32_t)(s0 - e_lo + 64 * q + lane);
-                                P.part[sl] = rank[q] | ((uint32_t)sps[q] << 16);
-                                __builtin_nontemporal_store(((unsigned long long)rank[q] << 32) | sl, reinterpret_cast<unsigned long long*>(P.evrec + rd.ev_off + s0 + 64 * q + lane));
+                                P.part[sl] = rank[q] | ((uint32_t)sps[q] << 16);   // (all the sample kernels need besides state[sl]: no evrec)
                             }
                         } else if (PEV_IN(64 * q + lane)) atomicAdd(&W.wslot[rank[q] >> PART_SUB_BITS], 1u);
                     }

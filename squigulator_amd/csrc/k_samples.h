@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_st
     d.ev_read0 = lt * LEAN_EV;
     d.read = r;
     d.shift_lo = shift_lo; d.shift_hi = shift_hi;
-    d.pad = 0;
+    d.slot_first = P.one ? rd.slot0 + lt * LEAN_EV : 0;
     P.items[g] = d;
     P.tfix_n[g] = 0;
 }
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
             it.ev_read0 = lt * LEAN_EV;
             it.read = r;
             it.shift_lo = shift_lo; it.shift_hi = shift_hi;
-            it.pad = 0;
+            it.slot_first = P.one ? rd.slot0 + lt * LEAN_EV : 0;
         }
         const int ne = it.n_ev;                                         // events of this item
         if (ne == 0) continue;                                         // not taken, or empty
@@ -201,7 +201,22 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         // ---- set-up: LEAN_EPL consecutive events per lane ----
         uint2 er[LEAN_EPL];
         int sps[LEAN_EPL];
-        if (e0 + LEAN_EPL <= ne) {
+        if (P.one) {
+            // (wave-uniform) one-partition hand-out: the item's events are consecutive slots: rank and dwell from part[], states below
+            const uint32_t gslot = (uint32_t)it.slot_first + (uint32_t)e0;
+            if (e0 + LEAN_EPL <= ne) {
+                uint32_t pw_[LEAN_EPL];
+                __builtin_memcpy(pw_, P.part + gslot, 4 * LEAN_EPL);
+#pragma unroll
+                for (int q = 0; q < LEAN_EPL; q++) { er[q] = make_uint2(gslot + (uint32_t)q, pw_[q] & 0xffffu); sps[q] = (int)(pw_[q] >> 16); }
+            } else {
+#pragma unroll
+                for (int q = 0; q < LEAN_EPL; q++) {
+                    const uint32_t w_ = e0 + q < ne ? P.part[gslot + q] : 0u;
+                    er[q] = make_uint2(gslot + (uint32_t)q, w_ & 0xffffu); sps[q] = (int)(w_ >> 16);
+                }
+            }
+        } else if (e0 + LEAN_EPL <= ne) {
             uint32_t ew[2 * LEAN_EPL];
             __builtin_memcpy(ew, P.evrec + gev, 8 * LEAN_EPL);                        // 8-B aligned wide loads
 #pragma unroll
@@ -386,9 +401,15 @@ __global__ __launch_bounds__(256) void k_samples(const SigParams P, const int n_
         uint2 er = make_uint2(0u, 0u);
         int sps = 0;
         if (valid) {
-            er = P.evrec[rd.ev_off + e];
-            sps = P.dwell ? (int)P.dwell[rd.ev_off + e] : P.const_sps;
-            if (P.part_state) er.x = P.part_state[er.x];                // k > 6, bucketed hand-out (k_part.h): slot -> state
+            if (P.one) {                                               // one-partition hand-out: rank and dwell from part[]
+                const uint32_t sl = (uint32_t)rd.slot0 + (uint32_t)e, w_ = P.part[sl];
+                er = make_uint2(sl, w_ & 0xffffu);
+                sps = (int)(w_ >> 16);
+            } else {
+                er = P.evrec[rd.ev_off + e];
+                sps = P.dwell ? (int)P.dwell[rd.ev_off + e] : P.const_sps;
+            }
+            if (P.part_state) er.x = P.part_state[er.x];                // few workers, bucketed hand-out (k_part.h): slot -> state
         }
         const float2 md = valid ? P.model[er.y] : make_float2(0.f, 0.f);
         const int incl = wave_incl_scan(sps, lane);
