@@ -56,3 +56,50 @@ def test_random_configuration_matches_oracle(seed, monkeypatch):
                 assert b.offset[i] == w.offset and b.median_before[i] == w.median_before
             b.free()
         gen.close()
+
+
+def _few_case(seed):
+    """few workers, chains cut into links (forced: the batches are small): every k of the bucketed hand-out (7, 8, 9: 4, 16, 64
+    partitions) and of its one-partition case (5, 6), dwells from 2 to 600 samples (constant ones included), every flag set"""
+    rng = np.random.default_rng(5000 + seed)
+    base, _ = profiles.get_profile(["dna-r10-prom", "rna004-prom", "dna-r9-prom", "rna-r9-prom"][seed % 4])
+    dwell_mean = float(rng.choice([2.0, 9.0, 13.0, 31.0, 120.0, 600.0]))
+    dwell_std = float(rng.choice([0.0, 0.5, 4.0, dwell_mean * 0.8])) if seed % 5 else 0.0
+    prof = base.replace(dwell_mean=dwell_mean, dwell_std=dwell_std, offset_std=float(rng.choice([0.0, 5.0])),
+                        range=base.range * float(rng.uniform(0.6, 1.8)))
+    flags = FLAG_SETS[int(rng.integers(0, len(FLAG_SETS)))]
+    k = [9, 8, 7, 6, 5, 9][seed % 6]
+    T = int(rng.integers(1, 5))
+    batches = []
+    for _ in range(int(rng.integers(2, 4))):
+        n = int(rng.integers(T + 1, 3 * T + 8))
+        lens = rng.choice([1, k - 1, k, k + 1, 64, 65, 300, 511, 512, 513, 1023, 1024, 1025, 1600, 2100], n)
+        batches.append([bytes(rng.choice(list(b"ACGTacgtNRY"), int(m), p=[.22, .22, .22, .22, .02, .02, .02, .02, .02, .01, .01]).astype(np.uint8))
+                        for m in lens])
+    links = str(rng.choice([2, 7, 40, 100000]))
+    return prof, flags, k, T, int(rng.integers(1, 1 << 30)), batches, links
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(36))
+def test_random_few_worker_configuration_matches_oracle(seed, monkeypatch):
+    prof, flags, k, T, s, batches, links = _few_case(seed)
+    monkeypatch.setenv("SQG_SPLIT_CHAINS", links)
+    if seed % 9 == 8:
+        monkeypatch.setenv("SQG_PART_CLAIMS", "1")       # the order-free kernels
+    mean, stdv = model.synthetic_model(k, salt=seed)
+    orac = orc.Oracle(prof, flags, k, mean, stdv, s, num_workers=T)
+    want = [orac.run_batch_seqs(bt) for bt in batches]
+    orac.close()
+    for mode in (api.MODE_CERTIFIED, api.MODE_EXACT):
+        gen = api.SignalGenerator(prof, flags, k, mean, stdv, s, num_workers=T, mode=mode)
+        for bi, bt in enumerate(batches):
+            b = gen.submit(bt)
+            sig, dw = b.signal(), b.dwell()
+            for i, w in enumerate(want[bi]):
+                np.testing.assert_array_equal(sig[b.sig_off[i]:b.sig_off[i + 1]], w.sig,
+                                              err_msg=f"seed {seed} mode {mode} batch {bi} read {i} (k={k} T={T} flags={flags:#x} links={links} dwell={prof.dwell_mean}/{prof.dwell_std})")
+                np.testing.assert_array_equal(dw[b.ev_off[i]:b.ev_off[i + 1]], w.ss)
+                assert b.offset[i] == w.offset and b.median_before[i] == w.median_before
+            b.free()
+        gen.close()
