@@ -202,3 +202,16 @@ def test_second_part_starts_at_every_position_of_a_segment(name, links, monkeypa
     assert sum(len(r) + 237 for r in batches[0]) > 70000
     _check(prof, fl, k, 1, 99, batches, modes=(api.MODE_CERTIFIED,))
     _check(prof, fl, k, 2, 99, batches[:1], modes=(api.MODE_EXACT,))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T", [("dna-r10-prom", 20), ("dna-r10-prom", 37), ("dna-r9-prom", 33)])
+def test_many_worker_chains_each_with_several_reads(name, T):
+    """`-t 20 ... -t 37` with a dozen reads per worker: more than 1024 (worker chain, partition) pairs for the 9-mer table (k_part_slices
+    walks them 1024 at a time), chains of very different weight, workers without a read in the second batch"""
+    rng = np.random.default_rng(606 + T)
+    prof, fl = profiles.get_profile(name)
+    k = profiles.default_kmer_size(fl)
+    batches = [_reads(rng, 12 * T, k, 1500), _reads(rng, T - 3, k, 1500) + _reads(rng, 5 * T, k, 900)]
+    assert sum(max(len(r) - k + 1, 5) for r in batches[0]) > 70000
+    _check(prof, fl, k, T, 5, batches, modes=(api.MODE_CERTIFIED,))
