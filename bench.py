@@ -21,7 +21,8 @@ generates a range of each batch; one all-gather of per-stream sample counts per 
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (k_samples_lean) against HBM: achieved =
 algorithmic bytes (2*N_samples + N_bases + 24*N_reads per launch) / its average launch duration measured
-with hipEvents on the library's stream; `step_frac` is the same bytes over the whole step.  `cpu_baseline` is the
+with hipEvents on the library's stream; `step_frac` is the same bytes over the whole step, `step_traffic(_frac)` all the HBM bytes of a
+step (PMC, every kernel of the timed region) over the step's time.  `cpu_baseline` is the
 reference's own gensig.c/genread.c (oracle/_ref/ref_harness) timed on this box's host cores, one `-t 1` process per
 physical core, read loop only (kind "reference"); the oracle restatement (kind "port") when that binary is absent.
 """
@@ -166,6 +167,24 @@ WORKLOADS = {
     "sequin-rna004": ("rna004-prom", profiles.SQ_PREFIX, "rna", 1, 32768,
                       "rnasequin_sequences_2.4.fa -x rna004-prom --prefix=yes, whole transcripts (configs[4])"),
 }
+
+
+STEP_KERNELS = ("k_part_events", "k_part_tile_bases", "k_part_offsets", "k_part_slices", "k_part_slice_bounds", "k_part_hist", "k_part_scan",
+                "k_part_hand", "k_events", "k_link_prefix", "k_scan", "k_items", "k_samples", "k_fixup")
+
+
+def pmc_step_traffic(workload_key):
+    """HBM bytes of one whole step -- every kernel of the timed region, one launch each -- from the same PMC passes
+    (profiles/traffic_latest.json); None when no profile of this workload exists"""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+        if doc.get("workload_key") != workload_key:
+            return None
+        return float(sum(v["hbm_bytes_per_launch"] for k, v in doc["kernels"].items() if k.startswith(STEP_KERNELS)))
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def pmc_traffic(workload_key):
@@ -577,6 +596,11 @@ def main():
                          "step_frac": alg_bytes / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S,
                          "workload_key": wkey},
         }
+        st = pmc_step_traffic(wkey)
+        if st is not None:
+            # all the HBM traffic of a step (PMC, every kernel of the timed region) over the step's time: how busy the memory is
+            out["roofline"]["step_traffic"] = st
+            out["roofline"]["step_traffic_frac"] = st / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S
         if not args.no_store_probe:
             out["roofline"]["measured_store_peak_GBps"] = gen.probe_store_bandwidth(1 << 30, 10) / 1e9
         if digests:
