@@ -468,7 +468,14 @@ def main():
     # the reads ARE the reference's: gen_read (src/genread.c) with `--seed 42 -r <rlen> -t T -K N*K` on the resident genome,
     # sampled on the device at staging time (outside the timed region)
     nsteps = args.warmup + args.steps
-    batches = [gen.sample(K * world, None, lo=r_lo, hi=r_hi) if range_mode else gen.sample(K, workers) for _ in range(nsteps)]
+    # staged ahead: everything, up to STAGE_AHEAD batches (0.2 GB of HBM each at the headline size); a longer run stages the rest
+    # as it goes -- batch i + STAGE_AHEAD when batch i is done and freed, with STAGE_AHEAD - 1 batches still queued on the device
+    STAGE_AHEAD = 160
+
+    def stage_one():
+        return gen.sample(K * world, None, lo=r_lo, hi=r_hi) if range_mode else gen.sample(K, workers)
+
+    batches = [stage_one() for _ in range(min(nsteps, args.warmup + STAGE_AHEAD))]
 
     def sync_all():
         torch.cuda.synchronize()
@@ -500,21 +507,33 @@ def main():
     sig_ms, ev_ms, lean_ms = [], [], []
     samples = bases = reads = 0
     digests = []
-    for b in batches[args.warmup:]:
-        run(b)                        # asynchronous: all K steps are queued back to back (range mode: one exchange per step)
-    for b in batches[args.warmup:]:
+    timed = batches[args.warmup:]
+    for b in timed:
+        run(b)                        # asynchronous: the steps are queued back to back (range mode: one exchange per step)
+    to_stage = args.steps - len(timed)
+    i = 0
+    while i < len(timed):
+        b = timed[i]
         b.wait()
         tm = gen.timing()
         sig_ms.append(tm["samples_ms"]); ev_ms.append(tm["events_ms"])
         lean_ms.append(tm["lean_ms"] if tm["lean_ms"] > 0 else tm["samples_ms"])
         samples += b.n_samples; bases += b.n_bases; reads += b.n_reads
+        if to_stage > 0:              # a long run: this batch makes room for one more (the device has STAGE_AHEAD - 1 queued meanwhile)
+            b.free()
+            timed[i] = None
+            nb = stage_one()
+            run(nb)
+            timed.append(nb)
+            to_stage -= 1
+        i += 1
     sync_all()
     dt = time.perf_counter() - t0
 
     if args.digest:
         # tests: per batch, the sum of the reads' xxh64 digests over each of this rank's D parts (parts of the JOB's batch)
         import xxhash
-        for b in batches[args.warmup:]:
+        for b in timed:
             # (the slabs of older batches have been reused: generate again, deterministically the same?  No: the context's
             # streams have moved on.  Digests therefore need steps <= 2, which the slabs still hold.)
             sig = b.signal()
@@ -625,7 +644,7 @@ def main():
             out["cpu_baseline"] = ref or {"value": port_rate, "unit": "samples/s", "cores": 1 if one_worker else min(os.cpu_count() or 1, 64),
                                           "kind": "port", "sample": f"oracle restatement on the {n_chk} reads of parity_check"}
         print(json.dumps(out))
-    for b in batches:
+    for b in batches[:args.warmup] + [b for b in timed if b is not None]:
         b.free()
     gen.close()
     if world > 1:
