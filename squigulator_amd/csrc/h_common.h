@@ -76,6 +76,7 @@ struct sqg_ctx {
     bool force_fix = false;
     bool lds_ordered = false;             // k_lds_order_check passed on this device: k_part_hand_ord hands the streams out (k_part.h)
     uint8_t* d_genome = nullptr;                                // resident reference (sqg_genome_load)
+    uint32_t* d_nprefix = nullptr;                              // ... and its 'N's per 64-base block, summed (k_nprefix_*)
     long long* d_contig_off = nullptr; long long* d_cum = nullptr;
     float* d_trans_csum = nullptr; int* d_trans_idx = nullptr;
     uint32_t* d_samp = nullptr;                                 // [nw][3] sampler stream states: ref_pos, rand_strand, rand_rlen

@@ -46,7 +46,7 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
         if (S.sampled) (void)hipEventDestroy(S.sampled);
     }
     (void)hipFree(ctx->d_svb); (void)hipFree(ctx->d_svb_size); (void)hipFree(ctx->d_svb_off);
-    (void)hipFree(ctx->d_genome); (void)hipFree(ctx->d_contig_off); (void)hipFree(ctx->d_cum);
+    (void)hipFree(ctx->d_genome); (void)hipFree(ctx->d_contig_off); (void)hipFree(ctx->d_cum); (void)hipFree(ctx->d_nprefix);
     (void)hipFree(ctx->d_trans_csum); (void)hipFree(ctx->d_trans_idx); (void)hipFree(ctx->d_samp);
     (void)hipFree(ctx->d_meth); (void)hipFree(ctx->d_meth_has); (void)hipFree(ctx->d_meth_st);
     if (ctx->stage_stream) { (void)hipStreamSynchronize(ctx->stage_stream); (void)hipStreamDestroy(ctx->stage_stream); }

@@ -17,7 +17,7 @@ static int genome_load_impl(sqg_ctx_t* c, const sqg_genome_t* g, const bool on_d
         if (len < 0 || len > 2000000000LL) return SQG_EINVAL;
         run += len; cum[(size_t)i] = run;
     }
-    (void)hipFree(c->d_genome); (void)hipFree(c->d_contig_off); (void)hipFree(c->d_cum);
+    (void)hipFree(c->d_genome); (void)hipFree(c->d_contig_off); (void)hipFree(c->d_cum); (void)hipFree(c->d_nprefix); c->d_nprefix = nullptr;
     (void)hipFree(c->d_trans_csum); (void)hipFree(c->d_trans_idx); (void)hipFree(c->d_samp);
     c->d_genome = nullptr; c->d_contig_off = nullptr; c->d_cum = nullptr; c->d_trans_csum = nullptr; c->d_trans_idx = nullptr; c->d_samp = nullptr;
     HIPCHK(c, hipMalloc(&c->d_genome, (size_t)total + 16));
@@ -40,7 +40,15 @@ static int genome_load_impl(sqg_ctx_t* c, const sqg_genome_t* g, const bool on_d
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stage_stream));
     GenomeParams& G = c->genome;
-    G.seq = c->d_genome; G.contig_off = c->d_contig_off; G.cum = c->d_cum;
+    {   // 'N's per 64-base block, summed: the sampler's 10 % test reads two entries instead of the candidate read (genomes below 2^32 'N's: all)
+        const long long n_blocks = (total + 63) / 64;
+        HIPCHK(c, hipMalloc(&c->d_nprefix, ((size_t)n_blocks + 2) * sizeof(uint32_t)));
+        if (n_blocks > 0) hipLaunchKernelGGL(k_nprefix_count, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, c->stream, c->d_genome, (long long)total, n_blocks, c->d_nprefix);
+        hipLaunchKernelGGL(k_nprefix_scan, dim3(1), dim3(1024), 0, c->stream, c->d_nprefix, n_blocks);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    G.seq = c->d_genome; G.contig_off = c->d_contig_off; G.cum = c->d_cum; G.nprefix = c->d_nprefix;
     G.trans_csum = c->d_trans_csum; G.trans_idx = c->d_trans_idx;
     G.sum = total; G.grng_b = (double)(g->rlen / 2); G.n_contigs = nc; G.n_trans = g->n_trans; G.rlen = g->rlen;
     G.flags = (int)g->mode;

@@ -16,6 +16,7 @@ struct GenomeParams {
     long long sum;               // ref->sum
     double grng_b;               // (double)(rlen / 2)
     int n_contigs, n_trans, rlen, flags;
+    const uint32_t* nprefix;     // [sum / 64 + 2] 'N's in seq[0, 64 i): a candidate read's count without reading the read (k_nprefix_*)
     const uint8_t* meth;         // --meth-freq (sqg_genome_set_meth): round(255*freq) per base, laid out like seq; or null
     const uint8_t* meth_has;     // [n_contigs] the contig has an array at all (ref->ref_meth[i] != NULL, src/genread.c:208)
 };
@@ -57,6 +58,55 @@ __device__ static inline int count_N(const uint8_t* __restrict__ p, int n, int l
     if (lane < n - n8) cnt += p[n8 + lane] == 'N';
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
     return cnt;
+}
+
+// the same count from the genome's table of 'N's per 64-base block: two look-ups and the two ragged ends
+__device__ static inline int count_N_at(const GenomeParams& G, long long src, int n, int lane) {
+    const long long a = src, b = src + n, ba = (a + 63) >> 6, bb = b >> 6;
+    if (!G.nprefix || ba >= bb) return count_N(G.seq + src, n, lane);
+    return (int)(G.nprefix[bb] - G.nprefix[ba]) + count_N(G.seq + a, (int)((ba << 6) - a), lane) + count_N(G.seq + (bb << 6), (int)(b - (bb << 6)), lane);
+}
+
+// the table: 'N's of every 64-base block (one thread each), then their running sum (one workgroup, 16384 blocks per round)
+__global__ __launch_bounds__(256) void k_nprefix_count(const uint8_t* __restrict__ seq, long long total, long long n_blocks, uint32_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_blocks) return;
+    const uint8_t* p = seq + (i << 6);
+    const int n = (int)min(64LL, total - (i << 6));
+    int cnt = 0;
+    if (n == 64) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            unsigned long long v;
+            __builtin_memcpy(&v, p + 8 * q, 8);
+            const unsigned long long x = v ^ 0x4e4e4e4e4e4e4e4eull;        // zero byte <=> 'N'
+            cnt += __popcll(~(((x & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | x | 0x7f7f7f7f7f7f7f7full));
+        }
+    } else for (int q = 0; q < n; q++) cnt += p[q] == 'N';
+    out[i + 1] = (uint32_t)cnt;                                       // (out[0] = 0: set by the scan)
+}
+__global__ __launch_bounds__(1024) void k_nprefix_scan(uint32_t* __restrict__ t, long long n_blocks) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    if (tid == 0) { carry = 0; t[0] = 0; }
+    __syncthreads();
+    for (long long base = 0; base < n_blocks; base += 16384) {
+        uint32_t v[16], run = 0;
+        const long long i0 = base + (long long)tid * 16;
+#pragma unroll
+        for (int q = 0; q < 16; q++) { v[q] = i0 + q < n_blocks ? t[i0 + q + 1] : 0u; run += v[q]; }
+        const uint32_t incl = (uint32_t)wave_incl_scan_dpp((int)run);
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        uint32_t at = carry + incl - run;
+        for (int w = 0; w < wid; w++) at += wsum[w];
+#pragma unroll
+        for (int q = 0; q < 16; q++) { at += v[q]; if (i0 + q < n_blocks) t[i0 + q + 1] = at; }
+        __syncthreads();
+        if (tid == 1023) carry = at;
+        __syncthreads();
+    }
 }
 
 // a^n mod M
@@ -113,7 +163,7 @@ __device__ static inline bool samp_attempt(const GenomeParams& G, uint32_t& c_po
     const int n = min(len, clen - pos);                       // src/genread.c:149-177: clipped at the contig's end
     if (n < 200) return false;                                // src/genread.c:126
     const long long src = G.contig_off[idx] + pos;
-    const int nN = count_N(G.seq + src, n, lane);
+    const int nN = count_N_at(G, src, n, lane);
     if ((double)nN > 0.1 * (double)n) return false;           // src/genread.c:139-142
     rec.src = src; rec.ref_idx = idx; rec.ref_pos = pos; rec.rlen = n; rec.strand = strand; rec.n_N = nN;
     rec.ref_len = (G.flags & (SQG_SAMPLE_RNA | SQG_SAMPLE_CDNA)) ? len : clen;
