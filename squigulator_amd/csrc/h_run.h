@@ -63,7 +63,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     SigParams P;
     memset(&P, 0, sizeof P);
     P.link_rows = (b->split && !b->part) ? c->d_link_rows : nullptr;
-    P.part = c->d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = c->d_pcnt; P.poff = b->one ? b->d_link_slot : c->d_pcnt ? c->d_pcnt + (size_t)b->n_chains * n_part : nullptr; P.n_part = n_part;
+    P.part = c->d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = c->d_pcnt; P.poff = b->one ? b->d_link_slot : c->d_pcnt ? c->d_pcnt + (size_t)b->n_chains * n_part : nullptr; P.n_part = n_part; P.n_links = b->n_chains;
     P.link_q = b->d_link_q; P.pieces = b->d_pieces; P.piece_total = b->d_piece_total;
     P.one = b->one ? 1 : 0;
     P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
@@ -161,7 +161,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                     if ((rc = dbg_sync(c, "k_part_events<one>/k_part_slices"))) return rc;
                 } else {
                     hipLaunchKernelGGL(k_part_offsets, dim3((unsigned)n_part, (unsigned)b->n_wchains), dim3(1024), 0, c->stream, c->d_pcnt,
-                                       c->d_pcnt + (size_t)b->n_chains * n_part, n_part, b->d_wlink_off, ptotal);
+                                       c->d_pcnt + (size_t)b->n_chains * n_part, n_part, b->n_chains, b->d_wlink_off, ptotal);
                     hipLaunchKernelGGL(k_part_slices, dim3(1), dim3(1024), 0, c->stream, pstart, ptotal, (int)n_pairs, b->slice_len, pfirst);
                     hipLaunchKernelGGL(k_part_slice_bounds, dim3((pgrid + 255) / 256), dim3(256), 0, c->stream, pstart, ptotal, (int)n_pairs, b->slice_len, pfirst, slice_lo, slice_hi);
                     HIPCHK(c, hipGetLastError());

@@ -261,6 +261,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         // a slice's per-stream sample counts are 32-bit (a bucketed event carries its dwell in 16 bits)
         len = std::min<long long>(len, (long long)(4.0e9 / std::min(std::max(c->dwell_hi, 1.0), 65535.0)));
         len = std::max<long long>(PART_STEP, len / PART_STEP * PART_STEP);
+        if (!senv) len = std::max<long long>(len, std::min<long long>(8 * PART_STEP, (long long)(4.0e9 / std::min(std::max(c->dwell_hi, 1.0), 65535.0)) / PART_STEP * PART_STEP));   // small batches: fewer, not shorter slices (a slice costs a 16-KiB table in three passes)
         b->slice_len = (uint32_t)len;
         b->max_slices = (long long)(nev / len) + (long long)n_wchains * n_part;
         b->part = true;

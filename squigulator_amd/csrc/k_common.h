@@ -220,8 +220,8 @@ struct SigParams {
                                  // (dwell << 16) | low PART_SUB_BITS of the rank
     uint32_t* part_state;        // [n_events] same slots (k_part_hand): the stream's state at the event's first draw; non-null tells
                                  // the sample kernels that evrec.x is a slot, not a state
-    uint32_t* pcnt;              // [n_links][n_part] events per (link, partition)
-    const uint32_t* poff;        // [n_links][n_part] first slot in part[] of the link's events of the partition, relative to pstart (k_part_offsets)
+    uint32_t* pcnt;              // [n_part][n_links] events per (link, partition)
+    const uint32_t* poff;        // [n_part][n_links] first slot in part[] of the link's events of the partition, relative to pstart (k_part_offsets)
     const uint32_t* pstart;      // [n_wchains][n_part] first slot of the (worker chain, partition) (k_part_slices): poff is relative to it
     const int* link_q;           // [n_links] the worker chain a link belongs to
     int one;                     // one-partition hand-out (k <= 6): part[slot] = rank | dwell << 16 and part_state[slot], slots in event order from
@@ -229,6 +229,7 @@ struct SigParams {
     const int4* pieces;          // k_part_events: the links are runs of pieces {read, first event, end event, -}; chain_off indexes them
     uint32_t* piece_total;       // [n_pieces] samples of each piece (first event pass; k_part_tile_bases)
     int n_part;                  // partitions = num_kmer >> PART_SUB_BITS
+    int n_links;                 // pcnt / poff are partition-major: [partition][link] (k_part_offsets sweeps a partition's links)
 };
 
 #define PART_SUB_BITS 12         // a partition's sub-row: 4096 streams, 16 KiB of LDS (the size of a whole 6-mer row).  (2048-stream

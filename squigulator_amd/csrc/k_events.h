@@ -361,7 +361,7 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
                                         (unsigned long long)(P.rows ? P.reads[P.chain_reads[c_lo]].worker : 0) * P.seed_step) % LCG_M);
     if (DIRECT && P.use_streams) for (int i = tid; i < P.num_kmer; i += NT) L.row[i] = HIST ? 0u : row[i];
     if (PART) {
-        if (tid < PART_MAX) L.prun[tid] = (HIST || tid >= P.n_part) ? 0u : P.poff[(size_t)chain * P.n_part + tid] + P.pstart[(size_t)P.link_q[chain] * P.n_part + tid];
+        if (tid < PART_MAX) L.prun[tid] = (HIST || tid >= P.n_part) ? 0u : P.poff[(size_t)tid * P.n_links + chain] + P.pstart[(size_t)P.link_q[chain] * P.n_part + tid];
         for (int i = tid; i < (NT / 64) * PART_MAX; i += NT) L.pmask[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     const uint32_t a2nt = DW ? lcg_jump2(P.pw, (uint32_t)SEG) : 0u;      // time-stream jump over one segment
@@ -679,6 +679,6 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
         __syncthreads();
     }
     if (DIRECT && P.use_streams) for (int i = tid; i < P.num_kmer; i += NT) row[i] = L.row[i];
-    if (PART && HIST && tid < P.n_part) P.pcnt[(size_t)chain * P.n_part + tid] = L.prun[tid];
+    if (PART && HIST && tid < P.n_part) P.pcnt[(size_t)tid * P.n_links + chain] = L.prun[tid];
 }
 

@@ -25,14 +25,15 @@
 // grid (partitions, worker chains), 1024 threads, each with a run of consecutive links of the chain.
 //   wlink_off[q]..wlink_off[q+1]   the links of worker chain q, in chain order
 // poff[l][p] <- the chain's events of partition p before link l; ptotal[q][p] <- all of them
-__global__ __launch_bounds__(1024) void k_part_offsets(const uint32_t* __restrict__ pcnt, uint32_t* __restrict__ poff, const int n_part,
+__global__ __launch_bounds__(1024) void k_part_offsets(const uint32_t* __restrict__ pcnt, uint32_t* __restrict__ poff, const int n_part, const int n_links,
                                                        const int* __restrict__ wlink_off, uint32_t* __restrict__ ptotal) {
     __shared__ uint32_t wsum[16];
     const int p = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l0 = wlink_off[q], l1 = wlink_off[q + 1];
     const int per = (l1 - l0 + 1023) / 1024, la = min(l0 + tid * per, l1), lb = min(la + per, l1);
     uint32_t own = 0;                                             // my links' events of partition p
-    for (int l = la; l < lb; l++) own += pcnt[(size_t)l * n_part + p];
+    pcnt += (size_t)p * n_links; poff += (size_t)p * n_links;     // (partition-major: a thread's links are consecutive words)
+    for (int l = la; l < lb; l++) own += pcnt[l];
     const uint32_t incl = (uint32_t)wave_incl_scan_dpp((int)own);
     if (lane == 63) wsum[wid] = incl;
     __syncthreads();
@@ -40,8 +41,8 @@ __global__ __launch_bounds__(1024) void k_part_offsets(const uint32_t* __restric
     for (int w = 0; w < 16; w++) { if (w < wid) before += wsum[w]; total += wsum[w]; }
     uint32_t at = before + incl - own;
     for (int l = la; l < lb; l++) {
-        const uint32_t cnt = pcnt[(size_t)l * n_part + p];
-        poff[(size_t)l * n_part + p] = at;
+        const uint32_t cnt = pcnt[l];
+        poff[l] = at;
         at += cnt;
     }
     if (tid == 0) ptotal[(size_t)q * n_part + p] = total;

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
     const int c_lo = P.chain_off[chain], c_hi = P.chain_off[chain + 1];
     const int k = P.k;
     const uint32_t kmask = (1u << (2 * k)) - 1u;                  // (k <= 9 here)
-    W.wslot[lane] = (SCATTER && lane < P.n_part) ? P.poff[(size_t)chain * P.n_part + lane] + P.pstart[(size_t)P.link_q[chain] * P.n_part + lane] : 0u;
+    W.wslot[lane] = (SCATTER && lane < P.n_part) ? P.poff[(size_t)lane * P.n_links + chain] + P.pstart[(size_t)P.link_q[chain] * P.n_part + lane] : 0u;
     uint32_t slot0 = ONE ? P.poff[chain] : 0u;                     // ONE: the link's first slot (absolute: staging knows every link's events); then the read's
     if (SCATTER) W.flu[lane] = W.wslot[lane];
     // SCATTER: the slots [a, b) of lane p's partition go from the ring to part[], 64-B line by line (whole lines but for a link's
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
         }
     }
     if (SCATTER) flush(W.flu[lane], W.wslot[lane]);                 // what is left in the rings: each partition's last, partial line
-    if (MODE == PEV_COUNT && lane < P.n_part) P.pcnt[(size_t)chain * P.n_part + lane] = W.wslot[lane];
+    if (MODE == PEV_COUNT && lane < P.n_part) P.pcnt[(size_t)lane * P.n_links + chain] = W.wslot[lane];
 }
 
 // Reads cut into several pieces: the first pass wrote every piece's tile offsets relative to the piece's own first sample; the pieces
