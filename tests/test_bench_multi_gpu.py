@@ -62,3 +62,28 @@ def test_gpus_flag_without_enough_devices_fails_loudly():
                         "--no-cpu-baseline", "--no-store-probe", "--genome-mb", "8"], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode != 0
     assert "ranks but" in (p.stderr + p.stdout)
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_contract():
+    """the one JSON line of the driver's command (small genome and batches, short CPU legs): every field the contract names, the
+    roofline and cpu_baseline objects, the parity check of the timed regime"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--genome-mb", "24",
+                        "--batch-reads", "1024", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["metric"] == "simulated raw samples/sec" and d["unit"] == "samples/s" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None and d["value"] > 0 and d["ms_per_step"] > 0 and isinstance(d["dtype"], str)
+    assert "workload" in d["config"] and "dna-r10-prom" in d["config"]["workload"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert "traffic" in r and r["kernel"] == "k_samples_lean" and r["kernel_ms"] > 0 and 0 < r["step_frac"] < r["frac"]
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["unit"] == "samples/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    assert d["parity_check"]["equal"] is True and d["parity_check"]["reads_differing"] == 0
