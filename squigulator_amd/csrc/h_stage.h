@@ -173,16 +173,21 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     // the hand-out over bucketed events (k_part.h) instead of per-link rows: k > 6 (up to PART_MAX partitions of 4096 streams), and
     // k <= 6 as its one-partition case -- nothing to bucket, the events stay in chain order -- on devices with ordered LDS atomics
     const bool part_one = c->num_kmer <= PART_SUB && c->lds_ordered && !(c->cfg.flags & SQG_METH) && !getenv("SQG_PART_WG_EVENTS");
-    const bool part_ok = ((c->num_kmer > PART_SUB && c->num_kmer <= PART_MAX * PART_SUB) || part_one) && nev < 4294967000LL && !getenv("SQG_NO_PART");
+    const char* split_env = getenv("SQG_SPLIT_CHAINS");
+    const int forced = split_env ? atoi(split_env) : -1;
+    bool part_ok = ((c->num_kmer > PART_SUB && c->num_kmer <= PART_MAX * PART_SUB) || part_one) && nev < 4294967000LL && !getenv("SQG_NO_PART");
+    // ... when the events outweigh the tables: every (worker chain, partition) costs at least one 16-KiB table in three passes
+    // (hundreds of workers with a read or two each: the per-link rows, or no cut at all, are the better choice)
+    if (forced < 0 && !c->range_mode && nev < (long long)n_wchains * (part_one ? 1 : (c->num_kmer + PART_SUB - 1) >> PART_SUB_BITS) * 1024) part_ok = false;
     {
-        const char* env = getenv("SQG_SPLIT_CHAINS");
-        const int forced = env ? atoi(env) : -1;
+        // (bucketed hand-out: a link is one wavefront of k_part_events -- 8 per SIMD -- and may hold pieces of reads, so that a few
+        // long reads are worth cutting as well; one workgroup of k_events and whole reads otherwise)
+        const bool wave_links = part_ok && c->lds_ordered && !(c->cfg.flags & SQG_METH) && !getenv("SQG_PART_WG_EVENTS");
         const bool multi = n > n_wchains;
-        const bool want = c->range_mode ? n > 0 : forced >= 0 ? (forced > 0 && multi) : (multi && n_wchains < 1024 && nev >= 65536);
+        const bool want = c->range_mode ? n > 0 : forced >= 0 ? (forced > 0 && (multi || wave_links))
+                                                              : ((multi || (wave_links && n_wchains <= 16)) && n_wchains < 1024 && nev >= 65536);
         if (c->use_kmer_streams && want) {
             const size_t row_bytes = (size_t)c->num_kmer * sizeof(uint32_t);
-            // (bucketed hand-out: a link is one wavefront of k_part_events -- 8 per SIMD; one workgroup of k_events otherwise)
-            const bool wave_links = part_ok && c->lds_ordered && !(c->cfg.flags & SQG_METH) && !getenv("SQG_PART_WG_EVENTS");
             long long target = forced > 0 ? forced : wave_links ? 8192 : part_ok ? 4096 : 2048;
             if (!part_ok) target = std::min<long long>(target, std::max<long long>(8, (long long)(((size_t)1 << 30) / row_bytes)));
             std::vector<int> link_off(1, 0);

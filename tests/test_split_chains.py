@@ -215,3 +215,19 @@ def test_many_worker_chains_each_with_several_reads(name, T):
     batches = [_reads(rng, 12 * T, k, 1500), _reads(rng, T - 3, k, 1500) + _reads(rng, 5 * T, k, 900)]
     assert sum(max(len(r) - k + 1, 5) for r in batches[0]) > 70000
     _check(prof, fl, k, T, 5, batches, modes=(api.MODE_CERTIFIED,))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T,lens", [("dna-r10-prom", 1, [180000]), ("dna-r9-prom", 1, [150000]), ("dna-r10-prom", 2, [90000, 70001]),
+                                         ("rna004-prom", 3, [40000, 30000, 20000])])
+def test_a_few_long_reads_are_cut_into_pieces(name, T, lens):
+    """one read per worker, nothing but long reads: each is cut into pieces of whole segments that different wavefronts walk
+    (k_part_events.h) -- the time stream's position, the tile offsets and the read's totals have to come out as in one walk.
+    Two batches: the workers' streams carry over"""
+    rng = np.random.default_rng(17)
+    prof, fl = profiles.get_profile(name)
+    if fl & profiles.SQ_RNA:
+        fl |= profiles.SQ_PREFIX
+    k = profiles.default_kmer_size(fl)
+    batches = [[bytes(rng.choice(list(b"ACGT"), n).astype(np.uint8)) for n in lens] for _ in range(2)]
+    _check(prof, fl, k, T, 3, batches, modes=(api.MODE_CERTIFIED,))
