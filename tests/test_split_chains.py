@@ -205,10 +205,14 @@ def test_second_part_starts_at_every_position_of_a_segment(name, links, monkeypa
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("links", [None, "3000"])
 @pytest.mark.parametrize("name,T", [("dna-r10-prom", 20), ("dna-r10-prom", 37), ("dna-r9-prom", 33)])
-def test_many_worker_chains_each_with_several_reads(name, T):
-    """`-t 20 ... -t 37` with a dozen reads per worker: more than 1024 (worker chain, partition) pairs for the 9-mer table (k_part_slices
-    walks them 1024 at a time), chains of very different weight, workers without a read in the second batch"""
+def test_many_worker_chains_each_with_several_reads(name, T, links, monkeypatch):
+    """`-t 20 ... -t 37` with a dozen reads per worker: chains of very different weight, workers without a read in the second batch.
+    By default such a batch has too few events per (worker chain, partition) for the bucketed hand-out and takes the per-link rows;
+    forced links keep it there: more than 1024 pairs for the 9-mer table (k_part_slices walks them 1024 at a time)"""
+    if links:
+        monkeypatch.setenv("SQG_SPLIT_CHAINS", links)
     rng = np.random.default_rng(606 + T)
     prof, fl = profiles.get_profile(name)
     k = profiles.default_kmer_size(fl)
