@@ -178,8 +178,12 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 }
             }
             if (phase != 1) {
-                if ((size_t)pg.x * pg.y >= 512) hipLaunchKernelGGL(k_part_scan<64>, pg, dim3(1024), 0, c->stream, c->d_phist, c->d_rows, c->num_kmer, n_part, pfirst, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, direct ? 1 : 0, b->d_err);
-                else hipLaunchKernelGGL(k_part_scan<16>, dim3((unsigned)((c->num_kmer + 15) / 16), (unsigned)b->n_wchains), dim3(1024), 0, c->stream, c->d_phist, c->d_rows, c->num_kmer, n_part, pfirst, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, direct ? 1 : 0, b->d_err);
+#define SCANL(R_, G_) hipLaunchKernelGGL((k_part_scan<R_, G_>), dim3((unsigned)((c->num_kmer + R_ - 1) / R_), (unsigned)b->n_wchains), dim3(R_ * G_), 0, c->stream, \
+                                        c->d_phist, c->d_rows, c->num_kmer, n_part, pfirst, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, direct ? 1 : 0, b->d_err)
+                if ((long long)b->max_slices <= 8 * (long long)n_pairs) SCANL(256, 1);       // a slice or two per pair: one thread per rank walks them
+                else if ((size_t)pg.x * pg.y >= 512) SCANL(64, 16);
+                else SCANL(16, 64);
+#undef SCANL
                 if (before) {                                     // every worker's row moves past the whole batch, all ranges
                     const dim3 ag((unsigned)((n_rows + 255) / 256));
                     if (direct) hipLaunchKernelGGL(k_rows_advance<true>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);

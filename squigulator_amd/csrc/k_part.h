@@ -135,14 +135,15 @@ __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* __restrict__ 
 // as the slice finds it: seed(worker, rank) * a^(2 * samples before), the seed being (seed_base + worker*seed_step + rank) mod M
 // (src/sim.c:249).  states != 0 (k <= 6): the worker's row holds the streams' states themselves, as every other path of k <= 6
 // keeps them, and moves on by a^(2 * samples of the batch).
-// grid (num_kmer / R, worker chains), 1024 threads: R ranks x 1024 / R runs of consecutive slices (R = 64: 256-B rows of cells per
-// wavefront; R = 16 when that would leave CUs without a workgroup -- one partition with thousands of slices, k <= 6).
-template <int R>
-__global__ __launch_bounds__(1024) void k_part_scan(uint32_t* __restrict__ phist, uint32_t* __restrict__ rows, const int num_kmer, const int n_part,
+// grid (num_kmer / R, worker chains), R x G threads: R ranks x G runs of consecutive slices.  64 x 16: 256-B rows of cells per
+// wavefront; 16 x 64 when that would leave CUs without a workgroup (one partition with thousands of slices, k <= 6); 256 x 1 when
+// the (chain, partition) pairs are many and have a slice or two each (dozens of workers: a workgroup per 64 ranks and pair would be
+// millions of nearly idle workgroups).
+template <int R, int G>
+__global__ __launch_bounds__(R * G) void k_part_scan(uint32_t* __restrict__ phist, uint32_t* __restrict__ rows, const int num_kmer, const int n_part,
                                                     const uint32_t* __restrict__ pfirst, const int* __restrict__ wlink_worker,
                                                     const uint32_t* __restrict__ before, const uint32_t* __restrict__ pw,
                                                     const uint32_t seed_base, const uint32_t seed_step, const int states, unsigned int* __restrict__ err) {
-    constexpr int G = 1024 / R;
     __shared__ unsigned long long sums[G][R];
     const int lane = threadIdx.x % R, g = threadIdx.x / R, q = blockIdx.y;
     const int j = blockIdx.x * R + lane;
