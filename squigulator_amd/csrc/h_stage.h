@@ -185,7 +185,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         const bool wave_links = part_ok && c->lds_ordered && !(c->cfg.flags & SQG_METH) && !getenv("SQG_PART_WG_EVENTS");
         const bool multi = n > n_wchains;
         const bool want = c->range_mode ? n > 0 : forced >= 0 ? (forced > 0 && (multi || wave_links))
-                                                              : ((multi || (wave_links && n_wchains <= 16)) && n_wchains < 1024 && nev >= 65536);
+                                                              : ((multi || (wave_links && n_wchains <= 16)) && n_wchains < (wave_links && part_one ? 2048 : 1024) && nev >= 65536);   // (measured: from 2048 / 1024 chains on, one workgroup of k_events per chain is as fast or faster)
         if (c->use_kmer_streams && want) {
             const size_t row_bytes = (size_t)c->num_kmer * sizeof(uint32_t);
             long long target = forced > 0 ? forced : wave_links ? 8192 : part_ok ? 4096 : 2048;
