@@ -173,34 +173,41 @@ STEP_KERNELS = ("k_part_events", "k_part_tile_bases", "k_part_offsets", "k_part_
                 "k_part_hand", "k_events", "k_link_prefix", "k_scan", "k_items", "k_samples", "k_fixup")
 
 
-def pmc_step_traffic(workload_key):
-    """HBM bytes of one whole step -- every kernel of the timed region, one launch each -- from the same PMC passes
-    (profiles/traffic_latest.json); None when no profile of this workload exists"""
+def _traffic_doc(workload_key):
+    """profiles/traffic_latest.json if it belongs to THIS workload and to THESE kernels: the file is stamped with a hash of the
+    library's sources (squigulator_amd.build.source_hash) by tools/make_traffic.py; counters of other kernels are not quoted"""
+    from squigulator_amd import build as _b
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(path) as f:
             doc = json.load(f)
-        if doc.get("workload_key") != workload_key:
+        if doc.get("workload_key") != workload_key or doc.get("source_hash") != _b.source_hash():
             return None
-        return float(sum(v["hbm_bytes_per_launch"] for k, v in doc["kernels"].items() if k.startswith(STEP_KERNELS)))
+        return doc
     except (OSError, KeyError, ValueError):
+        return None
+
+
+def pmc_step_traffic(workload_key):
+    """HBM bytes of one whole step -- every kernel of the timed region, one launch each -- from the same PMC passes
+    (profiles/traffic_latest.json); None when no profile of this workload and this build exists"""
+    doc = _traffic_doc(workload_key)
+    try:
+        return None if doc is None else float(sum(v["hbm_bytes_per_launch"] for k, v in doc["kernels"].items() if k.startswith(STEP_KERNELS)))
+    except (KeyError, ValueError):
         return None
 
 
 def pmc_traffic(workload_key):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of the same command
-    (tools/prof_pmc.sh -> profiles/traffic_latest.json); None when no profile of this workload exists.
+    (tools/prof_pmc.sh -> profiles/traffic_latest.json); None when no profile of this workload and this build exists.
     The counters cannot be read from inside the process being timed, so the bench quotes the committed
-    measurement of the identical configuration."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    measurement of the identical configuration and the identical sources."""
+    doc = _traffic_doc(workload_key)
     try:
-        with open(path) as f:
-            doc = json.load(f)
-        if doc.get("workload_key") == workload_key:
-            return float(doc["kernels"]["k_samples_lean"]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
+        return None if doc is None else float(doc["kernels"]["k_samples_lean"]["hbm_bytes_per_launch"])
+    except (KeyError, ValueError):
+        return None
 
 
 def host_info():
@@ -382,10 +389,17 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL) for one rank per GPU; gloo only to exercise the N>1 control flow on a box with fewer GPUs than "
                          "ranks (ranks then share GPUs)")
+    ap.add_argument("--lib", default=None,
+                    help="measure THIS shared library instead of the in-tree build (A/B runs).  The SQG_LIB environment variable alone "
+                         "is refused: a bench line must say which library it timed")
     ap.add_argument("--digest", type=int, default=0,
                     help="D > 0 (tests): fetch every timed batch's signal and report, per batch, the sums of the reads' xxh64 digests "
                          "over D equal parts of the job's batch (N ranks report N*D/N parts each)")
     args = ap.parse_args()
+    if args.lib:
+        os.environ["SQG_LIB"] = os.path.abspath(args.lib)
+    elif os.environ.get("SQG_LIB"):
+        raise SystemExit("SQG_LIB is set but --lib was not given: bench.py measures the in-tree build unless told otherwise")
 
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:
@@ -505,7 +519,7 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     sig_ms, ev_ms, lean_ms = [], [], []
-    samples = bases = reads = 0
+    samples = bases = reads = fallback = 0
     digests = []
     timed = batches[args.warmup:]
     for b in timed:
@@ -518,7 +532,7 @@ def main():
         tm = gen.timing()
         sig_ms.append(tm["samples_ms"]); ev_ms.append(tm["events_ms"])
         lean_ms.append(tm["lean_ms"] if tm["lean_ms"] > 0 else tm["samples_ms"])
-        samples += b.n_samples; bases += b.n_bases; reads += b.n_reads
+        samples += b.n_samples; bases += b.n_bases; reads += b.n_reads; fallback += tm["fallback_samples"]
         if to_stage > 0:              # a long run: this batch makes room for one more (the device has STAGE_AHEAD - 1 queued meanwhile)
             b.free()
             timed[i] = None
@@ -577,6 +591,8 @@ def main():
         else:
             regime = f"-t {T} -K {T} (T=K virtual workers, {K} per GPU)"
         wkey = f"{args.workload}|{args.profile}|W={W}|batch_reads={K}|rlen={args.rlen}|mode={args.mode}"
+        from squigulator_amd import build as _build
+        lib_path = api.LOADED_PATH or _build.LIB
         out = {
             "metric": "simulated raw samples/sec",
             "value": tot_samples / dt_max,
@@ -598,7 +614,11 @@ def main():
                 "reads": "gen_read on the device-resident genome (library sampler), as the reference with these options",
                 "pore_model": "synthetic stand-in table (built-in ONT tables absent from the reference mount)",
             },
+            "library": {"path": os.path.relpath(lib_path, ROOT), "sha256_16": _build.file_hash(lib_path),
+                        "source_hash": _build.source_hash(), "in_tree": os.path.abspath(lib_path) == os.path.abspath(_build.LIB),
+                        "stale": _build.needs_build()},
             "reads_per_s": tot_reads / dt_max,
+            "fp64_fixup_frac": (fallback / samples if samples else 0.0) if args.mode == "certified" else None,   # samples the fp32 path left to FP64
             "samples_per_step_per_gpu": samples / steps,
             "kernel_ms": {"k_samples_lean": k_ms,
                           # from the end of the event side to the batch's last kernel; the fix-ups run on their own stream next to

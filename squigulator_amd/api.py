@@ -83,6 +83,7 @@ EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_d
            "sqg_genome_set_meth")
 
 _lib = None
+LOADED_PATH = None          # the library the last load_library() call opened (bench.py prints it with its hash)
 
 
 def load_library(path: str | None = None):
@@ -95,6 +96,8 @@ def load_library(path: str | None = None):
         raise RuntimeError(f"{path} is missing: build it with `python -m squigulator_amd.build` "
                            "(there is no CPU fallback for the signal path)")
     L = C.CDLL(path)
+    global LOADED_PATH
+    LOADED_PATH = os.path.abspath(path)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.sqg_create.restype = C.c_int
     L.sqg_create.argtypes = [C.POINTER(CCfg), C.POINTER(vp)]

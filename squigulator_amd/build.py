@@ -18,9 +18,34 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsqg_hip.so")
 SOURCES = [os.path.join(CSRC, "sqg_hip.hip")]
-HEADERS = [os.path.join(os.path.dirname(HERE), "include", "sqg.h")] + \
-          [os.path.join(CSRC, h) for h in ("sqg_kernels.h", "k_common.h", "k_events.h", "k_part.h", "k_samples.h", "k_sampler.h", "k_svb.h",
-                                           "h_common.h", "h_context.h", "h_stage.h", "h_sampler.h", "h_run.h", "h_results.h", "h_blow5.h")]
+import glob
+import hashlib
+
+
+def headers() -> list:
+    """every header the one translation unit includes: include/sqg.h and all of csrc/*.h (globbed: a new header is a dependency
+    the moment it exists)"""
+    return [os.path.join(os.path.dirname(HERE), "include", "sqg.h")] + sorted(glob.glob(os.path.join(CSRC, "*.h")))
+
+
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the sources the library is built from, in a fixed order: stamps the PMC traffic file
+    (tools/make_traffic.py) so that bench.py can tell whether the counters it quotes belong to the kernels it runs"""
+    h = hashlib.sha256()
+    for p in SOURCES + headers():
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def file_hash(path: str) -> str:
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
 ARCH = "gfx950"
 
 
@@ -35,7 +60,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+    return any(os.path.getmtime(p) > t for p in SOURCES + headers())
 
 
 def build(force: bool = False, verbose: bool = True) -> str:

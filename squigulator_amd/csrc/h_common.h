@@ -36,6 +36,9 @@ struct sqg_ctx {
         uint4* d_tfix = nullptr; size_t tfix_cap = 0;
         unsigned char* d_tfix_n = nullptr; size_t tfixn_cap = 0;
         ItemDesc* d_items = nullptr; size_t items_cap = 0;          // [n_stiles] work items of the lean kernel (k_items)
+        uint32_t* d_part = nullptr; size_t part_cap = 0;            // [n_events] bucketed events (k_part.h).  Per slot: with one partition
+                                                                    // (k <= 6) the sample kernels -- the generic one and the fix-ups run on
+                                                                    // fix_stream, next to the following batch's event pass -- read rank and dwell from it
         uint32_t* d_part_state = nullptr; size_t part_state_cap = 0;   // [n_events] k > 6, split chains (k_part.h): stream state at each
                                                                     // bucketed event; read by the sample kernels like evrec
         unsigned long long gen = 0;                // bumped whenever a batch starts writing the slot's buffers
@@ -47,7 +50,6 @@ struct sqg_ctx {
     unsigned long long* d_scan_part = nullptr; size_t scan_part_cap = 0;   // k_scan: {ticket, total} per workgroup
     uint32_t* d_link_rows = nullptr; size_t link_rows_cap = 0;   // split chains: one row per link of the running batch
     // k > 6, split chains (k_part.h), buffers of the running batch
-    uint32_t* d_part = nullptr; size_t part_cap = 0;             // [n_events] bucketed events
     uint32_t* d_pcnt = nullptr; size_t pcnt_cap = 0;             // [n_links][n_part]
     uint32_t* d_slice = nullptr; size_t slice_cap = 0;           // {slice_lo, slice_hi}[max_slices], pfirst[n_pairs + 1], pstart, ptotal [n_pairs] (k_part.h)
     uint32_t* d_phist = nullptr; size_t phist_cap = 0;           // [max_slices][PART_SUB]

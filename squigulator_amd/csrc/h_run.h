@@ -53,7 +53,6 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     const int kmer_pad = n_part * PART_SUB;
     const size_t n_pairs = (size_t)b->n_wchains * (size_t)n_part;   // (worker chain, partition)
     if (phase != 2 && b->part) {
-        if ((rc = ensure(c, (void**)&c->d_part, &c->part_cap, (size_t)b->n_events + PART_SLACK, sizeof(uint32_t)))) return rc;
         if ((rc = ensure(c, (void**)&c->d_pcnt, &c->pcnt_cap, (size_t)2 * b->n_chains * (size_t)n_part, sizeof(uint32_t)))) return rc;   // counts, offsets
         if ((rc = ensure(c, (void**)&c->d_slice, &c->slice_cap, (size_t)2 * (size_t)b->max_slices + (size_t)3 * n_pairs + 1, sizeof(uint32_t)))) return rc;
         if ((rc = ensure(c, (void**)&c->d_phist, &c->phist_cap, (size_t)b->max_slices * (size_t)PART_SUB, sizeof(uint32_t)))) return rc;
@@ -63,7 +62,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     SigParams P;
     memset(&P, 0, sizeof P);
     P.link_rows = (b->split && !b->part) ? c->d_link_rows : nullptr;
-    P.part = c->d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = c->d_pcnt; P.poff = b->one ? b->d_link_slot : c->d_pcnt ? c->d_pcnt + (size_t)b->n_chains * n_part : nullptr; P.n_part = n_part; P.n_links = b->n_chains;
+    P.part = S.d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = c->d_pcnt; P.poff = b->one ? b->d_link_slot : c->d_pcnt ? c->d_pcnt + (size_t)b->n_chains * n_part : nullptr; P.n_part = n_part; P.n_links = b->n_chains;
     P.link_q = b->d_link_q; P.pieces = b->d_pieces; P.piece_total = b->d_piece_total;
     P.one = b->one ? 1 : 0;
     P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
@@ -168,7 +167,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                     if ((rc = dbg_sync(c, "k_events<count>/k_part_offsets"))) return rc;
                     launch_part_events(0, false);                 // every event to its slot (the dwell is in memory now)
                 }
-                hipLaunchKernelGGL(k_part_hist, dim3(pgrid), dim3(256), 0, c->stream, c->d_part, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist);
+                hipLaunchKernelGGL(k_part_hist, dim3(pgrid), dim3(256), 0, c->stream, S.d_part, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist);
                 HIPCHK(c, hipGetLastError());
                 if ((rc = dbg_sync(c, "k_events<scatter>/k_part_hist"))) return rc;
                 if (phase == 1) {                                 // range sharding: what this range draws per stream, for the exchange
@@ -189,9 +188,9 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                     if (direct) hipLaunchKernelGGL(k_rows_advance<true>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
                     else hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
                 }
-                if (c->lds_ordered) hipLaunchKernelGGL(k_part_hand_ord, dim3(pgrid), dim3(64), 0, c->stream, c->d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow);
-                else if (c->dwell_hi >= (double)PART_JT) hipLaunchKernelGGL(k_part_hand<true>, dim3(pgrid), dim3(64), 0, c->stream, c->d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);
-                else hipLaunchKernelGGL(k_part_hand<false>, dim3(pgrid), dim3(64), 0, c->stream, c->d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);
+                if (c->lds_ordered) hipLaunchKernelGGL(k_part_hand_ord, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow);
+                else if (c->dwell_hi >= (double)PART_JT) hipLaunchKernelGGL(k_part_hand<true>, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);
+                else hipLaunchKernelGGL(k_part_hand<false>, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);
                 HIPCHK(c, hipGetLastError());
                 if ((rc = dbg_sync(c, "k_part_scan/k_part_hand"))) return rc;
             }

@@ -45,6 +45,7 @@ static int grow_slot(sqg_ctx* c, sqg_ctx::Slot& Z, const sqg_batch* b, bool with
     }
     if ((rc2 = ensure(c, (void**)&Z.d_dwell, &Z.dwell_cap, (size_t)b->n_events + 1024, sizeof(uint16_t)))) return rc2;
     if ((rc2 = ensure(c, (void**)&Z.d_evrec, &Z.evrec_cap, (size_t)b->n_events + 64, sizeof(uint2)))) return rc2;
+    if (b->part && (rc2 = ensure(c, (void**)&Z.d_part, &Z.part_cap, (size_t)b->n_events + PART_SLACK, sizeof(uint32_t)))) return rc2;
     if (b->part && (rc2 = ensure(c, (void**)&Z.d_part_state, &Z.part_state_cap, (size_t)b->n_events + PART_SLACK, sizeof(uint32_t)))) return rc2;
     if ((rc2 = ensure(c, (void**)&Z.d_tile_so, &Z.tile_cap, (size_t)b->n_tiles + 64, sizeof(uint32_t)))) return rc2;
     if ((rc2 = ensure(c, (void**)&Z.d_slow, &Z.slow_cap, (size_t)b->n_tiles + 64, sizeof(int)))) return rc2;

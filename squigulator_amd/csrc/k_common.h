@@ -17,6 +17,13 @@
 #define POW_WORDS (4 * POW_N + POW_TOP)
 #define LCG_ORD2 1073741823u   // (M-1)/2: a^(2n) depends on n mod this
 
+#ifndef SQG_U2
+#define SQG_U2 1            // second uniform of the fp32 deviate: 0 = FP64 fract, 1 = int -> float conversion, 2 = mantissa bits (A/B)
+#endif
+
+#ifndef SQG_NEARONE
+#define SQG_NEARONE 0       // A/B: the near-one states rejected through a NaN instead of a comparison (k_samples_lean)
+#endif
 #define NEAR_ONE_BITS 17    // c1 > M - 2^17 (u within 6e-5 of 1): always taken to the FP64 path
 
 // ---- MINSTD in canonical form: c' = a*c mod (2^31-1), c in [1, M-1] -------------------------
@@ -66,7 +73,14 @@ __device__ static inline double box_muller_exact(uint32_t c1, uint32_t c2) {
 // v_log_f32 is log2, v_cos_f32 takes turns.  The 6.2831853-vs-2*pi ratio (1 - 1.1e-9) is below fp32
 // resolution; the sweep (k_certify) prices it with everything else.
 __device__ static inline float box_muller_fast(uint32_t c1) {
+#if SQG_NEARONE
+    // c1 * 2^-31 -- and a NaN for the states next to M (c1 > M - 2^17, where -2 ln u cancels: they always take the FP64 path): with
+    // 2^17 added the integer turns negative there, v_log_f32 of a negative number is NaN, and a NaN fails every acceptance test
+    // (|d| < thr is false) without a comparison of its own
+    const float uf = __builtin_fmaf((float)(int)(c1 + (1u << NEAR_ONE_BITS)), 4.656612873077393e-10f, -6.103515625e-05f);
+#else
     const float uf = (float)c1 * 4.656612873077393e-10f;                  // c1 * 2^-31 (exact scaling)
+#endif
     const float lg = __builtin_amdgcn_logf(uf);                           // (log2 of the UNscaled c1 would save this multiplication, but
                                                                           // v_log_f32's error grows with |log2|: near 2^30 the swept bound
                                                                           // becomes 10x larger and 2e-3 of the samples fall back: measured)
@@ -74,8 +88,23 @@ __device__ static inline float box_muller_fast(uint32_t c1) {
     const float r = __builtin_amdgcn_sqrtf(y);
     // second uniform c2/M = frac(a*c1/M): four full-rate FP64/convert instructions instead of a modular
     // multiplication plus an int->float conversion (the product is exact to 2^-39, far below fp32 resolution)
+#if SQG_U2 == 0
     const double t2 = (double)c1 * (16807.0 / 2147483647.0);                // a / M
     const float cs = __builtin_amdgcn_cosf((float)__builtin_amdgcn_fract(t2));
+#else
+    // ... without FP64: with p = a*c1 (46 bits), frac(p / M) = frac(p 2^-31 + p 2^-62) to 2^-60.  The first term's fraction is
+    // the low 31 bits of p: v_mul_lo_u32 keeps 32 of them, and v_cos_f32 is periodic -- an integer more or less does not matter.
+    // The second term, < 2^-16, is uf * a 2^-31.  fp32 resolves the sum to 2^-24 turns; k_certify prices that with the rest.
+#if SQG_U2 == 1
+    const uint32_t plo = c1 * 16807u;
+    const float t2 = __builtin_fmaf((float)(int)plo, 4.656612873077393e-10f, uf * 7.826369259425611e-06f);   // a 2^-31
+#else
+    const uint32_t plo = c1 * 33614u;                                        // low 32 bits of 2p: bits 30..0 of p on top
+    // the top 23 bits of the 32 as the mantissa of a float in [1, 2) (truncated: up to 2^-23 turns too low; part of what k_certify measures)
+    const float t2 = __builtin_fmaf(uf, 7.826369259425611e-06f, __uint_as_float(__builtin_amdgcn_alignbit(0x7fu, plo, 9))) ;
+#endif
+    const float cs = __builtin_amdgcn_cosf(t2);
+#endif
     return r * cs;
 }
 

@@ -39,6 +39,9 @@ __device__ static inline void push_fix_one(const SigParams& P, long long at, uin
     } else atomicOr(P.err, 8u);
 }
 
+#ifndef SQG_LEAN_XCD
+#define SQG_LEAN_XCD 1                     // A/B: XCD-contiguous item map of k_samples_lean
+#endif
 #define LEAN_EPL_MAX 4                     // events per lane of the lean kernel: 4, 2 or 1 (SigParams.lean_epl, chosen per profile so
                                            // that a work item -- 64*epl consecutive events of a read -- stays below LEAN_MAX_SAMPLES)
 #define FIX_SLOTS 8                        // parked undecided samples per super tile (expected ~0.5); overflow -> global list
@@ -145,7 +148,17 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
     const float thr = P.thr_all;
     const char* mult_b = reinterpret_cast<const char*>(L.mult);
 
-    for (int g = blockIdx.x * 4 + wid; g < n_stiles; g += gridDim.x * 4) {
+    // workgroup -> items: consecutive workgroup ids are dispatched to different XCDs (id % 8), each with an L2 of its own, while
+    // consecutive ITEMS share lines of state[] / part[] (a (link, partition)'s run of slots spans ~4 items of a read): XCD x takes
+    // the x-th eighth of the items, so that the neighbours' lines are hits in ITS L2 instead of a second fetch by another one
+    unsigned wg0 = blockIdx.x;
+#if SQG_LEAN_XCD
+    {
+        const unsigned q = gridDim.x >> 3, rem = gridDim.x & 7u, x = blockIdx.x & 7u;
+        wg0 = x * q + min(x, rem) + (blockIdx.x >> 3);
+    }
+#endif
+    for (int g = (int)wg0 * 4 + wid; g < n_stiles; g += gridDim.x * 4) {
         // the item's descriptor -- what the read, its 64-event tiles and the scanned read offsets say about this item -- is
         // wave-uniform: the whole look-up chain runs on the scalar unit (sload: constant-address-space loads)
         ItemDesc it;
@@ -305,7 +318,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
             const float d = vh - (t - LEAN_MAGIC);                                                                \
             const int si_ = (int)(idx4 >> 2) + 64 * (DI);              /* my sample index within the item */         \
             const bool act = !(TAIL) || si_ < wave_total;                                                         \
-            const bool ok = fabsf(d) < thr && c1 <= LCG_M - (1u << NEAR_ONE_BITS);                                \
+            const bool ok = fabsf(d) < thr LEAN_NEARONE_TEST;                                                     \
             /* RNA adaptor window: the ADC value gets -(int16)(30*dig/range) with int16 wrap (src/genread.c:79-86) */ \
             const bool shf = (SH) && (uint32_t)(si_ - it.shift_lo) < (uint32_t)(it.shift_hi - it.shift_lo);       \
             char* const dst_b = out_b + (RNA ? -128 * (DI) : 128 * (DI));                                         \
@@ -326,6 +339,11 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
             MN = *reinterpret_cast<const uint32_t*>(mult_b + ((DI) == (ST) - 1 ? 0 : 256 * ((DI) + 1)) + (idx4 - (RN.y >> 16))); }
 
         /* ablation builds (tools/ab_variants.sh; results are wrong): -DSQG_ABL_NOARITH, -DSQG_ABL_NOSTORE, -DSQG_ABL_NOLOOP */
+#if SQG_NEARONE
+        #define LEAN_NEARONE_TEST                                      /* box_muller_fast returns NaN there: |d| < thr is false */
+#else
+        #define LEAN_NEARONE_TEST && c1 <= LCG_M - (1u << NEAR_ONE_BITS)
+#endif
 #if defined(SQG_ABL_NOSTORE)
         #define LEAN_STORE_COND && (__float_as_uint(t) == 0x12345u)
 #else
@@ -371,6 +389,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         #undef LEAN_EVOF
         #undef LEAN_ARITH
         #undef LEAN_STORE_COND
+        #undef LEAN_NEARONE_TEST
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         const int nfix = W.nfix;
         if ((LEAN_EPL == 4 || nfix) && lane == 0) P.tfix_n[g] = (unsigned char)min(nfix, FIX_SLOTS);   // (k_items cleared it for the short items)

@@ -235,3 +235,34 @@ def test_a_few_long_reads_are_cut_into_pieces(name, T, lens):
     k = profiles.default_kmer_size(fl)
     batches = [[bytes(rng.choice(list(b"ACGT"), n).astype(np.uint8)) for n in lens] for _ in range(2)]
     _check(prof, fl, k, T, 3, batches, modes=(api.MODE_CERTIFIED,))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob", ["SQG_TEST_NO_LEAN", "SQG_TEST_DELTA_X"])
+def test_queued_one_partition_batches_keep_their_own_events(knob, monkeypatch):
+    """k <= 6, few workers (the one-partition hand-out): the sample kernels read rank and dwell from part[].  Batch i's generic
+    kernel and fix-ups run on a stream of their own, next to batch i+1's event pass -- which must not write the part[] batch i is
+    still reading (part[] is per slot).  Batches of different reads queued back to back, every tile through the slow kernels."""
+    monkeypatch.setenv(knob, "1" if knob == "SQG_TEST_NO_LEAN" else "0.05")
+    rng = np.random.default_rng(11)
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    mean, stdv = model.synthetic_model(6)
+    # a long batch (its slow kernels take a while) followed by short ones (their event passes are over quickly), several rounds
+    sizes = [3000, 160, 160, 3000, 160]
+    batches = [[bytes(rng.choice(list(b"ACGT"), int(m)).astype(np.uint8)) for m in rng.integers(300, 1500, n)] for n in sizes]
+    orac = orc.Oracle(prof, fl, 6, mean, stdv, 42, num_workers=1)
+    want = [orac.run_batch_seqs(bt, want_ss=False) for bt in batches]
+    orac.close()
+    gen = api.SignalGenerator(prof, fl, 6, mean, stdv, 42, num_workers=1, mode=api.MODE_CERTIFIED)
+    # two batches in flight at any time (a batch's results live in its slot until the batch after the next one runs)
+    staged = [gen.stage(bt) for bt in batches]
+    staged[0].run()
+    for bi in range(len(staged)):
+        if bi + 1 < len(staged):
+            staged[bi + 1].run()
+        b = staged[bi].wait()
+        sig = b.signal()
+        for i, w in enumerate(want[bi]):
+            np.testing.assert_array_equal(sig[b.sig_off[i]:b.sig_off[i + 1]], w.sig, err_msg=f"batch {bi} read {i}")
+        b.free()
+    gen.close()

@@ -23,7 +23,9 @@ for f, name in (("pmc4", "FETCH_SIZE"), ("pmc5", "WRITE_SIZE")):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == name:
             acc[r["Kernel_Name"]][name].append(float(r["Counter_Value"]))
-out = {"round": rnd, "workload_key": key,
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from squigulator_amd import build as _build  # noqa: E402
+out = {"round": rnd, "workload_key": key, "source_hash": _build.source_hash(),
        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/prof_pmc.sh); unit KiB; "
                  "FETCH_SIZE doubled per the gfx950 correction (MI355X_MICROARCH.md, HBM); WRITE_SIZE checked on "
                  "k_store_probe (1 GiB written per launch)",
