@@ -356,6 +356,30 @@ def parity_check(prof, flags, k, mean, stdv, contigs, rlen, n_reads, one_worker,
     return out, rate
 
 
+def pipeline_leg(stage_one, run, n_batches):
+    """Nothing staged ahead: ONE host thread samples + stages batch i+1 (device-side gen_read, descriptors, links), queues it, waits
+    for batch i and frees it -- two batches in flight, results left in HBM.  Returns (samples, reads, seconds, host seconds spent
+    in the sampler + staging call per batch)."""
+    cur = run(stage_one())
+    samples = reads = 0
+    t_stage = 0.0
+    t0 = time.perf_counter()
+    for _ in range(n_batches):
+        a = time.perf_counter()
+        nxt = stage_one()
+        t_stage += time.perf_counter() - a
+        run(nxt)
+        cur.wait()
+        samples += cur.n_samples; reads += cur.n_reads
+        cur.free()
+        cur = nxt
+    cur.wait()
+    samples += cur.n_samples; reads += cur.n_reads
+    dt = time.perf_counter() - t0
+    cur.free()
+    return samples, reads, dt, t_stage / max(n_batches, 1)
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -379,6 +403,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall time of each multi-process CPU leg")
     ap.add_argument("--no-store-probe", action="store_true")
+    ap.add_argument("--pipeline-seconds", type=float, default=2.5,
+                    help="wall time of the streaming leg (`pipeline` in the line: nothing staged ahead, sampler + staging + run + free "
+                         "from one host thread); 0 skips it")
     ap.add_argument("--workers-per-gpu", type=int, default=None,
                     help="W > 0: the job has T = N*W virtual workers, W per GPU (sharded by worker, no data-path collective), and every "
                          "batch of N*K reads is split over them as the reference's static partition does (src/thread.c:80-99): "
@@ -392,6 +419,10 @@ def main():
     ap.add_argument("--lib", default=None,
                     help="measure THIS shared library instead of the in-tree build (A/B runs).  The SQG_LIB environment variable alone "
                          "is refused: a bench line must say which library it timed")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even for ONE rank (rendezvous on 127.0.0.1): the model broadcast, the barriers, the "
+                         "reductions and -- with --job-workers -- the per-batch all-gather of the stream counts then run through the "
+                         "chosen backend (nccl = RCCL) exactly as they do at N > 1 (tests: RCCL on a one-GPU box)")
     ap.add_argument("--digest", type=int, default=0,
                     help="D > 0 (tests): fetch every timed batch's signal and report, per batch, the sums of the reads' xxh64 digests "
                          "over D equal parts of the job's batch (N ranks report N*D/N parts each)")
@@ -425,11 +456,15 @@ def main():
     local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        kw = {}
+        if world_env is None:                                      # a single rank started by hand (--force-dist)
+            kw = dict(init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, **kw)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", **kw)
 
     wl_profile, wl_flags, wl_mode, wl_w, wl_k, wl_desc = WORKLOADS[args.workload]
     K = args.batch_reads or wl_k
@@ -446,7 +481,7 @@ def main():
         mean, stdv = model.synthetic_model(k)
     else:
         mean, stdv = np.zeros(n_k, np.float32), np.zeros(n_k, np.float32)
-    if world > 1:
+    if use_dist:
         mean, stdv = shard.broadcast_model(mean, stdv, src=0)
 
     range_mode = args.job_workers > 0
@@ -493,7 +528,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -506,12 +541,13 @@ def main():
         if not range_mode or not gen_has_streams:
             return b.run()
         mine = shard.counts_tensor(b.run_begin(), n_rows, dev)
-        if world > 1:
+        if use_dist:
             before, after = shard.exchange_counts(mine)
         else:
             before = after = torch.zeros_like(mine)
         torch.cuda.synchronize()
         keep.append((before, after))                               # alive until the batch has run
+        del keep[:-4]
         return b.run_end(before.data_ptr(), after.data_ptr())
 
     for b in batches[:args.warmup]:
@@ -560,13 +596,16 @@ def main():
                 parts.append(acc)
             digests.append(parts)
 
-    on_gpu = world == 1 or args.backend == "nccl"
+    on_gpu = not use_dist or args.backend == "nccl"
     tot = torch.tensor([float(samples), float(reads), dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
-    if world > 1:
+    dt_min = dt
+    if use_dist:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        mn = tot.clone()
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        dt_max = float(mx[2])
+        dt_max, dt_min = float(mx[2]), float(mn[2])
         if args.digest:
             allq = [None] * world
             dist.all_gather_object(allq, digests)
@@ -575,6 +614,24 @@ def main():
     else:
         dt_max = dt
     tot_samples, tot_reads = float(tot[0]), float(tot[1])
+
+    # the streaming leg: the same job with nothing staged ahead (the sampler's and the staging kernels share the GPU with the generator)
+    pipe = None
+    if args.pipeline_seconds > 0 and not args.digest:
+        for b in batches[:args.warmup] + [b for b in timed if b is not None]:
+            b.free()
+        batches, timed = [], []
+        n_pipe = int(min(max(args.pipeline_seconds / max(dt_max / max(args.steps, 1), 1e-5), 8), 20000))
+        sync_all()
+        pipe = pipeline_leg(stage_one, run, n_pipe)
+        sync_all()
+
+    ptot = torch.tensor(list(pipe[:3]) if pipe else [0.0, 0.0, 1.0], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+    if use_dist:
+        pmx = ptot.clone()
+        dist.all_reduce(pmx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ptot, op=dist.ReduceOp.SUM)
+        ptot[2] = pmx[2]
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -617,6 +674,15 @@ def main():
             "library": {"path": os.path.relpath(lib_path, ROOT), "sha256_16": _build.file_hash(lib_path),
                         "source_hash": _build.source_hash(), "in_tree": os.path.abspath(lib_path) == os.path.abspath(_build.LIB),
                         "stale": _build.needs_build()},
+            # the N ranks' own clocks around the same K steps (value uses the slowest) and what torch.distributed says the world is
+            "ranks": {"world_size": dist.get_world_size() if use_dist else 1, "backend": dist.get_backend() if use_dist else None,
+                      "ms_per_step_min": dt_min / steps * 1e3, "ms_per_step_max": dt_max / steps * 1e3},
+            "pipeline": None if pipe is None else {
+                "value": float(ptot[0]) / float(ptot[2]), "unit": "samples/s", "reads_per_s": float(ptot[1]) / float(ptot[2]),
+                "seconds": float(ptot[2]), "batches_per_gpu": n_pipe + 1, "ms_per_step": float(ptot[2]) / (n_pipe + 1) * 1e3,
+                "host_stage_ms_per_batch": pipe[3] * 1e3, "vs_value": float(ptot[0]) / float(ptot[2]) / (tot_samples / dt_max),
+                "what": "nothing staged ahead: one host thread per GPU samples (device-side gen_read) + stages batch i+1, queues it, "
+                        "waits for batch i and frees it; two batches in flight, results left in HBM"},
             "reads_per_s": tot_reads / dt_max,
             "fp64_fixup_frac": (fallback / samples if samples else 0.0) if args.mode == "certified" else None,   # samples the fp32 path left to FP64
             "samples_per_step_per_gpu": samples / steps,
@@ -667,7 +733,7 @@ def main():
     for b in batches[:args.warmup] + [b for b in timed if b is not None]:
         b.free()
     gen.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -50,6 +50,12 @@ extern "C" {
  * src/seq.h:45-74, and a worker's seeds advance by 5^k + 10 (src/sim.c:325).  Reads handed to sqg_batch_stage carry 'M' where
  * gen_read methylated a CpG; the device sampler does it itself once sqg_genome_set_meth has been called. */
 #define SQG_METH        0x1000u
+/* not an opt_t.flag bit either, and no effect on any result: the few-worker stream hand-out normally relies on the lanes of one
+ * LDS atomic being served in ascending lane order -- verified for gfx950 offline (2e8 fetch-adds, tools/README.md), re-checked
+ * on the device at sqg_create in the production shape (4096-entry table, 16-bit addends, four wavefronts per CU) and sampled in
+ * every batch (the first events of every slice against order-free prefix sums; a mismatch fails the batch).  Set: the context
+ * uses the order-free kernels (claim protocol, lane masks) from the start -- slower, no such dependence. */
+#define SQG_ORDER_FREE  0x2000u
 
 /* error codes */
 #define SQG_OK            0
@@ -59,6 +65,7 @@ extern "C" {
 #define SQG_ESEQUENCE    -4   /* batches must be run in the order staged      */
 #define SQG_ENODEVICE    -5   /* no usable gfx950 device / HIP not available  */
 #define SQG_EOVERFLOW    -6   /* a read would exceed UINT32_MAX samples (src/sim.c:559-562) */
+#define SQG_EIO          -7   /* the BLOW5 writer could not open / write its file (errno text: stderr / sqg_blow5_last_error) */
 
 /* arithmetic mode of the sample kernel */
 #define SQG_MODE_EXACT      0 /* every sample through the FP64 path                      */

@@ -12,6 +12,7 @@
  * The BLOW5 writer is the product's own host code (squigulator_amd/csrc/h_blow5.h), compiled in unchanged.
  */
 #include <algorithm>
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -60,6 +61,7 @@ extern "C" const char* sqg_strerror(int code) {
     case SQG_ESEQUENCE: return "batches must be run in staging order";
     case SQG_ENODEVICE: return "no usable HIP device";
     case SQG_EOVERFLOW: return "read too long (>= UINT32_MAX samples) or dwell > 65535";
+    case SQG_EIO: return "file I/O error";
     default: return "unknown error";
     }
 }

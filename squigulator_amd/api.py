@@ -18,7 +18,7 @@ MODE_EXACT = 0
 MODE_CERTIFIED = 1
 
 _ERRORS = {-1: "SQG_EINVAL", -2: "SQG_ENOMEM", -3: "SQG_EDEVICE", -4: "SQG_ESEQUENCE",
-           -5: "SQG_ENODEVICE", -6: "SQG_EOVERFLOW"}
+           -5: "SQG_ENODEVICE", -6: "SQG_EOVERFLOW", -7: "SQG_EIO"}
 
 
 class SqgError(RuntimeError):
@@ -174,6 +174,55 @@ def load_library(path: str | None = None):
     return L
 
 
+def _atoi(t: str) -> int:
+    """C atoi: optional blanks and sign, then the leading digits (0 when there are none)"""
+    import re
+    m = re.match(r"\s*([+-]?\d+)", t)
+    return int(m.group(1)) if m else 0
+
+
+def _atof(t: str) -> float:
+    """C atof: the longest leading decimal floating-point prefix (0.0 when there is none)"""
+    import re
+    m = re.match(r"\s*([+-]?(\d+\.?\d*([eE][+-]?\d+)?|\.\d+([eE][+-]?\d+)?|inf(inity)?|nan))", t, re.I)
+    return float(m.group(1)) if m else 0.0
+
+
+def load_meth_freq(contigs, names, meth_freq_path: str):
+    """load_meth_freq, src/ref.c:291-361: the --meth-freq table (tab separated: contig, 0-based position of a C, frequency in [0, 1])
+    as one frequency byte per base of the concatenated contigs + a flag per contig; the reference's checks, as ValueError"""
+    idx = {n: i for i, n in enumerate(names)}
+    arrs = [np.zeros(len(c), np.uint8) for c in contigs]
+    has = np.zeros(len(contigs), np.uint8)
+    with open(meth_freq_path) as f:
+        for line, ln in enumerate(f):
+            if ln.startswith("#"):
+                continue
+            # the checks of load_meth_freq, src/ref.c:314-345 (the reference exits; here: ValueError naming the line)
+            cols = ln.rstrip("\n").split("\t")
+            if len(cols) < 3 or not all(cols[:3]):
+                raise ValueError(f"{meth_freq_path}: malformed line {line} (need contig, position, frequency; src/ref.c:279-289)")
+            name, pos, fr = cols[:3]
+            if name not in idx:
+                raise ValueError(f"There was no such chromosome in the reference. Check line {line} value {name} of the input methy-freq file.")
+            i, p = idx[name], _atoi(pos)
+            if p < 0:
+                raise ValueError(f"Chromosome position cannot be negative. Check line {line} value {p} of the input methy-freq file.")
+            if p >= len(contigs[i]):
+                raise ValueError(f"Chromosome {name} position must be less than the length {len(contigs[i])}. Check line {line} value {p} "
+                                 "of the input methy-freq file.")
+            if contigs[i][p:p + 1] not in (b"C", b"c"):
+                raise ValueError(f"The chromosome {name} position {p} in the reference was a {contigs[i][p:p + 1].decode()}. How can it be "
+                                 f"methylated C? Check line {line} of the input methy-freq file.")
+            fq = float(np.float32(_atof(fr)))
+            if fq < 0 or fq > 1:
+                raise ValueError(f"Methylation frequency must be between 0 to 1. Check line {line} value {fq:f} of the input methy-freq file.")
+            has[i] = 1
+            arrs[i][p] = int(np.floor(float(np.float32(fq) * np.float32(255)) + 0.5))     # (uint8_t)roundf(freq*255), float freq
+    blob = np.concatenate(arrs) if arrs else np.zeros(1, np.uint8)
+    return blob, has
+
+
 class Blow5Writer:
     """The library's native BLOW5 writer (sqg_blow5_*): header, record framing and zlib on host threads; the signal field is
     the svb-zd encoding made on the device.  Pure host code: write() works without a GPU."""
@@ -321,7 +370,7 @@ class SignalGenerator:
         a = np.frombuffer(self._model, dtype=np.float32).reshape(n, 2)
         a[:, 0] = level_mean
         a[:, 1] = level_stdv
-        cfg = CCfg(ABI_VERSION, CProfile(*profile.as_tuple()), flags & 0x103d, amp_noise, kmer_size,
+        cfg = CCfg(ABI_VERSION, CProfile(*profile.as_tuple()), flags & 0x303d, amp_noise, kmer_size,
                    self._model, seed, num_workers, worker_lo,
                    num_workers if worker_hi is None else worker_hi, device, mode)
         h = C.c_void_p()
@@ -383,20 +432,7 @@ class SignalGenerator:
     def set_meth(self, contigs, names, meth_freq_path: str):
         """--meth-freq FILE (tab separated: contig, 0-based position of a C, frequency) for the genome loaded with
         load_genome(contigs): the per-base frequency bytes load_meth_freq builds (src/ref.c:291-361)"""
-        idx = {n: i for i, n in enumerate(names)}
-        arrs = [np.zeros(len(c), np.uint8) for c in contigs]
-        has = np.zeros(len(contigs), np.uint8)
-        with open(meth_freq_path) as f:
-            for ln in f:
-                if ln.startswith("#"):
-                    continue
-                name, pos, fr = ln.rstrip("\n").split("\t")[:3]
-                i, p = idx[name], int(pos)
-                if contigs[i][p:p + 1] not in (b"C", b"c"):
-                    raise ValueError(f"{name}:{p} is not a C")
-                has[i] = 1
-                arrs[i][p] = int(np.floor(float(np.float32(float(fr)) * np.float32(255)) + 0.5))     # (uint8_t)roundf(freq*255), float freq
-        blob = np.concatenate(arrs) if arrs else np.zeros(1, np.uint8)
+        blob, has = load_meth_freq(contigs, names, meth_freq_path)
         self._chk(self.L.sqg_genome_set_meth(self.ctx, blob.ctypes.data, has.ctypes.data), "sqg_genome_set_meth")
 
     def load_genome_device(self, d_seqs: int, contig_lens, rlen: int, mode: int = SAMPLE_DNA):

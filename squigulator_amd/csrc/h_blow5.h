@@ -27,6 +27,7 @@ struct sqg_blow5 {
     long long n_reads = 0;               // records written: the next read_number
     unsigned long long n_samples = 0;    // samples written: the next start_time (core->n_samples, src/sim.c:602)
     unsigned long long n_bytes = 0;      // file bytes so far
+    bool failed = false;                 // a write came up short: records of an unfinished batch are on disk, nothing more is written
     std::string err;
 };
 
@@ -67,11 +68,19 @@ extern "C" int sqg_blow5_open(const char* path, const sqg_profile_t* profile, ui
     sqg_blow5* w = new (std::nothrow) sqg_blow5();
     if (!w) return SQG_ENOMEM;
     w->fp = fopen(path, "wb");
-    if (!w->fp) { delete w; return SQG_EINVAL; }
+    if (!w->fp) {                                                   // (no writer to ask: the reason goes to stderr, the code says I/O)
+        fprintf(stderr, "[sqg] sqg_blow5_open: cannot open %s for writing: %s\n", path, strerror(errno));
+        delete w;
+        return SQG_EIO;
+    }
     w->profile = *profile; w->flags = flags;
     w->threads = threads > 0 ? threads : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     const std::string h = blow5_header(*profile, flags);
-    if (fwrite(h.data(), 1, h.size(), w->fp) != h.size()) { fclose(w->fp); delete w; return SQG_EINVAL; }
+    if (fwrite(h.data(), 1, h.size(), w->fp) != h.size()) {
+        fprintf(stderr, "[sqg] sqg_blow5_open: cannot write the header of %s: %s\n", path, strerror(errno));
+        fclose(w->fp); delete w;
+        return SQG_EIO;
+    }
     w->n_bytes = h.size();
     *out = w;
     return SQG_OK;
@@ -107,12 +116,15 @@ static bool blow5_record(z_stream& zs, std::vector<uint8_t>& raw, std::vector<ui
 extern "C" int sqg_blow5_write(sqg_blow5_t* w, int32_t n, const char* read_ids, const int64_t* id_off, const double* offset,
                                const double* median_before, const int64_t* sig_off, const uint8_t* svb, const int64_t* svb_off) {
     if (!w || !w->fp || n < 0) return SQG_EINVAL;
+    if (w->failed) { w->err = "sqg_blow5_write: the writer failed earlier (the file is incomplete): close it"; return SQG_EIO; }
     if (n == 0) return SQG_OK;
-    if (!read_ids || !id_off || !offset || !median_before || !sig_off || !svb || !svb_off) return SQG_EINVAL;
+    if (!read_ids || !id_off || !offset || !median_before || !sig_off || !svb || !svb_off) { w->err = "sqg_blow5_write: null argument"; return SQG_EINVAL; }
     for (int i = 0; i < n; i++) {
         const int64_t il = id_off[i + 1] - id_off[i];
         if (il < 0 || il > 65535 || svb_off[i + 1] < svb_off[i] || sig_off[i + 1] < sig_off[i]) { w->err = "sqg_blow5_write: bad offsets"; return SQG_EINVAL; }
-        if (svb_off[i + 1] - svb_off[i] > 0xfffffff0LL) { w->err = "sqg_blow5_write: record too large"; return SQG_EOVERFLOW; }
+        // one deflate call per record: the raw record (encoding + ~100 B of fields + the id) and its deflateBound must fit zlib's 32-bit
+        // avail_in / avail_out (deflateBound(n) <= n + n/1000 + 64 KiB for these parameters)
+        if (svb_off[i + 1] - svb_off[i] > 0xf0000000LL - il) { w->err = "sqg_blow5_write: record too large"; return SQG_EOVERFLOW; }
     }
     // start_time of read i = samples of every read before it (src/sim.c:602, in read order)
     std::vector<unsigned long long> start((size_t)n);
@@ -140,9 +152,14 @@ extern "C" int sqg_blow5_write(sqg_blow5_t* w, int32_t n, const char* read_ids, 
         for (int t = 0; t < nth; t++) th.emplace_back(work, t);
         for (auto& t : th) t.join();
     }
-    for (int t = 0; t < nth; t++) if (bad[(size_t)t]) { w->err = "sqg_blow5_write: zlib failed"; return SQG_EINVAL; }
+    for (int t = 0; t < nth; t++) if (bad[(size_t)t]) { w->err = "sqg_blow5_write: zlib failed"; return SQG_EINVAL; }   // (nothing written yet)
     for (int t = 0; t < nth; t++) {
-        if (fwrite(outs[(size_t)t].data(), 1, outs[(size_t)t].size(), w->fp) != outs[(size_t)t].size()) { w->err = "sqg_blow5_write: short write"; return SQG_EINVAL; }
+        if (fwrite(outs[(size_t)t].data(), 1, outs[(size_t)t].size(), w->fp) != outs[(size_t)t].size()) {
+            // part of the batch's records is on disk: a retry would duplicate them.  The writer is dead from here on.
+            w->failed = true;
+            w->err = std::string("sqg_blow5_write: short write (") + strerror(errno) + "): the file is incomplete";
+            return SQG_EIO;
+        }
         w->n_bytes += outs[(size_t)t].size();
     }
     w->n_reads += n;
@@ -153,13 +170,14 @@ extern "C" int sqg_blow5_write(sqg_blow5_t* w, int32_t n, const char* read_ids, 
 // the batch's records: svb-zd on the device (sqg_batch_compress), ~1.3 B/sample over PCIe, framing and zlib on the host threads
 extern "C" int sqg_blow5_write_batch(sqg_blow5_t* w, sqg_ctx_t* c, sqg_batch_t* b, const char* read_ids, const int64_t* id_off) {
     if (!w || !c || !b) return SQG_EINVAL;
+    if (w->failed) { w->err = "sqg_blow5_write_batch: the writer failed earlier (the file is incomplete): close it"; return SQG_EIO; }
     sqg_result_t res;
     int rc = sqg_batch_wait(c, b, &res);
     if (rc) { w->err = sqg_last_error(c); return rc; }
     sqg_svb_t sv;
     if ((rc = sqg_batch_compress(c, b, &sv))) { w->err = sqg_last_error(c); return rc; }
     uint8_t* host = (uint8_t*)sqg_host_alloc((size_t)std::max<int64_t>(sv.n_bytes, 1));
-    if (!host) return SQG_ENOMEM;
+    if (!host) { w->err = "sqg_blow5_write_batch: no pinned host memory for the batch's encodings"; return SQG_ENOMEM; }
     rc = sqg_fetch_svb(c, b, host);
     if (rc == SQG_OK) rc = sqg_blow5_write(w, res.n_reads, read_ids, id_off, res.offset, res.median_before, res.sig_off, host, sv.svb_off);
     else w->err = sqg_last_error(c);
@@ -169,11 +187,13 @@ extern "C" int sqg_blow5_write_batch(sqg_blow5_t* w, sqg_ctx_t* c, sqg_batch_t* 
 
 extern "C" int sqg_blow5_close(sqg_blow5_t* w, int64_t* n_bytes) {
     if (!w) return SQG_EINVAL;
-    int rc = SQG_OK;
+    int rc = w->failed ? SQG_EIO : SQG_OK;                            // (a failed writer leaves no end marker: the file is not a valid BLOW5)
     if (w->fp) {
-        if (fwrite("5WOLB", 1, 5, w->fp) != 5) rc = SQG_EINVAL;          // slow5_eof_fwrite, slow5.c:4206
-        else w->n_bytes += 5;
-        if (fclose(w->fp) != 0) rc = SQG_EINVAL;
+        if (!w->failed) {
+            if (fwrite("5WOLB", 1, 5, w->fp) != 5) rc = SQG_EIO;         // slow5_eof_fwrite, slow5.c:4206
+            else w->n_bytes += 5;
+        }
+        if (fclose(w->fp) != 0) rc = SQG_EIO;
     }
     if (n_bytes) *n_bytes = (int64_t)w->n_bytes;
     delete w;

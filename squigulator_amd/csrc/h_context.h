@@ -11,6 +11,7 @@ extern "C" const char* sqg_strerror(int code) {
     case SQG_ESEQUENCE: return "batches must be run in staging order";
     case SQG_ENODEVICE: return "no usable HIP device";
     case SQG_EOVERFLOW: return "read too long (>= UINT32_MAX samples) or dwell > 65535";
+    case SQG_EIO: return "file I/O error";
     default: return "unknown error";
     }
 }
@@ -142,12 +143,20 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
         CHK(hipEventCreateWithFlags(&S.sampled, hipEventDisableTiming));
         CHK(hipEventRecord(S.done, c->stream2));
     }
-    if (c->use_kmer_streams && !getenv("SQG_PART_CLAIMS")) {
-        // the hand-out over bucketed events by ordered LDS atomics (few workers): measured on THIS device, not assumed (k_part.h); ~1 ms
+    if (c->use_kmer_streams && !getenv("SQG_PART_CLAIMS") && !(cfg->flags & SQG_ORDER_FREE)) {
+        // the hand-out over bucketed events by ordered LDS atomics (few workers).  Three lines of defence (k_part.h): an allow-list of
+        // architectures on which the property was verified offline (2e8 fetch-adds, tests/test_split_chains.py, tools/stress_few.py:
+        // ordered against order-free kernels over 4e11 samples); this check on THIS device, in the production shape (4096-entry
+        // table, 16-bit addends, four wavefronts per CU, ~1.5 ms; sixteen times as long on an architecture that is not on the list);
+        // and a sample of every slice of every batch (k_part_hand_ord).  SQG_ORDER_FREE in cfg.flags skips all of it.
+        hipDeviceProp_t prop;
+        CHK(hipGetDeviceProperties(&prop, cfg->device));
+        const bool listed = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+        if (!listed) fprintf(stderr, "[sqg] %s is not on the list of architectures verified for lane-ordered LDS atomics: extended probe\n", prop.gcnArchName);
         unsigned int* d_bad = nullptr;
         CHK(hipMalloc(&d_bad, sizeof(unsigned int)));
         CHK(hipMemset(d_bad, 0, sizeof(unsigned int)));
-        hipLaunchKernelGGL(k_lds_order_check, dim3(1024), dim3(64), 0, c->stream, 4, d_bad);   // (four wavefronts per CU: the LDS pipeline is shared, as in the kernels)
+        hipLaunchKernelGGL(k_lds_order_check, dim3(1024), dim3(64), 0, c->stream, listed ? 4 : 64, d_bad);   // (four wavefronts per CU: the LDS pipeline is shared, as in the kernels)
         CHK(hipGetLastError());
         unsigned int bad = 1;
         CHK(hipMemcpyAsync(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost, c->stream));

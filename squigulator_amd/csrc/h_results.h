@@ -21,8 +21,9 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
 #endif
         b->waited = true;
         if (e) {
-            c->err = "device reported: " + std::string((e & 1) ? "dwell>65535 " : "") + ((e & 2) ? "read>=UINT32_MAX samples " : "") + ((e & 4) ? "internal length mismatch " : "") + ((e & 8) ? "FP64 fix-up list overflow " : "") + ((e & 32) ? "one k-mer stream asked for >= 2^32 samples by one batch" : "");
-            b->wait_rc = (e & 12) ? SQG_EDEVICE : SQG_EOVERFLOW;
+            c->err = "device reported: " + std::string((e & 1) ? "dwell>65535 " : "") + ((e & 2) ? "read>=UINT32_MAX samples " : "") + ((e & 4) ? "internal length mismatch " : "") + ((e & 8) ? "FP64 fix-up list overflow " : "") + ((e & 32) ? "one k-mer stream asked for >= 2^32 samples by one batch " : "") +
+                     ((e & 64) ? "LDS atomics were not served in lane order (the batch's sample of the stream hand-out; create the context with SQG_ORDER_FREE)" : "");
+            b->wait_rc = (e & (12 | 64)) ? SQG_EDEVICE : SQG_EOVERFLOW;
             return b->wait_rc;
         }
         float d = 0, s = 0, t = 0, ee = 0;

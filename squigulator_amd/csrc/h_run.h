@@ -188,7 +188,8 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                     if (direct) hipLaunchKernelGGL(k_rows_advance<true>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
                     else hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
                 }
-                if (c->lds_ordered) hipLaunchKernelGGL(k_part_hand_ord, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow);
+                const int order_fault = getenv("SQG_TEST_ORDER_FAULT") ? 1 : 0;         // (tests: the per-batch order check has to fire)
+                if (c->lds_ordered) hipLaunchKernelGGL(k_part_hand_ord, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, b->d_err, order_fault);
                 else if (c->dwell_hi >= (double)PART_JT) hipLaunchKernelGGL(k_part_hand<true>, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);
                 else hipLaunchKernelGGL(k_part_hand<false>, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);
                 HIPCHK(c, hipGetLastError());

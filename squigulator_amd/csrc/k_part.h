@@ -401,12 +401,20 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
 // atomics cost the LDS: one address, one lane after the other.
 // a^(2n) comes from three 256-entry tables in LDS (n < 2^24: a stream's samples in one slice; else the global tables).
 #define PART_LT 256
+// Every slice of every batch also SAMPLES the property it stands on, in production shape (this table, these dwells, this
+// occupancy): the counts its first PART_CHECK events received are compared with order-free prefix sums over the same records (a
+// loop over the earlier events in LDS, ~1 % of the slice's work); a mismatch sets bit 64 of the batch's error word and the batch
+// fails (sqg_batch_wait: SQG_EDEVICE).  fault (tests: SQG_TEST_ORDER_FAULT=1): the first two rows' atomics are issued in the
+// wrong order, which the check has to notice.
+#define PART_CHECK 128
 __global__ __launch_bounds__(64) void k_part_hand_ord(const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out,
                                                       const uint32_t* __restrict__ slice_lo, const uint32_t* __restrict__ slice_hi,
                                                       const uint32_t* __restrict__ n_slices,
-                                                      const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pw) {
+                                                      const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pw,
+                                                      unsigned int* __restrict__ err, const int fault) {
     __shared__ uint32_t base[PART_SUB];                           // the streams' states as the slice finds them
     __shared__ uint32_t cnt[PART_SUB];                            // samples handed out so far
+    __shared__ uint4 chk[PART_CHECK / 4];                         // the slice's first events, for the order check
     __shared__ uint32_t lt0[PART_LT], lt1[PART_LT], lt2[PART_LT]; // a^(2j), a^(2 * 256 j), a^(2 * 65536 j), DOUBLED (lcg_mul_dbl)
     constexpr int NR = PART_STEP / 64;                            // records per lane and step
     const int lane = threadIdx.x;
@@ -426,16 +434,47 @@ __global__ __launch_bounds__(64) void k_part_hand_ord(const uint32_t* __restrict
     for (int r = 0; r < NR; r++) cur[r] = in[64 * r];               // (unconditional: PART_SLACK entries behind the last slice)
     __syncthreads();
     // one step: event 64 r + lane is the lane's r-th -- instruction order, then lane order
-    auto step = [&](auto full_tag, const uint32_t left) {
-        constexpr bool FULL = decltype(full_tag)::value;
+    auto step = [&](auto full_tag, auto check_tag, const uint32_t left) {
+        constexpr bool FULL = decltype(full_tag)::value, CHECK = decltype(check_tag)::value;
 #pragma unroll
         for (int r = 0; r < NR; r++) nxt[r] = in[PART_STEP + 64 * r];
         uint32_t n[NR], out[NR];
+        if (CHECK && fault) {                                       // (test hook) rows 0 and 1 in the wrong order
+            const uint32_t t = cur[0]; cur[0] = cur[1]; cur[1] = t;
+        }
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             n[r] = 0;
             if (FULL || (uint32_t)(64 * r + lane) < left) n[r] = __hip_atomic_fetch_add(&cnt[cur[r] & (PART_SUB - 1)], cur[r] >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");                          // (the compiler keeps the atomics in this order)
+        }
+        if (CHECK && fault) {
+            const uint32_t t = cur[0]; cur[0] = cur[1]; cur[1] = t;
+            const uint32_t u = n[0]; n[0] = n[1]; n[1] = u;
+        }
+        if (CHECK) {
+            // the slice's first PART_CHECK events (cnt started at zero): what each received against the samples of the earlier ones
+            // on its stream, found without any ordering assumption
+            static_assert(PART_CHECK == 128, "two rows");
+            const bool v0 = FULL || (uint32_t)lane < left, v1 = FULL || (uint32_t)(64 + lane) < left;
+            reinterpret_cast<uint32_t*>(chk)[lane] = v0 ? cur[0] : 0u;            // (an event that does not exist: dwell 0)
+            reinterpret_cast<uint32_t*>(chk)[64 + lane] = v1 ? cur[1] : 0u;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const uint32_t s0 = cur[0] & (PART_SUB - 1), s1 = cur[1] & (PART_SUB - 1);
+            uint32_t w0 = 0, w1 = 0;
+#pragma unroll 4
+            for (int j4 = 0; j4 < PART_CHECK / 4; j4++) {
+                const uint4 q = chk[j4];
+                const uint32_t rec[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int j = 4 * j4 + i;
+                    const uint32_t d = rec[i] >> 16, sb = rec[i] & (PART_SUB - 1);
+                    if (j < lane && sb == s0) w0 += d;
+                    if (j < 64 + lane && sb == s1) w1 += d;
+                }
+            }
+            if ((v0 && n[0] != w0) || (v1 && n[1] != w1)) atomicOr(err, 64u);
         }
 #pragma unroll
         for (int r = 0; r < NR; r++) {
@@ -453,30 +492,33 @@ __global__ __launch_bounds__(64) void k_part_hand_ord(const uint32_t* __restrict
         in += PART_STEP; out_p += PART_STEP;
     };
     uint32_t b = lo;
-    for (; b + PART_STEP <= hi; b += PART_STEP) step(std::true_type{}, 0u);
-    if (b < hi) step(std::false_type{}, hi - b);
+    if (b + PART_STEP <= hi) { step(std::true_type{}, std::true_type{}, 0u); b += PART_STEP; }
+    else if (b < hi) { step(std::false_type{}, std::true_type{}, hi - b); b = hi; }
+    for (; b + PART_STEP <= hi; b += PART_STEP) step(std::true_type{}, std::false_type{}, 0u);
+    if (b < hi) step(std::false_type{}, std::false_type{}, hi - b);
 }
 
 // Are the lanes of one LDS atomic that meet on an address served in ascending lane order, and successive instructions in
-// program order?  Every wavefront plays rounds of 16 fetch-adds per lane against a small table, with addresses from one per
-// lane to one for all and some lanes idle, and compares what each returns with the sum over the earlier events (instruction,
-// lane) of the round on the same address.  bad <- number of mismatches.  grid: any, 64 threads.
+// program order?  Every wavefront plays rounds of 16 fetch-adds per lane against a table of the production size (4096 entries:
+// the sub-row of k_part_hand_ord) with 16-bit addends (a bucketed event's dwell), addresses from one per lane to one for all
+// (1 .. 4096 distinct ones) and some lanes idle, and compares what each returns with the sum over the earlier events
+// (instruction, lane) of the round on the same address.  bad <- number of mismatches.  grid: any, 64 threads.
 __global__ __launch_bounds__(64) void k_lds_order_check(const int rounds, unsigned int* __restrict__ bad) {
-    __shared__ uint32_t tab[256];
+    __shared__ uint32_t tab[PART_SUB];
     __shared__ uint4 ev[16 * 64 / 4];                             // the round's events in order: address << 16 | value (0: idle lane)
     const int lane = threadIdx.x;
     uint32_t s = (uint32_t)(blockIdx.x * 64 + lane) * 2654435761u + 12345u;
     unsigned int wrong = 0;
     for (int it = 0; it < rounds; it++) {
-        for (int i = lane; i < 256; i += 64) tab[i] = 0u;
-        const uint32_t spread = 1u << ((it + blockIdx.x) % 9);      // 1 .. 256 distinct addresses
+        for (int i = lane; i < PART_SUB; i += 64) tab[i] = 0u;
+        const uint32_t spread = 1u << ((it + blockIdx.x) % 13);     // 1 .. 4096 distinct addresses
         uint32_t a[16], v[16], got[16];
         bool on[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             s = s * 1664525u + 1013904223u;
-            a[r] = (s >> 20) & (spread - 1);
-            v[r] = ((s >> 8) & 1023u) + 1u;
+            a[r] = (s >> 18) & (spread - 1);
+            v[r] = ((s >> 2) & 0xffffu) | 1u;                       // 1 .. 65535
             on[r] = ((s >> 3) & 15u) != 0u || (it & 1);             // odd rounds: every lane; even: one in 16 idle
             reinterpret_cast<uint32_t*>(ev)[64 * r + lane] = a[r] << 16 | (on[r] ? v[r] : 0u);
         }

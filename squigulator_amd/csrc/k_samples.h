@@ -62,11 +62,12 @@ __global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_st
     const int ne = rd.ne0 + rd.ne1;
     const int n_ev = min(LEAN_EV, ne - lt * LEAN_EV);
     const long long sig_base = P.sig_off[r];
-    const uint32_t read_len = (uint32_t)(P.sig_off[r + 1] - sig_base);
+    const long long read_len64 = P.sig_off[r + 1] - sig_base;
+    const uint32_t read_len = (uint32_t)read_len64;
     const uint32_t base_pos = P.tile_so[rd.tile_off + lt * LEAN_EPL];
     const uint32_t next_pos = (lt + 1) * LEAN_EV < ne ? P.tile_so[rd.tile_off + (lt + 1) * LEAN_EPL] : read_len;
     const int n_samples = (int)(next_pos - base_pos);
-    bool take = rd.fast != 0 && n_samples <= LEAN_MAX_SAMPLES;
+    bool take = rd.fast != 0 && n_samples <= LEAN_MAX_SAMPLES && n_samples >= 0 && read_len64 < 4294967295LL;   // (a read of >= UINT32_MAX samples fails the batch, src/sim.c:559-562: k_scan; nobody writes it)
     int shift_lo = 0, shift_hi = 0;
     if (P.shift_len > 0) {                                             // RNA adaptor level-shift window (src/genread.c:79-86)
         const long long n1 = (long long)P.seglen[2 * r];
@@ -173,11 +174,12 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
             const int ne_read = rd.ne0 + rd.ne1;
             const int n_ev = min(LEAN_EV, ne_read - lt * LEAN_EV);
             const long long sig_base = sload(P.sig_off + r);
-            const uint32_t read_len = (uint32_t)(sload(P.sig_off + r + 1) - sig_base);
+            const long long read_len64 = sload(P.sig_off + r + 1) - sig_base;
+            const uint32_t read_len = (uint32_t)read_len64;
             const uint32_t base_pos = sload(P.tile_so + rd.tile_off + lt * LEAN_EPL);
             const uint32_t next_pos = (lt + 1) * LEAN_EV < ne_read ? sload(P.tile_so + rd.tile_off + (lt + 1) * LEAN_EPL) : read_len;
             const int n_samples = (int)(next_pos - base_pos);
-            const bool take = rd.fast != 0 && n_samples <= LEAN_MAX_SAMPLES && n_samples > 0;
+            const bool take = rd.fast != 0 && n_samples <= LEAN_MAX_SAMPLES && n_samples > 0 && read_len64 < 4294967295LL;
             if (!take) {                                               // leave these (up to LEAN_EPL) 64-event tiles to the generic kernel
                 if (lane == 0) {
                     const int nt = (n_ev + 63) >> 6;
@@ -435,6 +437,8 @@ __global__ __launch_bounds__(256) void k_samples(const SigParams P, const int n_
         const int wave_total = __shfl(incl, 63);
         const int so = incl - sps;                                     // first sample of my event within the tile
         const long long sig_base = P.sig_off[r];
+        if (P.sig_off[r + 1] - sig_base >= 4294967295LL) continue;     // a read of >= UINT32_MAX samples fails the batch (k_scan; src/sim.c:559-562): its
+                                                                       // 32-bit positions would wrap, nobody writes it
         const uint32_t read_len = (uint32_t)(P.sig_off[r + 1] - sig_base);
         const long long n1 = (long long)P.seglen[2 * r];               // samples of segment 0
         const long long shift_lo = n1 - P.shift_len;                    // src/genread.c:79

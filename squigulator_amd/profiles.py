@@ -24,6 +24,9 @@ SQ_ONT = 0x400
 # not an opt_t.flag bit: the reference keys CpG methylation on opt.meth_freq != NULL (src/sim.c:231,297, src/gensig.c:231,251);
 # here it is a flag of the context: 5-letter (A C G M T) pore table of 5^k rows, ranks of src/seq.h:45-74
 SQ_METH = 0x1000
+# implementation option of this library (include/sqg.h SQG_ORDER_FREE), no effect on results: the few-worker stream hand-out by
+# the order-free kernels (claim protocol, lane masks) instead of the lane-ordered LDS atomics
+SQ_ORDER_FREE = 0x2000
 
 
 @dataclass(frozen=True)

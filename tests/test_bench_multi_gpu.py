@@ -87,3 +87,54 @@ def test_bench_line_carries_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["unit"] == "samples/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert d["parity_check"]["equal"] is True and d["parity_check"]["reads_differing"] == 0
+    # round 3: the streaming leg (nothing staged ahead), the library that was timed, the ranks' own clocks
+    pl = d["pipeline"]
+    assert pl["unit"] == "samples/s" and pl["value"] > 0 and pl["seconds"] > 0 and pl["batches_per_gpu"] >= 9
+    assert pl["vs_value"] == pytest.approx(pl["value"] / d["value"], rel=1e-9) and pl["vs_value"] > 0.3
+    lib = d["library"]
+    assert lib["in_tree"] is True and lib["stale"] is False and len(lib["sha256_16"]) == 16 and len(lib["source_hash"]) == 16
+    assert d["ranks"]["world_size"] == 1 and d["ranks"]["ms_per_step_min"] == pytest.approx(d["ms_per_step"], rel=1e-9)
+
+
+@pytest.mark.gpu
+def test_bench_refuses_an_unnamed_library(tmp_path):
+    """SQG_LIB in the environment redirects the Python binding (A/B builds); bench.py must not time a library it does not name"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["SQG_LIB"] = os.path.join(ROOT, "oracle", "libsqg_cpu.so")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--genome-mb", "8",
+                        "--no-cpu-baseline", "--no-store-probe"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode != 0 and "--lib" in (p.stderr + p.stdout)
+
+
+def test_traffic_file_is_only_quoted_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
+    """profiles/traffic_latest.json carries a hash of csrc/ + include/sqg.h; bench.py nulls `traffic` when it does not match"""
+    sys.path.insert(0, ROOT)
+    import bench
+    from squigulator_amd import build
+    doc = {"workload_key": "w", "source_hash": build.source_hash(), "kernels": {"k_samples_lean": {"hbm_bytes_per_launch": 5.0},
+                                                                                 "k_part_hist": {"hbm_bytes_per_launch": 2.0}}}
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles" / "traffic_latest.json").write_text(json.dumps(doc))
+    assert bench.pmc_traffic("w") == 5.0 and bench.pmc_step_traffic("w") == 7.0
+    assert bench.pmc_traffic("other") is None
+    doc["source_hash"] = "0" * 16
+    (tmp_path / "profiles" / "traffic_latest.json").write_text(json.dumps(doc))
+    assert bench.pmc_traffic("w") is None and bench.pmc_step_traffic("w") is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [["--genome-mb", 24, "--job-workers", 1, "--batch-reads", 1024],
+                                  ["--genome-mb", 24, "--workers-per-gpu", 1, "--batch-reads", 1024],
+                                  ["--workload", "ncov-r9", "--job-workers", 3, "--batch-reads", 600]],
+                         ids=["r10_range", "r10_worker", "r9_range_t3"])
+def test_rccl_runs_with_one_rank(args):
+    """RCCL (torch.distributed backend nccl) on the one GPU of the box: a single rank forced through init_process_group runs the
+    pore-model broadcast, the barriers and reductions and -- range sharding -- the per-batch all-gather of the device-resident
+    stream counts (the __cuda_array_interface__ tensor over sqg_batch_run_begin's pointer) through RCCL.  Results: the plain run's."""
+    plain = _bench("--gpus", 1, "--digest", 4, *args)
+    rccl = _bench("--gpus", 1, "--digest", 4, "--force-dist", "--backend", "nccl", *args)
+    assert plain["ranks"]["backend"] is None and rccl["ranks"]["backend"] == "nccl" and rccl["ranks"]["world_size"] == 1
+    assert plain["digest"] == rccl["digest"]

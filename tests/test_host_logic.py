@@ -76,3 +76,37 @@ def test_read_ranges_partition_every_batch():
             assert all(lo <= hi for lo, hi in cuts)
             sizes = [hi - lo for lo, hi in cuts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_meth_freq_table_is_validated_like_the_reference(tmp_path):
+    """load_meth_freq, src/ref.c:314-345: unknown contig, negative / out-of-range position, not a C, frequency outside [0, 1],
+    missing columns -- each is an error naming the line (the reference exits), none reaches the uint8 table"""
+    import pytest
+    from squigulator_amd import api
+    contigs, names = [b"ACGTCCGA", b"ggcatc"], ["chr1", "chr2"]
+
+    def run(text):
+        p = tmp_path / "m.tsv"
+        p.write_text(text)
+        return api.load_meth_freq(contigs, names, str(p))
+
+    blob, has = run("#chr\tpos\tfreq\nchr1\t1\t0.5\nchr2\t2\t1\nchr1\t4\t0\n")
+    assert list(has) == [1, 1] and blob[1] == 128 and blob[8 + 2] == 255 and blob[4] == 0 and blob.sum() == 128 + 255
+    for text, what in (("chrX\t1\t0.5\n", "no such chromosome"), ("chr1\t-1\t0.5\n", "cannot be negative"),
+                       ("chr1\t8\t0.5\n", "must be less than the length 8"), ("chr1\t0\t0.5\n", "was a A"),
+                       ("chr1\t1\t1.5\n", "between 0 to 1"), ("chr1\t1\t-0.1\n", "between 0 to 1"), ("chr1\t1\n", "malformed line"),
+                       ("chr1\n", "malformed line")):
+        with pytest.raises(ValueError, match=what):
+            run(text)
+
+
+def test_blow5_writer_reports_io_errors(tmp_path):
+    """sqg_blow5_open on a path that cannot be created: SQG_EIO (not a generic SQG_EINVAL), the reason on stderr"""
+    import pytest
+    from squigulator_amd import api, profiles
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    with pytest.raises(api.SqgError) as ei:
+        api.Blow5Writer(str(tmp_path / "no" / "such" / "dir" / "x.blow5"), prof, fl)
+    assert ei.value.code == -7
+    w = api.Blow5Writer(str(tmp_path / "ok.blow5"), prof, fl)
+    assert w.close() > 0

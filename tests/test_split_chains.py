@@ -266,3 +266,51 @@ def test_queued_one_partition_batches_keep_their_own_events(knob, monkeypatch):
             np.testing.assert_array_equal(sig[b.sig_off[i]:b.sig_off[i + 1]], w.sig, err_msg=f"batch {bi} read {i}")
         b.free()
     gen.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dna-r10-prom", "dna-r9-prom"])
+def test_order_free_kernels_are_selectable_through_the_cfg(name):
+    """SQG_ORDER_FREE in cfg.flags (not an environment variable): the context never relies on the lane order of LDS atomics and
+    gives the same signals"""
+    rng = np.random.default_rng(77)
+    prof, fl = profiles.get_profile(name)
+    k = profiles.default_kmer_size(fl)
+    mean, stdv = model.synthetic_model(k)
+    batches = [_reads(rng, 170, k, 3500) for _ in range(2)]
+    out = []
+    for extra in (0, profiles.SQ_ORDER_FREE):
+        gen = api.SignalGenerator(prof, fl | extra, k, mean, stdv, 5, num_workers=1, mode=api.MODE_CERTIFIED)
+        bad, used = gen.probe_lds_order(workgroups=64, rounds=4)
+        assert bad == 0 and used == (extra == 0)
+        sigs = []
+        for bt in batches:
+            b = gen.submit(bt)
+            sigs.append(b.signal().copy())
+            b.free()
+        gen.close()
+        out.append(sigs)
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["dna-r10-prom", "dna-r9-prom"])
+def test_every_batch_samples_the_lane_order_and_fails_loudly(name, monkeypatch):
+    """k_part_hand_ord checks the first events of every slice against order-free prefix sums; with the atomics of the first two
+    rows issued in the wrong order (test hook) the batch must fail, not return swapped streams"""
+    rng = np.random.default_rng(78)
+    prof, fl = profiles.get_profile(name)
+    k = profiles.default_kmer_size(fl)
+    mean, stdv = model.synthetic_model(k)
+    reads = _reads(rng, 400, k, 3500)
+    gen = api.SignalGenerator(prof, fl, k, mean, stdv, 5, num_workers=1, mode=api.MODE_CERTIFIED)
+    b = gen.submit(reads)                                           # the healthy path passes its own check
+    b.free()
+    gen.close()
+    monkeypatch.setenv("SQG_TEST_ORDER_FAULT", "1")
+    gen = api.SignalGenerator(prof, fl, k, mean, stdv, 5, num_workers=1, mode=api.MODE_CERTIFIED)
+    with pytest.raises(api.SqgError) as ei:
+        gen.submit(reads)
+    assert "lane order" in str(ei.value)
+    gen.close()
