@@ -29,16 +29,19 @@ struct sqg_ctx {
         uint16_t* d_dwell = nullptr; size_t dwell_cap = 0;
         unsigned long long* d_seglen = nullptr; long long* d_sigoff = nullptr; size_t reads_cap = 0;
         FixEntry* d_fix = nullptr; size_t fix_cap = 0;
-        unsigned int* d_fix_count = nullptr;       // [0] fix-up entries, [1] slow tiles
+        unsigned int* d_fix_count = nullptr;       // [0] fix-up entries, [1] slow tiles, [2] entries that went through the lean kernel's lists
+        FixEntry* d_fix_sh = nullptr;              // the lean kernel's FIX_SHARDS lists of FIX_SHARD_CAP entries (64 MB)
+        unsigned int* d_fix_sh_count = nullptr;    // ... their counters, FIX_SHARD_STRIDE words apart
         uint2* d_evrec = nullptr; size_t evrec_cap = 0;
         uint32_t* d_tile_so = nullptr; size_t tile_cap = 0;
         int* d_slow = nullptr; size_t slow_cap = 0;
-        uint4* d_tfix = nullptr; size_t tfix_cap = 0;
-        unsigned char* d_tfix_n = nullptr; size_t tfixn_cap = 0;
         ItemDesc* d_items = nullptr; size_t items_cap = 0;          // [n_stiles] work items of the lean kernel (k_items)
         uint32_t* d_part = nullptr; size_t part_cap = 0;            // [n_events] bucketed events (k_part.h).  Per slot: with one partition
                                                                     // (k <= 6) the sample kernels -- the generic one and the fix-ups run on
                                                                     // fix_stream, next to the following batch's event pass -- read rank and dwell from it
+        uint32_t* d_lbase = nullptr; size_t lbase_cap = 0;          // [n_links][PART_MAX] first slot of every (link, partition): written by the scatter
+                                                                    // pass, read by the sample kernels (SigParams.evrec32)
+        int* d_tile_link = nullptr; size_t tile_link_cap = 0;       // [n_tiles] the link of every 64-event tile (same)
         uint32_t* d_part_state = nullptr; size_t part_state_cap = 0;   // [n_events] k > 6, split chains (k_part.h): stream state at each
                                                                     // bucketed event; read by the sample kernels like evrec
         unsigned long long gen = 0;                // bumped whenever a batch starts writing the slot's buffers
@@ -93,7 +96,6 @@ struct sqg_ctx {
     uint8_t* d_svb = nullptr; size_t svb_cap = 0;               // svb-zd encodings of the last compressed batch
     long long* d_svb_size = nullptr; size_t svb_size_cap = 0;   // per read
     long long* d_svb_off = nullptr; size_t svb_off_cap = 0;
-    long long tile_fix = 0;                // undecided samples parked per tile in the last batch (timing info)
     std::string err;
 };
 

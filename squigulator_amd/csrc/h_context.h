@@ -40,9 +40,9 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_scan_part); (void)hipFree(ctx->d_xcounts); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_samp_scratch); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err);
     for (auto& S : ctx->slot) {
         (void)hipFree(S.d_sig); (void)hipFree(S.d_dwell); (void)hipFree(S.d_seglen); (void)hipFree(S.d_sigoff);
-        (void)hipFree(S.d_fix); (void)hipFree(S.d_fix_count);
+        (void)hipFree(S.d_fix); (void)hipFree(S.d_fix_count); (void)hipFree(S.d_fix_sh); (void)hipFree(S.d_fix_sh_count);
         (void)hipFree(S.d_evrec); (void)hipFree(S.d_tile_so); (void)hipFree(S.d_slow);
-        (void)hipFree(S.d_tfix); (void)hipFree(S.d_tfix_n); (void)hipFree(S.d_items); (void)hipFree(S.d_part_state); (void)hipFree(S.d_part);
+        (void)hipFree(S.d_items); (void)hipFree(S.d_part_state); (void)hipFree(S.d_part); (void)hipFree(S.d_lbase); (void)hipFree(S.d_tile_link);
         if (S.done) (void)hipEventDestroy(S.done);
         if (S.sampled) (void)hipEventDestroy(S.sampled);
     }
@@ -139,6 +139,13 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     for (auto& S : c->slot) {
         CHK(hipMalloc(&S.d_fix_count, 4 * sizeof(unsigned int)));
         CHK(hipMemset(S.d_fix_count, 0, 4 * sizeof(unsigned int)));
+        if (cfg->mode == SQG_MODE_CERTIFIED && c->use_kmer_streams) {
+            CHK(hipMalloc(&S.d_fix_sh, (size_t)FIX_SHARDS * FIX_SHARD_CAP * sizeof(FixEntry)));
+            CHK(hipMemset(S.d_fix_sh, 0, (size_t)FIX_SHARDS * FIX_SHARD_CAP * sizeof(FixEntry)));      // (tags of no batch)
+            // (counters, FIX_SHARD_STRIDE words apart, then one word of statistics per list)
+            CHK(hipMalloc(&S.d_fix_sh_count, ((size_t)FIX_SHARDS * FIX_SHARD_STRIDE + FIX_SHARDS) * sizeof(unsigned int)));
+            CHK(hipMemset(S.d_fix_sh_count, 0, ((size_t)FIX_SHARDS * FIX_SHARD_STRIDE + FIX_SHARDS) * sizeof(unsigned int)));
+        }
         CHK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
         CHK(hipEventCreateWithFlags(&S.sampled, hipEventDisableTiming));
         CHK(hipEventRecord(S.done, c->stream2));

@@ -38,7 +38,12 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
         if (c->cfg.mode == SQG_MODE_CERTIFIED && slot_is_mine(c, b)) {
             unsigned int cnt[4] = {0, 0, 0, 0};
             HIPCHK(c, hipMemcpy(cnt, S.d_fix_count, sizeof cnt, hipMemcpyDeviceToHost));
-            nfix = cnt[0] + cnt[2];                         // global list + the per-item slots of the lean kernel (counted by k_fixup_tiles)
+            nfix = cnt[0];                                  // the global list ...
+            if (S.d_fix_sh_count) {                         // ... + the lean kernel's lists (a word per list, written by k_fixup)
+                unsigned int st[FIX_SHARDS];
+                HIPCHK(c, hipMemcpy(st, S.d_fix_sh_count + (size_t)FIX_SHARDS * FIX_SHARD_STRIDE, sizeof st, hipMemcpyDeviceToHost));
+                for (int i = 0; i < FIX_SHARDS; i++) nfix += st[i];
+            }
         }
         c->timing.dwell_ms = d; c->timing.samples_ms = s; c->timing.total_ms = t; c->timing.fallback_samples = nfix;
     } else if (b->wait_rc) {

@@ -77,8 +77,11 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     P.meth_top = 1; for (int i = 1; i < c->k; i++) P.meth_top *= 5u;
     P.use_streams = c->use_kmer_streams ? 1 : 0;
     P.dwell_unbounded = c->dwell_hi > 65535.0 ? 1 : 0;
+    P.dwell_pack = c->dwell_hi < 1024.0 ? 1 : 0;
     P.rna = (c->cfg.flags & SQG_RNA) ? 1 : 0;
-    P.evrec = S.d_evrec; P.tile_so = S.d_tile_so; P.tile_read = b->d_tile_read; P.stile_read = b->d_stile_read;
+    P.evrec = S.d_evrec; P.tile_so = S.d_tile_so;
+    // bucketed hand-out with the wavefront-per-link passes: 4 B per event between the scatter pass and the sample kernels (k_part_events.h)
+    if (b->part && b->pieces && !b->one) { P.evrec32 = reinterpret_cast<uint32_t*>(S.d_evrec); P.lbase = S.d_lbase; P.tile_link = S.d_tile_link; } P.tile_read = b->d_tile_read; P.stile_read = b->d_stile_read;
     constexpr int NT = SQG_EVENT_THREADS, NT_WIDE = 1024;
     // few chains (the reference's default -K 1000 with one worker per read): a chain is a sequence of segments, each with
     // its barriers and LDS round trips, and there are not enough chains to hide them -- 1024 threads per chain walk it in a
@@ -244,7 +247,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 HIPCHK(c, hipMemsetAsync(c->d_scan_part, 0, c->scan_part_cap * sizeof(unsigned long long), c->stream));
         }
         hipLaunchKernelGGL(k_scan, dim3(scan_wgs), dim3(SCAN_WG), 0, c->stream, S.d_seglen, n, S.d_sigoff, b->h_sigoff_dev,
-                           b->d_err, S.d_fix_count, c->d_scan_part, ++c->scan_tickets);   // (a ticket per launch, also after a failed run)
+                           b->d_err, S.d_fix_count, c->d_scan_part, ++c->scan_tickets, S.d_fix_sh_count);   // (a ticket per launch, also after a failed run)
         HIPCHK(c, hipGetLastError());
         if ((rc = dbg_sync(c, "k_scan"))) return rc;
     } else HIPCHK(c, hipMemsetAsync(S.d_fix_count, 0, 4 * sizeof(unsigned int), c->stream));
@@ -273,6 +276,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     hipStream_t tail = c->stream2;                               // the stream the batch's last kernel runs on
     if (n > 0 && b->n_chains > 0) {
         P.sig = S.d_sig; P.fix = S.d_fix; P.fix_count = S.d_fix_count;
+        P.fix_sh = S.d_fix_sh; P.fix_sh_count = S.d_fix_sh_count; P.fix_sh_stat = S.d_fix_sh_count + (size_t)FIX_SHARDS * FIX_SHARD_STRIDE; P.fix_tag = (int)(b->run_idx & 0x3fffffff) + 1;
         P.fix_cap = (unsigned int)std::min<size_t>(S.fix_cap, 0xffffffffu);
         const bool rna_prefix = (c->cfg.flags & SQG_RNA) && (c->cfg.flags & SQG_PREFIX);
         P.shift_len = rna_prefix ? (int)strlen(kAdaptorRna) * (int)p.dwell_mean : 0;
@@ -281,7 +285,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             int32_t t = (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : (int32_t)0x80000000u;
             P.shift = (int)(int16_t)(uint16_t)((uint32_t)t & 0xffffu);
         }
-        P.slow_tiles = nullptr; P.slow_count = S.d_fix_count + 1; P.tfix = S.d_tfix; P.tfix_n = S.d_tfix_n; P.items = S.d_items; P.lean_epl = c->lean_epl;
+        P.slow_tiles = nullptr; P.slow_count = S.d_fix_count + 1; P.items = S.d_items; P.lean_epl = c->lean_epl;
         const int n_tiles = (int)b->n_tiles;
         const unsigned sgrid = (unsigned)((n_tiles + 3) / 4);
         if (certified && c->use_kmer_streams) {
@@ -306,13 +310,18 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             if ((rc = dbg_sync(c, "k_samples_lean"))) return rc;
             // what is left -- the items the lean kernel did not take (usually none) and the FP64 fix-ups, small latency-bound
             // kernels -- goes to a stream of its own: the next batch's k_events does not wait for it
+            static const bool fix_inline = getenv("SQG_FIX_INLINE") != nullptr;   // A/B: the left-over kernels on the batch's own stream
             HIPCHK(c, hipEventRecord(S.sampled, c->stream2));
-            HIPCHK(c, hipStreamWaitEvent(c->fix_stream, S.sampled, 0));
-            tail = c->fix_stream;
+            if (!fix_inline) {
+                HIPCHK(c, hipStreamWaitEvent(c->fix_stream, S.sampled, 0));
+                tail = c->fix_stream;
+            }
+            static const bool abl_nofix = getenv("SQG_ABL_NOFIX") != nullptr;   // timing-only ablation (results are wrong): what the left-over kernels cost the step
+            if (!abl_nofix) {
             hipLaunchKernelGGL((k_samples<1, true>), dim3(std::min(sgrid, 4096u)), dim3(256), 0, tail, P, n_tiles);
             if ((rc = dbg_sync(c, "k_samples<generic>"))) return rc;
-            hipLaunchKernelGGL(k_fixup, dim3(512), dim3(256), 0, tail, P);
-            hipLaunchKernelGGL(k_fixup_tiles, dim3((unsigned)((n_stiles + 255) / 256)), dim3(256), 0, tail, P, n_stiles);
+            hipLaunchKernelGGL(k_fixup, dim3(FIX_SHARDS), dim3(256), 0, tail, P);
+            }
             if ((rc = dbg_sync(c, "k_fixup"))) return rc;
         } else {
             HIPCHK(c, hipEventRecord(b->ev[7], c->stream));

@@ -46,12 +46,14 @@ static int grow_slot(sqg_ctx* c, sqg_ctx::Slot& Z, const sqg_batch* b, bool with
     if ((rc2 = ensure(c, (void**)&Z.d_dwell, &Z.dwell_cap, (size_t)b->n_events + 1024, sizeof(uint16_t)))) return rc2;
     if ((rc2 = ensure(c, (void**)&Z.d_evrec, &Z.evrec_cap, (size_t)b->n_events + 64, sizeof(uint2)))) return rc2;
     if (b->part && (rc2 = ensure(c, (void**)&Z.d_part, &Z.part_cap, (size_t)b->n_events + PART_SLACK, sizeof(uint32_t)))) return rc2;
+    if (b->part && b->pieces && !b->one) {
+        if ((rc2 = ensure(c, (void**)&Z.d_lbase, &Z.lbase_cap, (size_t)b->n_chains * PART_MAX, sizeof(uint32_t)))) return rc2;
+        if ((rc2 = ensure(c, (void**)&Z.d_tile_link, &Z.tile_link_cap, (size_t)b->n_tiles + 64, sizeof(int)))) return rc2;
+    }
     if (b->part && (rc2 = ensure(c, (void**)&Z.d_part_state, &Z.part_state_cap, (size_t)b->n_events + PART_SLACK, sizeof(uint32_t)))) return rc2;
     if ((rc2 = ensure(c, (void**)&Z.d_tile_so, &Z.tile_cap, (size_t)b->n_tiles + 64, sizeof(uint32_t)))) return rc2;
     if ((rc2 = ensure(c, (void**)&Z.d_slow, &Z.slow_cap, (size_t)b->n_tiles + 64, sizeof(int)))) return rc2;
     if (certified && c->use_kmer_streams) {
-        if ((rc2 = ensure(c, (void**)&Z.d_tfix, &Z.tfix_cap, (size_t)b->n_stiles * FIX_SLOTS + 64, sizeof(uint4)))) return rc2;
-        if ((rc2 = ensure(c, (void**)&Z.d_tfix_n, &Z.tfixn_cap, (size_t)b->n_stiles + 64, 1))) return rc2;
         if ((rc2 = ensure(c, (void**)&Z.d_items, &Z.items_cap, (size_t)b->n_stiles + 64, sizeof(ItemDesc)))) return rc2;
     }
     if (with_output) {
@@ -189,7 +191,10 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
                                                               : ((multi || (wave_links && n_wchains <= 16)) && n_wchains < (wave_links && part_one ? 2048 : 1024) && nev >= 65536);   // (measured: from 2048 / 1024 chains on, one workgroup of k_events per chain is as fast or faster)
         if (c->use_kmer_streams && want) {
             const size_t row_bytes = (size_t)c->num_kmer * sizeof(uint32_t);
-            long long target = forced > 0 ? forced : wave_links ? 8192 : part_ok ? 4096 : 2048;
+            // (one wavefront per link: 8192 links fill the machine twice over; a small batch -- the reference's default -K 1000 is 1e7
+            // events -- is better off with half as many links of twice the length: fewer ragged last segments, fewer cut reads.
+            // Measured at 1000 reads per batch, 9-mers: event side 0.224 -> 0.214 ms; with the longer slices below 0.196)
+            long long target = forced > 0 ? forced : wave_links ? (nev < 25000000LL ? 4096 : 8192) : part_ok ? 4096 : 2048;
             if (!part_ok) target = std::min<long long>(target, std::max<long long>(8, (long long)(((size_t)1 << 30) / row_bytes)));
             std::vector<int> link_off(1, 0);
             b->pieces = wave_links;
@@ -199,7 +204,9 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
                 // long as the others (k_part_events.h: what a piece needs from the pieces before it)
                 const int lo = wchain_off[(size_t)q], hi = wchain_off[(size_t)q + 1];
                 const long long lq = std::max<long long>(1, nev > 0 ? (target * wchain_ev[(size_t)q] + nev - 1) / nev : 1);
-                const long long per = std::max<long long>(1, (wchain_ev[(size_t)q] + lq - 1) / lq);
+                // (a link stays below 2^14 events -- an event's record for the sample kernels carries its slot within the (link,
+                // partition) in EVR_REL_BITS bits, k_common.h: a link closes at less than per + (per + per / 4) events)
+                const long long per = std::min<long long>(std::max<long long>(1, (wchain_ev[(size_t)q] + lq - 1) / lq), ((1 << EVR_REL_BITS) - 1) * 4 / 9);
                 const long long chunk = std::max<long long>(PEV_SEG, per / PEV_SEG * PEV_SEG);
                 long long acc = 0;
                 auto close = [&]() { link_off.push_back((int)pieces.size()); acc = 0; };
@@ -267,11 +274,21 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         // a slice's per-stream sample counts are 32-bit (a bucketed event carries its dwell in 16 bits)
         len = std::min<long long>(len, (long long)(4.0e9 / std::min(std::max(c->dwell_hi, 1.0), 65535.0)));
         len = std::max<long long>(PART_STEP, len / PART_STEP * PART_STEP);
-        if (!senv) len = std::max<long long>(len, std::min<long long>(8 * PART_STEP, (long long)(4.0e9 / std::min(std::max(c->dwell_hi, 1.0), 65535.0)) / PART_STEP * PART_STEP));   // small batches: fewer, not shorter slices (a slice costs a 16-KiB table in three passes)
+        if (!senv) len = std::max<long long>(len, std::min<long long>(16 * PART_STEP, (long long)(4.0e9 / std::min(std::max(c->dwell_hi, 1.0), 65535.0)) / PART_STEP * PART_STEP));   // small batches: fewer, not shorter slices (a slice costs a 16-KiB table in three passes; 16384 instead of 8192 events: event side -4 % at 4096 reads per batch, -9 % at 1000)
         b->slice_len = (uint32_t)len;
         b->max_slices = (long long)(nev / len) + (long long)n_wchains * n_part;
         b->part = true;
         b->one = part_one;
+        if (b->pieces && !part_one) {
+            // the sample kernels need an event's link (SigParams.evrec32): a read that is one piece says it itself (ReadDesc.slot0, not
+            // used otherwise with several partitions); the tiles of a read cut into pieces are looked up in tile_link (-1 here)
+            for (int l = 0; l < b->n_chains; l++)
+                for (int ci = chain_off[(size_t)l]; ci < chain_off[(size_t)l + 1]; ci++) {
+                    const Piece& pc = pieces[(size_t)ci];
+                    ReadDesc& d = rd[(size_t)pc.read];
+                    d.slot0 = (pc.e_lo == 0 && pc.e_hi == d.ne0 + d.ne1) ? l : -1;
+                }
+        }
         if (b->one) {                                             // part[] is the worker chains one after the other, each in chain order
             link_slot.assign((size_t)b->n_chains, 0u);
             long long at = 0;

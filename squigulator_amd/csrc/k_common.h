@@ -158,6 +158,21 @@ __device__ static inline uint32_t kmer_rank_of(const uint8_t* bp, int k, int met
     return rank;
 }
 
+// the same from ONE pair of loads (9 bases at most; the base buffer ends with slack): the fix-up kernels walk a chain of dependent
+// look-ups per sample, and nine byte loads in a loop of unknown length are nine round trips
+__device__ static inline uint32_t kmer_rank_wide(const uint8_t* bp, int k, int meth) {
+    unsigned long long w0; uint32_t w1;
+    __builtin_memcpy(&w0, bp, 8);
+    __builtin_memcpy(&w1, bp + 8, 4);
+    uint32_t rank = 0;
+#pragma unroll
+    for (int q = 0; q < 9; q++) {
+        const uint8_t b = q < 8 ? (uint8_t)(w0 >> (8 * q)) : (uint8_t)w1;
+        if (q < k) rank = meth ? rank * 5u + meth_code(b) : (rank << 2) | base_code(b);
+    }
+    return rank;
+}
+
 // ---- descriptors ---------------------------------------------------------------------------
 struct ReadDesc {
     long long base_off;   // first byte of segment 0 in the batch's base buffer
@@ -170,7 +185,8 @@ struct ReadDesc {
     int tile_off;         // first 64-event tile of this read in the batch's tile arrays
     int fast;             // certified mode: every ADC value of this read is provably in (2, 65000) -> lean kernel
     int stile_off;        // first 256-event super tile of this read
-    int slot0;            // one-partition hand-out (k <= 6, few workers; k_part.h): slot in part[] of the read's first event
+    int slot0;            // one-partition hand-out (k <= 6, few workers; k_part.h): slot in part[] of the read's first event;
+                          // several partitions with SigParams.evrec32: the read's link, -1 if it is cut into pieces of several links
 };
 
 struct FixEntry {         // one sample handed to the FP64 path
@@ -194,7 +210,8 @@ struct ItemDesc {
     int read;                    // read index (fix-up overflow path)
     int shift_lo, shift_hi;      // RNA adaptor level-shift window (src/genread.c:79-86) as sample indices within the item
                                  // (generation order): samples lo <= i < hi get -shift; hi <= lo: none
-    int slot_first;              // one-partition hand-out: slot in part[] of the item's first event (else 0)
+    int slot_first;              // one-partition hand-out: slot in part[] of the item's first event; bucketed hand-out with 16-bit event
+                                 // records (SigParams.evrec32): the item's LINK; else 0
 };
 
 struct SigParams {
@@ -221,7 +238,16 @@ struct SigParams {
     FixEntry* fix;               // certified mode: undecided samples
     unsigned int* fix_count;
     unsigned int fix_cap;
+    FixEntry* fix_sh;            // ... of the lean kernel: FIX_SHARDS lists of FIX_SHARD_CAP entries (a workgroup appends to list blockIdx % FIX_SHARDS:
+    unsigned int* fix_sh_count;  // one returning atomic per item with undecided samples, on one of FIX_SHARDS counters 128 B apart)
+    unsigned int* fix_sh_stat;   // [FIX_SHARDS] entries k_fixup took from each list
+    int fix_tag;                 // FixEntry.pad of this batch's entries (a list's count may include entries that went to the global list instead)
     uint2* evrec;                // per event {stream state at its first draw, k-mer rank}
+    uint32_t* evrec32;           // bucketed hand-out, wavefront-per-link passes (k_part_events.h): INSTEAD of evrec, 4 B per event between the
+                                 // scatter pass and the sample kernels: rank << EVR_REL_BITS | the event's slot relative to the first slot
+                                 // of its (link, partition) -- the absolute slot is lbase[link][rank >> 12] + that
+    uint32_t* lbase;             // [n_links][PART_MAX] first slot in part[] of every (link, partition) (written by the scatter pass)
+    int* tile_link;              // [n_tiles] the link every 64-event tile belongs to (written by the scatter pass)
     uint32_t* tile_so;           // per 64-event tile: its first sample within the read
     const int* tile_read;        // per tile: read index
     const int* stile_read;       // per 256-event super tile (lean kernel work item): read index
@@ -229,8 +255,6 @@ struct SigParams {
     int lean_epl;                // events per lane of the lean kernel (4, 2 or 1): a super tile is 64*lean_epl events
     int* slow_tiles;             // tiles the lean sample kernel left to the generic one
     unsigned int* slow_count;
-    uint4* tfix;                 // lean kernel: FIX_SLOTS undecided samples per tile {index in read, c1, event in read, 0}
-    unsigned char* tfix_n;       // lean kernel: entries used per tile
     double dig, range, kd;       // kd = dig/range
     float delta_x;               // swept bound on |x_fast - x_exact| (incl. margin)
     float thr_all;               // 1/2 - (largest eps over all k-mers): acceptance threshold of the lean kernel
@@ -239,6 +263,7 @@ struct SigParams {
     uint32_t meth_top;           // 5^(k-1)
     int num_kmer_pad;            // num_kmer rounded up to whole partitions (k_part.h)
     int const_sps;               // (int)dwell_mean, used when dwell == null
+    int dwell_pack;              // no dwell exceeds 1023: 64 of them sum to less than 2^16 (k_part_events: two tile sums per scan)
     int dwell_unbounded;         // the hard bound of a dwell draw (|z| <= 6.5556) exceeds 65535: k_events checks every draw
     int use_streams;             // 0 in --ideal / --ideal-amp (src/gensig.c:265-269)
     int rna;                     // reverse the signal (src/gensig.c:348-354)
@@ -261,6 +286,11 @@ struct SigParams {
     int n_links;                 // pcnt / poff are partition-major: [partition][link] (k_part_offsets sweeps a partition's links)
 };
 
+#define EVR_REL_BITS 14          // SigParams.evrec32: an event's slot within its (link, partition) -- staging keeps a link below 2^14 events --
+                                 // under the 18 bits of a 9-mer rank
+#define FIX_SHARDS 1024          // (a single counter: 90 000 returning device-scope atomics per batch on one address run at ~40 ns each and
+#define FIX_SHARD_CAP 2048       // stretch the sample kernel from 2.4 to 5.8 ms: measured)
+#define FIX_SHARD_STRIDE 32      // words between two counters
 #define PART_SUB_BITS 12         // a partition's sub-row: 4096 streams, 16 KiB of LDS (the size of a whole 6-mer row).  (2048-stream
                                  // partitions were measured: k_part_hand runs 16 wavefronts per CU instead of 8, but the scatter's runs
                                  // shrink to 16 B and the sample kernels' state gather spreads: no gain on the whole step)

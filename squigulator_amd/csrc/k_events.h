@@ -121,11 +121,14 @@ __global__ __launch_bounds__(256) void k_dwell(const ReadDesc* __restrict__ read
 __global__ __launch_bounds__(SCAN_WG) void k_scan(const unsigned long long* __restrict__ seglen, int n_reads,
                                                   long long* __restrict__ sig_off, long long* __restrict__ host_off,
                                                   unsigned int* __restrict__ err, unsigned int* __restrict__ counters,
-                                                  unsigned long long* __restrict__ part, unsigned long long ticket) {
+                                                  unsigned long long* __restrict__ part, unsigned long long ticket,
+                                                  unsigned int* __restrict__ shard_counters) {
     __shared__ long long wsum[SCAN_WG / 64];
     __shared__ long long before_sh;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = blockIdx.x;
     if (g == 0 && tid < 4) counters[tid] = 0;            // fix-up list / slow-tile list counters of this batch
+    if (shard_counters)                                  // ... and the FIX_SHARDS list counters of the lean kernel
+        for (int i = g * SCAN_WG + tid; i < FIX_SHARDS; i += gridDim.x * SCAN_WG) shard_counters[i * FIX_SHARD_STRIDE] = 0;
     const int i = g * SCAN_WG + tid;
     long long v = 0;
     if (i < n_reads) {

@@ -92,6 +92,11 @@ __global__ __launch_bounds__(256) void k_part_slice_bounds(const uint32_t* __res
 }
 
 // grid: slices (the host's bound; the live ones are pfirst[n_pairs]), 256 threads.  phist[s][sub] <- samples the slice's events draw from the stream
+// (sums commute: a thread takes four consecutive records with one 16-B load -- 4-B loads stream at 4.0 TB/s on this machine, 16-B
+// loads at 6.3, tools/pmc_calib.hip -- 2048 events of the slice per step, the next step's loads in flight during this one's atomics)
+#ifndef PART_HIST_V4
+#define PART_HIST_V4 1
+#endif
 __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* __restrict__ part, const uint32_t* __restrict__ slice_lo,
                                                    const uint32_t* __restrict__ slice_hi, const uint32_t* __restrict__ n_slices,
                                                    uint32_t* __restrict__ phist) {
@@ -101,6 +106,39 @@ __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* __restrict__ 
     for (int i = tid; i < PART_SUB; i += 256) row[i] = 0u;
     __syncthreads();
     const uint32_t lo = slice_lo[blockIdx.x], hi = slice_hi[blockIdx.x];
+#if PART_HIST_V4
+    // the slice from its first 16-B aligned record on in uint4s; the (up to three) records before that one by one
+    const uint32_t lo4 = min((lo + 3u) & ~3u, hi);
+    if (lo + (uint32_t)tid < lo4) { const uint32_t rec = part[lo + tid]; atomicAdd(&row[rec & (PART_SUB - 1)], rec >> 16); }
+    const uint4* in = reinterpret_cast<const uint4*>(part + lo4) + tid;
+    uint4 rec[2], nxt[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) rec[q] = in[256 * q];                        // (unconditional: PART_SLACK entries behind the last slice)
+    for (uint32_t b = lo4; b < hi; b += 2048) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) nxt[q] = in[512 + 256 * q];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t w[4] = {rec[q].x, rec[q].y, rec[q].z, rec[q].w};
+            const uint32_t at = b + 1024 * q + 4 * tid;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bool live = at + i < hi;
+                const uint32_t sub = w[i] & (PART_SUB - 1);
+                // a wavefront whose events all fall on one stream (poly-A tails ...): one add of the wavefront's sum instead of 64
+                // adds to one address
+                if (__builtin_amdgcn_ballot_w64(live && sub == (uint32_t)__builtin_amdgcn_readfirstlane((int)sub)) == ~0ull) {
+                    int sum = (int)(w[i] >> 16);
+                    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                    if ((tid & 63) == 0) atomicAdd(&row[sub], (uint32_t)sum);
+                } else if (live) atomicAdd(&row[sub], w[i] >> 16);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) rec[q] = nxt[q];
+        in += 512;
+    }
+#else
     const uint32_t* in = part + lo + tid;
     uint32_t rec[4], nxt[4];
 #pragma unroll
@@ -124,6 +162,7 @@ __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* __restrict__ 
         for (int q = 0; q < 4; q++) rec[q] = nxt[q];
         in += 1024;
     }
+#endif
     __syncthreads();
     uint32_t* dst = phist + (size_t)blockIdx.x * PART_SUB;
     for (int i = tid; i < PART_SUB; i += 256) dst[i] = row[i];
@@ -224,7 +263,7 @@ __global__ __launch_bounds__(256) void k_part_totals(const uint32_t* __restrict_
 #ifndef PART_MANY
 #define PART_MANY 24             // waiting events of a phase from which on the streams are taken one at a time straight away
 #endif
-#define PART_SLACK (2 * PART_STEP)   // entries behind the bucketed events: read ahead by the last step of a slice, and the dump of idle lanes' stores
+#define PART_SLACK (4 * PART_STEP + 64)   // entries behind the bucketed events: read ahead by the last step of a slice (k_part_hist: two steps of 2048), and the dump of idle lanes' stores
 template <bool BIGD>
 __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out,
                                                   const uint32_t* __restrict__ slice_lo, const uint32_t* __restrict__ slice_hi,

@@ -12,7 +12,8 @@
 //   SCATTER (k > 6, second pass) ranks again, dwell from memory; slot = fetch-add on the (link, partition)'s next slot -- stable by
 //           the order above; the records {dwell, low 12 bits of the rank} wait in per-partition rings in LDS until a whole 64-B line
 //           of part[] can be written (a partition gets 8 of a segment's 512 events: written as they come, every line of part[]
-//           would be written in pieces, which costs the memory system 1.5x the time: measured); evrec = {slot, rank}
+//           would be written in pieces, which costs the memory system 1.5x the time: measured); evrec32 = rank | slot - first slot of the
+//           (link, partition): 2 B per event for the sample kernels, which take the rank from the bases (lbase, tile_link)
 //   ONE     (k <= 6: one partition, the only pass) COUNT's work; an event's slot is its position in the worker chain, which staging
 //           knows for every link and read: part[slot] = {dwell, rank} is written straight away, and the sample kernels need no evrec
 //
@@ -32,6 +33,9 @@
 #define PEV_COUNT_OCC 1                  // first pass: wavefronts per SIMD the register allocation aims at
 #endif
 #define PEV_WAVES_SCATTER 2              // ... second pass (10 KiB of LDS per link)
+#ifndef PEV_PACK_SUMS
+#define PEV_PACK_SUMS 1                  // two tile sums per DPP scan (A/B)
+#endif
 #define PEV_HALO 24                      // bases behind the segment's own: 2 (k - 1) <= 16 (the k-mers of the RNA stall start k - 1 bases further on)
 #define PEV_WORDS ((PEV_SEG + PEV_HALO) / 16 + 2)
 
@@ -44,6 +48,7 @@ struct PevWave {
     uint32_t codes[PEV_WORDS];           // the segment's 2-bit base codes, 16 per word, first base in the top bits
     uint32_t wslot[PART_MAX];            // COUNT: the link's events per partition so far; SCATTER: the partition's next slot in part[]
     // SCATTER: a partition's records wait in its ring (slot s at ring[p][s % 32]) until a whole 64-B line of part[] can be written
+    uint32_t wbase[SCATTER ? PART_MAX : 1];              // SCATTER: first slot of the (link, partition): an event's record carries its slot minus this
     uint32_t flu[SCATTER ? PART_MAX : 1];                // first slot of the partition not yet written to part[]
     uint32_t ring[SCATTER ? PART_MAX * PEV_RING : 1];    // (a segment that does not fit the rings borrows them as its sort buffer)
     uint2 tasks[SCATTER ? PEV_TASKS : 1];                // lines to write: {line, partition | first element << 8 | end element << 16}
@@ -81,7 +86,11 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
     const uint32_t kmask = (1u << (2 * k)) - 1u;                  // (k <= 9 here)
     W.wslot[lane] = (SCATTER && lane < P.n_part) ? P.poff[(size_t)lane * P.n_links + chain] + P.pstart[(size_t)P.link_q[chain] * P.n_part + lane] : 0u;
     uint32_t slot0 = ONE ? P.poff[chain] : 0u;                     // ONE: the link's first slot (absolute: staging knows every link's events); then the read's
-    if (SCATTER) W.flu[lane] = W.wslot[lane];
+    if (SCATTER) {
+        W.flu[lane] = W.wslot[lane];
+        W.wbase[lane] = W.wslot[lane];
+        P.lbase[(size_t)chain * PART_MAX + lane] = W.wslot[lane];     // what the sample kernels add to an event's 16-bit record
+    }
     // SCATTER: the slots [a, b) of lane p's partition go from the ring to part[], 64-B line by line (whole lines but for a link's
     // first and last): every lane lists its lines, then 16 lanes write one line each
     auto flush = [&](const uint32_t a, const uint32_t b) {
@@ -224,6 +233,19 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
             if (DW) c_seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)lcg_mul(c_seg, a2seg));
             if (!SCATTER) {
                 // ---- first sample of every 64-event tile, the read's totals, events per partition
+                // (the samples of each of the segment's eight tiles: a sum over the wavefront -- two tiles per DPP scan, 16 bits each,
+                // while 64 dwells fit 16 bits: 7 of the pass's 69 instructions per event)
+                uint32_t tsum[PEV_EPL];
+                if (PEV_PACK_SUMS && P.dwell_pack) {
+#pragma unroll
+                    for (int q = 0; q < PEV_EPL; q += 2) {
+                        const uint32_t two = (uint32_t)pev_wave_sum((int)((uint32_t)sps[q] | ((uint32_t)sps[q + 1] << 16)));
+                        tsum[q] = two & 0xffffu; tsum[q + 1] = two >> 16;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < PEV_EPL; q++) tsum[q] = (uint32_t)pev_wave_sum(sps[q]);
+                }
                 uint32_t run = 0;
 #pragma unroll
                 for (int q = 0; q < PEV_EPL; q++) {
@@ -232,7 +254,7 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
                         if (lane == 0) P.tile_so[rd.tile_off + (e_q >> 6)] = (uint32_t)done + run;
                         if (rd.ne1 > 0 && rd.ne0 >= e_q && rd.ne0 < e_q + 64)       // the second part starts in this tile
                             n1 = (long long)done + run + pev_wave_sum(lane < rd.ne0 - e_q ? sps[q] : 0);
-                        run += (uint32_t)pev_wave_sum(sps[q]);
+                        run += tsum[q];
                         if (ONE) {
                             if (PEV_IN(64 * q + lane)) {
                                 const uint32_t sl = slot0 + (uint32_t)(s0 - e_lo + 64 * q + lane);
@@ -254,11 +276,14 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
                     asm volatile("" ::: "memory");                    // (the compiler keeps the atomics in this order)
                 }
                 const uint32_t end = W.wslot[lane];
+                // the event's record for the sample kernels: rank | its slot relative to the (link, partition)'s first (14 bits: staging
+                // keeps a link below 16384 events).  Non-temporal: not read before the sample kernel
 #pragma unroll
                 for (int q = 0; q < PEV_EPL; q++) {
                     if (PEV_IN(64 * q + lane))
-                        __builtin_nontemporal_store(((unsigned long long)rank[q] << 32) | slot[q], reinterpret_cast<unsigned long long*>(P.evrec + rd.ev_off + s0 + 64 * q + lane));
+                        __builtin_nontemporal_store((rank[q] << EVR_REL_BITS) | (slot[q] - W.wbase[rank[q] >> PART_SUB_BITS]), P.evrec32 + rd.ev_off + s0 + 64 * q + lane);
                 }
+                if (lane < PEV_EPL && s0 + 64 * lane < ne) P.tile_link[rd.tile_off + (s0 >> 6) + lane] = chain;   // (one tile per 64 events of the segment)
                 if (__builtin_amdgcn_ballot_w64(end - flu > (uint32_t)PEV_RING) == 0ull) {
                     // the records join their partitions' rings; what completes a line of part[] goes out
 #pragma unroll

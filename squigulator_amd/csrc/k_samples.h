@@ -2,6 +2,11 @@
 // Part of the device code of the per-read signal path; included through sqg_kernels.h (see there for the overview).
 #pragma once
 
+#ifndef SQG_LB_BPERM
+#define SQG_LB_BPERM 1                     // evrec32: a partition's first slot through the lane crossbar (ds_bpermute) instead of LDS memory
+                                           // (A/B: the LDS copy costs the sample kernel 4 %: a write, a fence, 1 KiB less LDS per workgroup)
+#endif
+
 struct SmpWaveLds {
     uint4 rec_a[64];            // {c_ev, first sample in tile, F | level_mean, sdk | sd}
     uint2 rec_b[64];            // {I | constant sample, thr}
@@ -91,9 +96,8 @@ __global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_st
     d.ev_read0 = lt * LEAN_EV;
     d.read = r;
     d.shift_lo = shift_lo; d.shift_hi = shift_hi;
-    d.slot_first = P.one ? rd.slot0 + lt * LEAN_EV : 0;
+    d.slot_first = P.one ? rd.slot0 + lt * LEAN_EV : P.evrec32 ? (rd.slot0 >= 0 ? rd.slot0 : P.tile_link[rd.tile_off + lt * LEAN_EPL]) : 0;
     P.items[g] = d;
-    P.tfix_n[g] = 0;
 }
 
 // load through the constant address space: for a wave-uniform address this is a scalar load (the arrays read this way
@@ -118,6 +122,10 @@ struct LeanWaveLds {
                                         // sample s; z: events begun before the step; w: 0}; entries 64, 65 are read ahead, never used
     int nfix;                           // undecided samples of the item so far
     int pad[3];
+    uint4 park[FIX_SLOTS];              // ... parked here {index in read, c1, event in read, in the level-shift window} until the item is done
+#if !SQG_LB_BPERM
+    uint32_t lb[PART_MAX];              // evrec32: first slot of every partition of the item's link
+#endif
 };
 template <int EPL>
 struct LeanLds {
@@ -185,7 +193,6 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
                     const int nt = (n_ev + 63) >> 6;
                     const unsigned int q = atomicAdd(P.slow_count, (unsigned int)nt);
                     for (int i = 0; i < nt; i++) P.slow_tiles[q + i] = rd.tile_off + lt * LEAN_EPL + i;
-                    P.tfix_n[g] = 0;
                 }
                 continue;
             }
@@ -206,7 +213,8 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
             it.ev_read0 = lt * LEAN_EV;
             it.read = r;
             it.shift_lo = shift_lo; it.shift_hi = shift_hi;
-            it.slot_first = P.one ? rd.slot0 + lt * LEAN_EV : 0;
+            // (the item's link: the read's, or -- a read cut into pieces -- what the scatter pass noted for the tile)
+            it.slot_first = P.one ? rd.slot0 + lt * LEAN_EV : P.evrec32 ? (rd.slot0 >= 0 ? rd.slot0 : sload(P.tile_link + rd.tile_off + lt * LEAN_EPL)) : 0;
         }
         const int ne = it.n_ev;                                         // events of this item
         if (ne == 0) continue;                                         // not taken, or empty
@@ -230,6 +238,37 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
                     const uint32_t w_ = e0 + q < ne ? P.part[gslot + q] : 0u;
                     er[q] = make_uint2(gslot + (uint32_t)q, w_ & 0xffffu); sps[q] = (int)(w_ >> 16);
                 }
+            }
+        } else if (P.evrec32) {
+            // (wave-uniform) bucketed hand-out, 4-B event records {rank, slot within the (link, partition)}: the slot is the first slot of the
+            // (link, partition) -- 64 words per link, staged through LDS -- plus the record's low bits
+#if SQG_LB_BPERM
+            const uint32_t lbv = P.lbase[(size_t)it.slot_first * PART_MAX + lane];      // lane p: partition p's first slot
+#else
+            W.lb[lane] = P.lbase[(size_t)it.slot_first * PART_MAX + lane];
+#endif
+            uint32_t ew[LEAN_EPL];
+            uint16_t dw[LEAN_EPL];
+            __builtin_memcpy(ew, P.evrec32 + gev, 4 * LEAN_EPL);       // (4-B / 2-B aligned wide loads; both arrays end with slack)
+            if (P.dwell) __builtin_memcpy(dw, P.dwell + gev, 2 * LEAN_EPL);
+            else {
+#pragma unroll
+                for (int q = 0; q < LEAN_EPL; q++) dw[q] = (uint16_t)P.const_sps;
+            }
+#if !SQG_LB_BPERM
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // W.lb is written
+#endif
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) {
+                const bool v = e0 + q < ne;
+                const uint32_t rank = v ? ew[q] >> EVR_REL_BITS : 0u;
+#if SQG_LB_BPERM
+                const uint32_t lb_p = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rank >> PART_SUB_BITS) << 2), (int)lbv);   // (lane crossbar: no LDS memory)
+#else
+                const uint32_t lb_p = W.lb[rank >> PART_SUB_BITS];
+#endif
+                er[q] = make_uint2(v ? lb_p + (ew[q] & ((1u << EVR_REL_BITS) - 1u)) : 0u, rank);
+                sps[q] = v ? (int)dw[q] : 0;
             }
         } else if (e0 + LEAN_EPL <= ne) {
             uint32_t ew[2 * LEAN_EPL];
@@ -297,7 +336,6 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         // byte offset of my sample of step 0 within the read: generation index i is stored at at0 + i (RNA: at0 - i)
         uint32_t voff = RNA ? 2u * (it.at0 - (uint32_t)lane) : 2u * (it.at0 + (uint32_t)lane);
         uint32_t idx4 = (uint32_t)lane << 2;                           // 4 * (my sample index within the item), advanced every second step
-        const int ev_read0 = it.ev_read0;                               // event index (within the read) of rec[0]
 #if defined(SQG_ABL_NOLOOP)
         const int nfull = 0, rem = wave_total & 1;
 #else
@@ -332,7 +370,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
                 const int slot = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u)); \
                 const uint32_t at_ = (RNA ? voff - 128u * (DI) : voff + 128u * (DI)) >> 1;                        \
                 const int ev_ = EV;                                                                               \
-                if (slot < FIX_SLOTS) P.tfix[(size_t)g * FIX_SLOTS + slot] = make_uint4(at_, c1, (uint32_t)(ev_read0 + ev_), shf ? 1u : 0u); \
+                if (slot < FIX_SLOTS) W.park[slot] = make_uint4(at_, c1, (uint32_t)ev_, shf ? 1u : 0u);              \
                 else push_fix_one(P, it.sig_base + at_, c1, it.ev_first + ev_, it.read, shf ? 1 : 0);   /* overflow (never in practice): global list */ \
                 if (slot + 1 == n0 + __popcll(am)) W.nfix = slot + 1;          /* the last of them publishes the new count */ \
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                            \
@@ -393,8 +431,30 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         #undef LEAN_STORE_COND
         #undef LEAN_NEARONE_TEST
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        const int nfix = W.nfix;
-        if ((LEAN_EPL == 4 || nfix) && lane == 0) P.tfix_n[g] = (unsigned char)min(nfix, FIX_SLOTS);   // (k_items cleared it for the short items)
+        // the item's parked samples (one item in seven has any) join one of the batch's FIX_SHARDS lists for k_fixup: ONE returning
+        // atomic per such item, at its end (per-item lists walked by a kernel of their own cost that kernel 0.28 ms and 0.4 GB per
+        // batch of scattered look-ups next to the following batch's event pass; ONE list, 9e4 atomics on one address, 3.4 ms)
+        const int nfix = min(W.nfix, FIX_SLOTS);
+        if (nfix) {
+            const unsigned int sh = blockIdx.x & (FIX_SHARDS - 1);
+            unsigned int at0 = 0;
+            if (lane == 0) at0 = atomicAdd(P.fix_sh_count + sh * FIX_SHARD_STRIDE, (unsigned int)nfix);
+            at0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)at0);
+            FixEntry* dst = P.fix_sh + (size_t)sh * FIX_SHARD_CAP + at0;
+            bool room = at0 + (unsigned int)nfix <= FIX_SHARD_CAP;
+            if (!room) {                                               // the list is full (forced fix-ups in tests): the global list
+                if (lane == 0) at0 = atomicAdd(P.fix_count, (unsigned int)nfix);
+                at0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)at0);
+                dst = P.fix + at0;
+                room = at0 + (unsigned int)nfix <= P.fix_cap;
+                if (!room && lane == 0) atomicOr(P.err, 8u);
+            }
+            if (room && lane < nfix) {
+                const uint4 pk = W.park[lane];
+                FixEntry fe; fe.at = it.sig_base + pk.x; fe.c1 = pk.y; fe.ev = it.ev_first + pk.z; fe.read = it.read; fe.shifted = (int)pk.w; fe.pad = P.fix_tag;
+                dst[lane] = fe;
+            }
+        }
     }
 }
 
@@ -426,6 +486,10 @@ __global__ __launch_bounds__(256) void k_samples(const SigParams P, const int n_
                 const uint32_t sl = (uint32_t)rd.slot0 + (uint32_t)e, w_ = P.part[sl];
                 er = make_uint2(sl, w_ & 0xffffu);
                 sps = (int)(w_ >> 16);
+            } else if (P.evrec32) {                                    // bucketed hand-out, 4-B event records: {rank, slot within the (link, partition)}
+                const uint32_t w_ = P.evrec32[rd.ev_off + e], rank = w_ >> EVR_REL_BITS;
+                er = make_uint2(P.lbase[(size_t)(rd.slot0 >= 0 ? rd.slot0 : P.tile_link[g]) * PART_MAX + (rank >> PART_SUB_BITS)] + (w_ & ((1u << EVR_REL_BITS) - 1u)), rank);
+                sps = P.dwell ? (int)P.dwell[rd.ev_off + e] : P.const_sps;
             } else {
                 er = P.evrec[rd.ev_off + e];
                 sps = P.dwell ? (int)P.dwell[rd.ev_off + e] : P.const_sps;
@@ -577,49 +641,40 @@ __global__ __launch_bounds__(256) void k_samples(const SigParams P, const int n_
 }
 
 // ---- k_fixup: FP64 path for the samples the certified kernels left undecided ------------------
-// per-tile slots of the lean kernel: one thread per super tile walks its (0-8, typically 0-1) parked samples.
-// No atomics: a returning atomic per wavefront on one counter costs ~10 ns each and serialises.
-__global__ __launch_bounds__(256) void k_fixup_tiles(const SigParams P, const int n_stiles) {
-    __shared__ uint16_t work[4][64 * FIX_SLOTS];         // per wavefront: (lane of the item << 4) | slot
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    const int n = g < n_stiles ? (int)P.tfix_n[g] : 0;
-    // spread the wavefront's parked samples (0-8 per item, ~0.5 on average) evenly over its lanes
-    const int incl = wave_incl_scan_dpp(n);
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    if (total == 0) return;
-    if (lane == 0) atomicAdd(P.fix_count + 2, (unsigned int)total);   // statistics: samples parked per item (sqg_get_timing)
-    for (int q = 0; q < n; q++) work[wid][incl - n + q] = (uint16_t)((lane << 4) | q);
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    for (int w = lane; w < total; w += 64) {
-        const int code = work[wid][w];
-        const int gi = g - lane + (code >> 4), slot = code & 15;
-        const int r = P.stile_read[gi];
-        const ReadDesc rd = P.reads[r];
-        const uint4 fe = P.tfix[(size_t)gi * FIX_SLOTS + slot];
-        const int e = (int)fe.z;
-        const uint8_t* bp = P.bases + rd.base_off + (e < rd.ne0 ? (long long)e : (long long)rd.len0 + (e - rd.ne0));
-        const uint32_t rank = kmer_rank_of(bp, P.k, P.meth);
-        const float2 md = P.model[rank];
-        int16_t q = sample_exact(fe.y, md.x, md.y, P.dig, P.range, rd.offset);
-        if (fe.w) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);      // RNA adaptor level shift
-        P.sig[P.sig_off[r] + fe.x] = q;
-    }
+// one list per batch (SigParams.fix): the lean kernel appends an item's parked samples at the item's end, the generic kernel per step
+__device__ static inline void fixup_one(const SigParams& P, const FixEntry& fe) {
+    const ReadDesc rd = P.reads[fe.read];
+    const int e = (int)(fe.ev - rd.ev_off);
+    const uint8_t* bp = P.bases + rd.base_off + (e < rd.ne0 ? (long long)e : (long long)rd.len0 + (e - rd.ne0));
+    const uint32_t rank = kmer_rank_wide(bp, P.k, P.meth);
+    const float2 md = P.model[rank];
+    int16_t q = sample_exact(fe.c1, md.x, md.y, P.dig, P.range, rd.offset);
+    if (fe.shifted) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);
+    P.sig[fe.at] = q;
 }
-
+// grid: FIX_SHARDS workgroups.  Workgroup s: list s of the lean kernel (entries of this batch carry its tag), and its share of the
+// global list (the generic kernel's samples, and what did not fit a list)
 __global__ __launch_bounds__(256) void k_fixup(const SigParams P) {
-    const unsigned int n = min(*P.fix_count, P.fix_cap);
-    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const FixEntry fe = P.fix[i];
-        const ReadDesc rd = P.reads[fe.read];
-        const int e = (int)(fe.ev - rd.ev_off);
-        const uint8_t* bp = P.bases + rd.base_off + (e < rd.ne0 ? (long long)e : (long long)rd.len0 + (e - rd.ne0));
-        const uint32_t rank = kmer_rank_of(bp, P.k, P.meth);
-        const float2 md = P.model[rank];
-        int16_t q = sample_exact(fe.c1, md.x, md.y, P.dig, P.range, rd.offset);
-        if (fe.shifted) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);
-        P.sig[fe.at] = q;
+    if (P.fix_sh) {
+        const unsigned int ns = min(P.fix_sh_count[blockIdx.x * FIX_SHARD_STRIDE], (unsigned int)FIX_SHARD_CAP);
+        const FixEntry* lst = P.fix_sh + (size_t)blockIdx.x * FIX_SHARD_CAP;
+        unsigned int mine = 0;
+        for (unsigned int i = threadIdx.x; i < ns; i += 256) {
+            const FixEntry fe = lst[i];
+            if (fe.pad != P.fix_tag) continue;                         // (counted, but written to the global list: the list was full)
+            fixup_one(P, fe);
+            mine++;
+        }
+        // statistics (sqg_get_timing): samples that went through this list (a word per list, summed by the host: 4096 atomics on one
+        // counter took this kernel from 15 to 124 us)
+        __shared__ unsigned int wsum[4];
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) P.fix_sh_stat[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
+    const unsigned int n = min(*P.fix_count, P.fix_cap);
+    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) fixup_one(P, P.fix[i]);
 }
 
 // ---- k_certify: max |x_fast - x_exact| over every state the fp32 path may accept ------------

@@ -5,7 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-prof}
 shift || true
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-store-probe $*"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-store-probe --pipeline-seconds 0 $*"
 # the stats pass runs the bench exactly as the driver does (defaults; CPU legs included): its kernel averages are the ones
 # the bench line's roofline.kernel_ms has to agree with
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python $GRAFT_REPO_ROOT/bench.py $* > $OUT/trace.log 2>&1
@@ -15,6 +15,16 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_
 ls -R $OUT | head -30
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in their own passes (TCC slots); the WRITE pass also runs the
 # bench's store probe (k_store_probe writes a known 1 GiB per launch) to calibrate WRITE_SIZE units
-BENCH2="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+BENCH2="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --pipeline-seconds 0 $*"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o pmc4 -- $BENCH2 > $OUT/pmc4.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o pmc5 -- $BENCH2 > $OUT/pmc5.log 2>&1
+# condense on the box (the raw traces of a default run -- timed steps + the streaming leg -- exceed what gpurun brings back):
+# $OUT/summary/<name>_{summary.md,kernel_stats.csv,traffic.json,bench_under_rocprof.json}; the big CSVs are dropped
+NAME=$(basename $OUT)
+mkdir -p $OUT/summary
+cd $GRAFT_REPO_ROOT
+python tools/summarize_prof.py $OUT $OUT/summary/$NAME > /dev/null 2> $OUT/summary/summarize.err
+python tools/make_traffic.py $OUT $OUT/summary/$NAME > /dev/null 2> $OUT/summary/traffic.err
+cp $OUT/summary/traffic_latest.json $OUT/summary/${NAME}_traffic_latest.json 2>/dev/null
+find $OUT -maxdepth 1 -name "*.csv" -size +2M -delete
+du -sh $OUT

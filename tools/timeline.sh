@@ -14,10 +14,11 @@ for f in glob.glob("$OUT/**/tl_memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "")))
 rows.sort()
-# last full batch: from the last k_events on
-idx = [i for i, r in enumerate(rows) if "k_events" in r[2]]
-lo = idx[-2] if len(idx) > 1 else idx[-1]
-hi = idx[-1]
+# one full batch of the timed region: from the first event pass of the second-to-last timed batch to the next batch's first event pass
+first = ("k_part_events<1", "k_part_events<2", "k_events")
+idx = [i for i, r in enumerate(rows) if any(f in r[2] for f in first) and "k_part_events<0, 1>" not in r[2]]
+lo = idx[-3] if len(idx) > 2 else idx[0]
+hi = idx[-2] if len(idx) > 2 else idx[-1]
 prev_end = rows[lo][0]
 t0 = rows[lo][0]
 for s, e, n in rows[lo:hi + 1]:
