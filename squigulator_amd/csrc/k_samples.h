@@ -2,6 +2,9 @@
 // Part of the device code of the per-read signal path; included through sqg_kernels.h (see there for the overview).
 #pragma once
 
+#ifndef SQG_ABL_FIXK
+#define SQG_ABL_FIXK 0                     // timing-only ablations of k_fixup (1: counts only, 2: entries read, not processed)
+#endif
 #ifndef SQG_LB_BPERM
 #define SQG_LB_BPERM 1                     // evrec32: a partition's first slot through the lane crossbar (ds_bpermute) instead of LDS memory
                                            // (A/B: the LDS copy costs the sample kernel 4 %: a write, a fence, 1 KiB less LDS per workgroup)
@@ -648,7 +651,11 @@ __device__ static inline void fixup_one(const SigParams& P, const FixEntry& fe) 
     const uint8_t* bp = P.bases + rd.base_off + (e < rd.ne0 ? (long long)e : (long long)rd.len0 + (e - rd.ne0));
     const uint32_t rank = kmer_rank_wide(bp, P.k, P.meth);
     const float2 md = P.model[rank];
+#if defined(SQG_ABL_FIXMATH)                                       /* timing-only ablation: the fix-up kernel without its FP64 arithmetic */
+    int16_t q = (int16_t)(fe.c1 + (uint32_t)md.x + (uint32_t)md.y);
+#else
     int16_t q = sample_exact(fe.c1, md.x, md.y, P.dig, P.range, rd.offset);
+#endif
     if (fe.shifted) q = (int16_t)(uint16_t)(((int)q - P.shift) & 0xffff);
     P.sig[fe.at] = q;
 }
@@ -659,12 +666,16 @@ __global__ __launch_bounds__(256) void k_fixup(const SigParams P) {
         const unsigned int ns = min(P.fix_sh_count[blockIdx.x * FIX_SHARD_STRIDE], (unsigned int)FIX_SHARD_CAP);
         const FixEntry* lst = P.fix_sh + (size_t)blockIdx.x * FIX_SHARD_CAP;
         unsigned int mine = 0;
+#if SQG_ABL_FIXK != 1
         for (unsigned int i = threadIdx.x; i < ns; i += 256) {
             const FixEntry fe = lst[i];
             if (fe.pad != P.fix_tag) continue;                         // (counted, but written to the global list: the list was full)
+#if SQG_ABL_FIXK != 2
             fixup_one(P, fe);
+#endif
             mine++;
         }
+#endif
         // statistics (sqg_get_timing): samples that went through this list (a word per list, summed by the host: 4096 atomics on one
         // counter took this kernel from 15 to 124 us)
         __shared__ unsigned int wsum[4];

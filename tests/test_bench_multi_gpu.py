@@ -138,3 +138,22 @@ def test_rccl_runs_with_one_rank(args):
     rccl = _bench("--gpus", 1, "--digest", 4, "--force-dist", "--backend", "nccl", *args)
     assert plain["ranks"]["backend"] is None and rccl["ranks"]["backend"] == "nccl" and rccl["ranks"]["world_size"] == 1
     assert plain["digest"] == rccl["digest"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,profile,regime", [("sequin-rna004", "rna004-prom", "-t 1"), ("ncov-r9", "dna-r9-prom", "T = K")])
+def test_bench_other_workloads(workload, profile, regime):
+    """BASELINE.json configs[4] (rnasequin -x rna004-prom --prefix=yes, whole transcripts, one worker per GPU) and configs[1] (nCoV
+    -x dna-r9-prom, T = K) through bench.py itself: the line, the roofline of the dominant kernel, the streaming leg, and the
+    parity check of the timed regime against the oracle"""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3", "--warmup", "1",
+                        "--batch-reads", "2048", "--cpu-seconds", "1", "--pipeline-seconds", "0.2"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert profile in d["config"]["workload"] and d["value"] > 0 and d["pipeline"]["value"] > 0
+    assert d["roofline"]["kernel"] == "k_samples_lean" and 0 < d["roofline"]["frac"] < 1
+    assert d["parity_check"]["equal"] is True and d["parity_check"]["regime"] == regime
+    assert d["cpu_baseline"]["value"] > 0
