@@ -94,13 +94,16 @@ __global__ __launch_bounds__(256) void k_part_slice_bounds(const uint32_t* __res
 // grid: slices (the host's bound; the live ones are pfirst[n_pairs]), 256 threads.  phist[s][sub] <- samples the slice's events draw from the stream
 // (sums commute: a thread takes four consecutive records with one 16-B load -- 4-B loads stream at 4.0 TB/s on this machine, 16-B
 // loads at 6.3, tools/pmc_calib.hip -- 2048 events of the slice per step, the next step's loads in flight during this one's atomics)
+#ifndef PART_HIST_PAD
+#define PART_HIST_PAD 0          // A/B: words of LDS a workgroup reserves beyond its table (fewer workgroups per CU: whole rounds of slices)
+#endif
 #ifndef PART_HIST_V4
 #define PART_HIST_V4 1
 #endif
 __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* __restrict__ part, const uint32_t* __restrict__ slice_lo,
                                                    const uint32_t* __restrict__ slice_hi, const uint32_t* __restrict__ n_slices,
                                                    uint32_t* __restrict__ phist) {
-    __shared__ uint32_t row[PART_SUB];
+    __shared__ uint32_t row[PART_SUB + PART_HIST_PAD];
     const int tid = threadIdx.x;
     if (blockIdx.x >= *n_slices) return;
     for (int i = tid; i < PART_SUB; i += 256) row[i] = 0u;
