@@ -296,7 +296,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             if (lean_grid_cap > 0) lgrid = std::min(lgrid, (unsigned)lean_grid_cap);
             // work items of 256 events (4 per lane) look their descriptor up themselves, on the scalar unit; with shorter
             // items (profiles with long dwells) the look-up chain per item is worth a kernel of its own
-            if (c->lean_epl < 4) hipLaunchKernelGGL(k_items, dim3((unsigned)((n_stiles + 255) / 256)), dim3(256), 0, c->stream, P, n_stiles, n, nullptr);
+            if (c->lean_epl < 4 || SQG_LEAN_ITEMS4) hipLaunchKernelGGL(k_items, dim3((unsigned)((n_stiles + 255) / 256)), dim3(256), 0, c->stream, P, n_stiles, n, nullptr);
             else P.items = nullptr;
             HIPCHK(c, hipEventRecord(b->ev[7], c->stream));              // event side done: the sample kernels may start ...
             HIPCHK(c, hipStreamWaitEvent(c->stream2, b->ev[7], 0));      // ... on their own stream, next to the next batch's k_events

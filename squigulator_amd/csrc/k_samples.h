@@ -5,6 +5,9 @@
 #ifndef SQG_ABL_FIXK
 #define SQG_ABL_FIXK 0                     // timing-only ablations of k_fixup (1: counts only, 2: entries read, not processed)
 #endif
+#ifndef SQG_LEAN_ITEMS4
+#define SQG_LEAN_ITEMS4 0                  // A/B: k_items prepares the descriptors of 256-event items as well (one look-up instead of a chain of three)
+#endif
 #ifndef SQG_LB_BPERM
 #define SQG_LB_BPERM 1                     // evrec32: a partition's first slot through the lane crossbar (ds_bpermute) instead of LDS memory
                                            // (A/B: the LDS copy costs the sample kernel 4 %: a write, a fence, 1 KiB less LDS per workgroup)
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         // the item's descriptor -- what the read, its 64-event tiles and the scanned read offsets say about this item -- is
         // wave-uniform: the whole look-up chain runs on the scalar unit (sload: constant-address-space loads)
         ItemDesc it;
-        if constexpr (LEAN_EPL < 4) {                                   // short items (1-2 events per lane): k_items prepared the descriptors
+        if constexpr (LEAN_EPL < 4 || SQG_LEAN_ITEMS4) {               // short items (1-2 events per lane): k_items prepared the descriptors
             it = sload(P.items + g);
             if (it.n_ev == 0) continue;                                // not taken, or empty
         } else {
@@ -296,12 +299,24 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
             }
         }
         float2 md[LEAN_EPL];
+#if defined(SQG_ABL_NODEP)       /* timing-only ablation (results are wrong): the set-up's second-level look-ups do not depend on the first */
+#pragma unroll
+        for (int q = 0; q < LEAN_EPL; q++) md[q] = (e0 + q < ne) ? P.model[(gev + q) & 0x3ffff] : make_float2(0.f, 0.f);
+        if (P.part_state) {
+            uint32_t stv[LEAN_EPL];
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) stv[q] = P.part_state[gev + q];
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) if (e0 + q < ne) er[q].x = (stv[q] + er[q].x) | 1u;
+        }
+#else
 #pragma unroll
         for (int q = 0; q < LEAN_EPL; q++) md[q] = (e0 + q < ne) ? P.model[er[q].y] : make_float2(0.f, 0.f);
         if (P.part_state) {                                            // (wave-uniform) k > 6, bucketed hand-out (k_part.h): slot -> state
 #pragma unroll
             for (int q = 0; q < LEAN_EPL; q++) if (e0 + q < ne) er[q].x = P.part_state[er[q].x];
         }
+#endif
         int lane_total = 0;
 #pragma unroll
         for (int q = 0; q < LEAN_EPL; q++) lane_total += sps[q];
