@@ -301,7 +301,8 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             HIPCHK(c, hipEventRecord(b->ev[7], c->stream));              // event side done: the sample kernels may start ...
             HIPCHK(c, hipStreamWaitEvent(c->stream2, b->ev[7], 0));      // ... on their own stream, next to the next batch's k_events
             HIPCHK(c, hipEventRecord(b->ev[5], c->stream2));
-#define LEANL(R, E) hipLaunchKernelGGL((k_samples_lean<R, E>), dim3(lgrid), dim3(256), 0, c->stream2, P, n_stiles)
+            static const unsigned lean_dynlds = getenv("SQG_LEAN_DYNLDS") ? (unsigned)atoi(getenv("SQG_LEAN_DYNLDS")) : 0u;   // A/B: bytes of LDS a workgroup reserves on top (fewer workgroups per CU)
+#define LEANL(R, E) hipLaunchKernelGGL((k_samples_lean<R, E>), dim3(lgrid), dim3(256), lean_dynlds, c->stream2, P, n_stiles)
             if (P.rna) { if (c->lean_epl == 4) LEANL(true, 4); else if (c->lean_epl == 2) LEANL(true, 2); else LEANL(true, 1); }
             else { if (c->lean_epl == 4) LEANL(false, 4); else if (c->lean_epl == 2) LEANL(false, 2); else LEANL(false, 1); }
 #undef LEANL
