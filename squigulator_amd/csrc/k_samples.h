@@ -380,8 +380,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
             /* RNA adaptor window: the ADC value gets -(int16)(30*dig/range) with int16 wrap (src/genread.c:79-86) */ \
             const bool shf = (SH) && (uint32_t)(si_ - it.shift_lo) < (uint32_t)(it.shift_hi - it.shift_lo);       \
             char* const dst_b = out_b + (RNA ? -128 * (DI) : 128 * (DI));                                         \
-            if (act && ok LEAN_STORE_COND) *reinterpret_cast<uint16_t*>(dst_b + voff) =                            \
-                (uint16_t)((__float_as_uint(t) + RA.y - (shf ? (uint32_t)P.shift : 0u)) & 0xffffu);                \
+            if (act && ok) { LEAN_STORE_STMT(DI, RA) }                                                              \
             else if (act) {                                        /* ~1 % of steps: park the undecided samples (no round trip) */ \
                 const unsigned long long am = __builtin_amdgcn_ballot_w64(true);                                  \
                 const int n0 = W.nfix;                                                                            \
@@ -406,6 +405,14 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         #define LEAN_STORE_COND && (__float_as_uint(t) == 0x12345u)
 #else
         #define LEAN_STORE_COND
+#endif
+        #define LEAN_STORE_VAL(RA_) (uint16_t)((__float_as_uint(t) + RA_.y - (shf ? (uint32_t)P.shift : 0u)) & 0xffffu)
+#if defined(SQG_ABL_STORE2)      /* timing-only ablation (results are wrong): the same bytes with half as many store instructions (a dword per lane every other step) */
+        #define LEAN_STORE_STMT(DI_, RA_) if (((DI_) & 1) == 0) *reinterpret_cast<uint32_t*>(dst_b + voff + 2u * (uint32_t)lane) = (uint32_t)LEAN_STORE_VAL(RA_) * 0x10001u;
+#elif defined(SQG_ABL_STORE4)    /* ... a quarter (8 bytes per lane every fourth step) */
+        #define LEAN_STORE_STMT(DI_, RA_) if (((DI_) & 3) == 0) *reinterpret_cast<uint2*>(dst_b + voff + 6u * (uint32_t)lane) = make_uint2((uint32_t)LEAN_STORE_VAL(RA_) * 0x10001u, c1);
+#else
+        #define LEAN_STORE_STMT(DI_, RA_) if (true LEAN_STORE_COND) *reinterpret_cast<uint16_t*>(dst_b + voff) = LEAN_STORE_VAL(RA_);
 #endif
 #if defined(SQG_ABL_NOARITH)
         #define LEAN_ARITH(RA, MU) const uint32_t c1 = (RA.x ^ MU) & 0x3fffffffu; const float x = __uint_as_float((RA.x + MU) & 0x3fffffffu);
@@ -447,6 +454,8 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         #undef LEAN_EVOF
         #undef LEAN_ARITH
         #undef LEAN_STORE_COND
+        #undef LEAN_STORE_STMT
+        #undef LEAN_STORE_VAL
         #undef LEAN_NEARONE_TEST
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         // the item's parked samples (one item in seven has any) join one of the batch's FIX_SHARDS lists for k_fixup: ONE returning
