@@ -8,6 +8,9 @@
 #ifndef SQG_LEAN_ITEMS4
 #define SQG_LEAN_ITEMS4 0                  // A/B: k_items prepares the descriptors of 256-event items as well (one look-up instead of a chain of three)
 #endif
+#ifndef SQG_LEAN_NT
+#define SQG_LEAN_NT 0                      // A/B: non-temporal sample stores
+#endif
 #ifndef SQG_LB_BPERM
 #define SQG_LB_BPERM 1                     // evrec32: a partition's first slot through the lane crossbar (ds_bpermute) instead of LDS memory
                                            // (A/B: the LDS copy costs the sample kernel 4 %: a write, a fence, 1 KiB less LDS per workgroup)
@@ -412,7 +415,11 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
 #elif defined(SQG_ABL_STORE4)    /* ... a quarter (8 bytes per lane every fourth step) */
         #define LEAN_STORE_STMT(DI_, RA_) if (((DI_) & 3) == 0) *reinterpret_cast<uint2*>(dst_b + voff + 6u * (uint32_t)lane) = make_uint2((uint32_t)LEAN_STORE_VAL(RA_) * 0x10001u, c1);
 #else
+#if SQG_LEAN_NT
+        #define LEAN_STORE_STMT(DI_, RA_) if (true LEAN_STORE_COND) __builtin_nontemporal_store(LEAN_STORE_VAL(RA_), reinterpret_cast<uint16_t*>(dst_b + voff));
+#else
         #define LEAN_STORE_STMT(DI_, RA_) if (true LEAN_STORE_COND) *reinterpret_cast<uint16_t*>(dst_b + voff) = LEAN_STORE_VAL(RA_);
+#endif
 #endif
 #if defined(SQG_ABL_NOARITH)
         #define LEAN_ARITH(RA, MU) const uint32_t c1 = (RA.x ^ MU) & 0x3fffffffu; const float x = __uint_as_float((RA.x + MU) & 0x3fffffffu);
