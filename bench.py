@@ -555,7 +555,7 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     sig_ms, ev_ms, lean_ms = [], [], []
-    samples = bases = reads = fallback = 0
+    samples = bases = reads = fallback = fallback_of = 0
     digests = []
     timed = batches[args.warmup:]
     for b in timed:
@@ -568,7 +568,9 @@ def main():
         tm = gen.timing()
         sig_ms.append(tm["samples_ms"]); ev_ms.append(tm["events_ms"])
         lean_ms.append(tm["lean_ms"] if tm["lean_ms"] > 0 else tm["samples_ms"])
-        samples += b.n_samples; bases += b.n_bases; reads += b.n_reads; fallback += tm["fallback_samples"]
+        samples += b.n_samples; bases += b.n_bases; reads += b.n_reads
+        if tm["fallback_samples"] >= 0:           # (-1: the batch's counters were reused by a later batch before it was waited for)
+            fallback += tm["fallback_samples"]; fallback_of += b.n_samples
         if to_stage > 0:              # a long run: this batch makes room for one more (the device has STAGE_AHEAD - 1 queued meanwhile)
             b.free()
             timed[i] = None
@@ -684,7 +686,8 @@ def main():
                 "what": "nothing staged ahead: one host thread per GPU samples (device-side gen_read) + stages batch i+1, queues it, "
                         "waits for batch i and frees it; two batches in flight, results left in HBM"},
             "reads_per_s": tot_reads / dt_max,
-            "fp64_fixup_frac": (fallback / samples if samples else 0.0) if args.mode == "certified" else None,   # samples the fp32 path left to FP64
+            # samples the fp32 path left to FP64, over the batches whose counters were still theirs when they were waited for
+            "fp64_fixup_frac": (fallback / fallback_of if fallback_of else None) if args.mode == "certified" else None,
             "samples_per_step_per_gpu": samples / steps,
             "kernel_ms": {"k_samples_lean": k_ms,
                           # from the end of the event side to the batch's last kernel; the fix-ups run on their own stream next to

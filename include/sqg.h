@@ -134,7 +134,8 @@ typedef struct {
     float samples_ms;           /* k_scan + k_samples_lean + k_samples<generic> + k_fixup*   */
     float lean_ms;              /* k_samples_lean alone: the dominant, roofline-priced kernel (0 if not launched) */
     float total_ms;             /* first launch to last completion                           */
-    int64_t fallback_samples;   /* CERTIFIED mode: samples recomputed on the FP64 path       */
+    int64_t fallback_samples;   /* CERTIFIED mode: samples recomputed on the FP64 path; -1: not known any more (the batch was
+                                 * waited for after two later batches had been run: the counters live with the output slabs) */
 } sqg_timing_t;
 
 int  sqg_create(const sqg_cfg_t *cfg, sqg_ctx_t **out);

@@ -34,7 +34,8 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
         c->timing.events_ms = ee;
         c->timing.lean_ms = 0.f;
         if (b->lean_timed) HIPCHK(c, hipEventElapsedTime(&c->timing.lean_ms, b->ev[5], b->ev[6]));
-        unsigned int nfix = 0;
+        long long nfix = 0;
+        if (c->cfg.mode == SQG_MODE_CERTIFIED && !slot_is_mine(c, b)) nfix = -1;   // the slot's counters belong to a later batch by now: not known
         if (c->cfg.mode == SQG_MODE_CERTIFIED && slot_is_mine(c, b)) {
             unsigned int cnt[4] = {0, 0, 0, 0};
             HIPCHK(c, hipMemcpy(cnt, S.d_fix_count, sizeof cnt, hipMemcpyDeviceToHost));

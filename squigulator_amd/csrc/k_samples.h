@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         #undef LEAN_STORE_VAL
         #undef LEAN_NEARONE_TEST
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        // the item's parked samples (one item in seven has any) join one of the batch's FIX_SHARDS lists for k_fixup: ONE returning
+        // the item's parked samples (every other item has one: 4.5e-4 of the samples) join one of the batch's FIX_SHARDS lists for k_fixup: ONE returning
         // atomic per such item, at its end (per-item lists walked by a kernel of their own cost that kernel 0.28 ms and 0.4 GB per
         // batch of scattered look-ups next to the following batch's event pass; ONE list, 9e4 atomics on one address, 3.4 ms)
         const int nfix = min(W.nfix, FIX_SLOTS);
