@@ -31,6 +31,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (multi-process GPU work on these hosts: dmabuf IPC only; must be set before HIP starts)
 import socket
 import subprocess
 import sys

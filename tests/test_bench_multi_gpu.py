@@ -157,3 +157,17 @@ def test_bench_other_workloads(workload, profile, regime):
     assert d["roofline"]["kernel"] == "k_samples_lean" and 0 < d["roofline"]["frac"] < 1
     assert d["parity_check"]["equal"] is True and d["parity_check"]["regime"] == regime
     assert d["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_run_the_streaming_leg_and_report_their_clocks():
+    """N > 1 without --digest: the timed steps, then the streaming leg on every rank (the same number of batches everywhere: range
+    sharding has a collective per batch), reductions over the ranks, `ranks` and `pipeline` in rank 0's line"""
+    for extra in (["--workers-per-gpu", 1], ["--job-workers", 1]):
+        d = _bench("--gpus", 2, "--backend", "gloo", "--genome-mb", 24, "--batch-reads", 512, "--pipeline-seconds", 0.3, *extra)
+        assert d["n_gpus"] == 2 and d["ranks"]["world_size"] == 2 and d["ranks"]["backend"] == "gloo"
+        assert d["ranks"]["ms_per_step_min"] <= d["ranks"]["ms_per_step_max"] == pytest.approx(d["ms_per_step"], rel=1e-9)
+        pl = d["pipeline"]
+        assert pl["value"] > 0 and pl["batches_per_gpu"] >= 9 and pl["reads_per_s"] > 0
+        # both ranks' samples are in the whole-job numbers
+        assert d["samples_per_step_per_gpu"] * 2 == pytest.approx(d["value"] * d["ms_per_step"] * 1e-3, rel=0.2)
