@@ -443,6 +443,9 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
 // atomics cost the LDS: one address, one lane after the other.
 // a^(2n) comes from three 256-entry tables in LDS (n < 2^24: a stream's samples in one slice; else the global tables).
 #define PART_LT 256
+#ifndef HAND_STEP
+#define HAND_STEP 1024          // events per step of k_part_hand_ord (A/B: 2048 -- twice the loads in flight; a slice is a multiple of PART_STEP)
+#endif
 // Every slice of every batch also SAMPLES the property it stands on, in production shape (this table, these dwells, this
 // occupancy): the counts its first PART_CHECK events received are compared with order-free prefix sums over the same records (a
 // loop over the earlier events in LDS, ~1 % of the slice's work); a mismatch sets bit 64 of the batch's error word and the batch
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(64) void k_part_hand_ord(const uint32_t* __restrict
     __shared__ uint32_t cnt[PART_SUB];                            // samples handed out so far
     __shared__ uint4 chk[PART_CHECK / 4];                         // the slice's first events, for the order check
     __shared__ uint32_t lt0[PART_LT], lt1[PART_LT], lt2[PART_LT]; // a^(2j), a^(2 * 256 j), a^(2 * 65536 j), DOUBLED (lcg_mul_dbl)
-    constexpr int NR = PART_STEP / 64;                            // records per lane and step
+    constexpr int NR = HAND_STEP / 64;                            // records per lane and step
     const int lane = threadIdx.x;
     if (blockIdx.x >= *n_slices) return;
     const uint4* src = reinterpret_cast<const uint4*>(phist + (size_t)blockIdx.x * PART_SUB);
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(64) void k_part_hand_ord(const uint32_t* __restrict
     auto step = [&](auto full_tag, auto check_tag, const uint32_t left) {
         constexpr bool FULL = decltype(full_tag)::value, CHECK = decltype(check_tag)::value;
 #pragma unroll
-        for (int r = 0; r < NR; r++) nxt[r] = in[PART_STEP + 64 * r];
+        for (int r = 0; r < NR; r++) nxt[r] = in[HAND_STEP + 64 * r];
         uint32_t n[NR], out[NR];
         if (CHECK && fault) {                                       // (test hook) rows 0 and 1 in the wrong order
             const uint32_t t = cur[0]; cur[0] = cur[1]; cur[1] = t;
@@ -531,12 +534,12 @@ __global__ __launch_bounds__(64) void k_part_hand_ord(const uint32_t* __restrict
         for (int r = 0; r < NR; r++) if (FULL || (uint32_t)(64 * r + lane) < left) out_p[64 * r] = out[r];
 #pragma unroll
         for (int r = 0; r < NR; r++) cur[r] = nxt[r];
-        in += PART_STEP; out_p += PART_STEP;
+        in += HAND_STEP; out_p += HAND_STEP;
     };
     uint32_t b = lo;
-    if (b + PART_STEP <= hi) { step(std::true_type{}, std::true_type{}, 0u); b += PART_STEP; }
+    if (b + HAND_STEP <= hi) { step(std::true_type{}, std::true_type{}, 0u); b += HAND_STEP; }
     else if (b < hi) { step(std::false_type{}, std::true_type{}, hi - b); b = hi; }
-    for (; b + PART_STEP <= hi; b += PART_STEP) step(std::true_type{}, std::false_type{}, 0u);
+    for (; b + HAND_STEP <= hi; b += HAND_STEP) step(std::true_type{}, std::false_type{}, 0u);
     if (b < hi) step(std::false_type{}, std::false_type{}, hi - b);
 }
 
