@@ -443,6 +443,9 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
 // atomics cost the LDS: one address, one lane after the other.
 // a^(2n) comes from three 256-entry tables in LDS (n < 2^24: a stream's samples in one slice; else the global tables).
 #define PART_LT 256
+#ifndef HAND_ABL
+#define HAND_ABL 0
+#endif
 #ifndef HAND_STEP
 #define HAND_STEP 1024          // events per step of k_part_hand_ord (A/B: 2048 -- twice the loads in flight; a slice is a multiple of PART_STEP)
 #endif
@@ -490,8 +493,12 @@ __global__ __launch_bounds__(64) void k_part_hand_ord(const uint32_t* __restrict
 #pragma unroll
         for (int r = 0; r < NR; r++) {
             n[r] = 0;
+#if HAND_ABL == 1      /* timing-only ablation: no atomics */
+            n[r] = cur[r] & 7u;
+#else
             if (FULL || (uint32_t)(64 * r + lane) < left) n[r] = __hip_atomic_fetch_add(&cnt[cur[r] & (PART_SUB - 1)], cur[r] >> 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             asm volatile("" ::: "memory");                          // (the compiler keeps the atomics in this order)
+#endif
         }
         if (CHECK && fault) {
             const uint32_t t = cur[0]; cur[0] = cur[1]; cur[1] = t;
@@ -521,17 +528,33 @@ __global__ __launch_bounds__(64) void k_part_hand_ord(const uint32_t* __restrict
             }
             if ((v0 && n[0] != w0) || (v1 && n[1] != w1)) atomicOr(err, 64u);
         }
+        // (the step's 2 x NR table reads first, back to back, then the multiplications, then ONE test for the rare second level: a test
+        // and a branch per record made every record wait for its own two LDS round trips -- 4100 cycles per 1024-event step and
+        // wavefront, of which the atomics are 660)
+        {
+            uint32_t bs[NR], m0[NR];
 #pragma unroll
-        for (int r = 0; r < NR; r++) {
-            out[r] = lcg_mul_dbl(base[cur[r] & (PART_SUB - 1)], lt0[n[r] & (PART_LT - 1)]);
-            if (__builtin_amdgcn_ballot_w64(n[r] >= (uint32_t)PART_LT)) {                       // (seldom: a dozen events on one stream before this one)
-                out[r] = lcg_mul_dbl(out[r], lt1[(n[r] >> 8) & (PART_LT - 1)]);
-                const uint32_t h = n[r] >> 16;
-                if (h) out[r] = h < PART_LT ? lcg_mul_dbl(out[r], lt2[h]) : lcg_mul(out[r], lcg_jump2(pw, h << 16));
+            for (int r = 0; r < NR; r++) { bs[r] = base[cur[r] & (PART_SUB - 1)]; m0[r] = lt0[n[r] & (PART_LT - 1)]; }
+            bool big = false;
+#pragma unroll
+            for (int r = 0; r < NR; r++) { out[r] = lcg_mul_dbl(bs[r], m0[r]); big |= n[r] >= (uint32_t)PART_LT; }
+            if (__builtin_amdgcn_ballot_w64(big)) {                                             // (seldom: a dozen events on one stream before this one)
+#pragma unroll
+                for (int r = 0; r < NR; r++) {
+                    if (__builtin_amdgcn_ballot_w64(n[r] >= (uint32_t)PART_LT)) {
+                        out[r] = lcg_mul_dbl(out[r], lt1[(n[r] >> 8) & (PART_LT - 1)]);
+                        const uint32_t h = n[r] >> 16;
+                        if (h) out[r] = h < PART_LT ? lcg_mul_dbl(out[r], lt2[h]) : lcg_mul(out[r], lcg_jump2(pw, h << 16));
+                    }
+                }
             }
         }
+#if HAND_ABL == 2      /* timing-only ablation: no stores */
+        if (out[0] == 0x12345u) out_p[0] = out[1] ^ out[NR - 1];
+#else
 #pragma unroll
         for (int r = 0; r < NR; r++) if (FULL || (uint32_t)(64 * r + lane) < left) out_p[64 * r] = out[r];
+#endif
 #pragma unroll
         for (int r = 0; r < NR; r++) cur[r] = nxt[r];
         in += HAND_STEP; out_p += HAND_STEP;
