@@ -37,14 +37,11 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
         long long nfix = 0;
         if (c->cfg.mode == SQG_MODE_CERTIFIED && !slot_is_mine(c, b)) nfix = -1;   // the slot's counters belong to a later batch by now: not known
         if (c->cfg.mode == SQG_MODE_CERTIFIED && slot_is_mine(c, b)) {
-            unsigned int cnt[4] = {0, 0, 0, 0};
-            HIPCHK(c, hipMemcpy(cnt, S.d_fix_count, sizeof cnt, hipMemcpyDeviceToHost));
+            unsigned int cnt[4 + FIX_SHARDS];                // the counters and the lists' statistics in one read-back
+            const bool lists = S.d_fix_sh_count != nullptr;
+            HIPCHK(c, hipMemcpy(cnt, S.d_fix_count, (lists ? 4 + FIX_SHARDS : 4) * sizeof(unsigned int), hipMemcpyDeviceToHost));
             nfix = cnt[0];                                  // the global list ...
-            if (S.d_fix_sh_count) {                         // ... + the lean kernel's lists (a word per list, written by k_fixup)
-                unsigned int st[FIX_SHARDS];
-                HIPCHK(c, hipMemcpy(st, S.d_fix_sh_count + (size_t)FIX_SHARDS * FIX_SHARD_STRIDE, sizeof st, hipMemcpyDeviceToHost));
-                for (int i = 0; i < FIX_SHARDS; i++) nfix += st[i];
-            }
+            if (lists) for (int i = 0; i < FIX_SHARDS; i++) nfix += cnt[4 + i];   // ... + the lean kernel's lists (a word per list, written by k_fixup)
         }
         c->timing.dwell_ms = d; c->timing.samples_ms = s; c->timing.total_ms = t; c->timing.fallback_samples = nfix;
     } else if (b->wait_rc) {

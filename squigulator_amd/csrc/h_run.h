@@ -276,7 +276,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     hipStream_t tail = c->stream2;                               // the stream the batch's last kernel runs on
     if (n > 0 && b->n_chains > 0) {
         P.sig = S.d_sig; P.fix = S.d_fix; P.fix_count = S.d_fix_count;
-        P.fix_sh = S.d_fix_sh; P.fix_sh_count = S.d_fix_sh_count; P.fix_sh_stat = S.d_fix_sh_count + (size_t)FIX_SHARDS * FIX_SHARD_STRIDE; P.fix_tag = (int)(b->run_idx & 0x3fffffff) + 1;
+        P.fix_sh = S.d_fix_sh; P.fix_sh_count = S.d_fix_sh_count; P.fix_sh_stat = S.d_fix_count + 4; P.fix_tag = (int)(b->run_idx & 0x3fffffff) + 1;
         P.fix_cap = (unsigned int)std::min<size_t>(S.fix_cap, 0xffffffffu);
         const bool rna_prefix = (c->cfg.flags & SQG_RNA) && (c->cfg.flags & SQG_PREFIX);
         P.shift_len = rna_prefix ? (int)strlen(kAdaptorRna) * (int)p.dwell_mean : 0;
