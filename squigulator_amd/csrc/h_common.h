@@ -30,7 +30,8 @@ struct sqg_ctx {
         unsigned long long* d_seglen = nullptr; long long* d_sigoff = nullptr; size_t reads_cap = 0;
         FixEntry* d_fix = nullptr; size_t fix_cap = 0;
         unsigned int* d_fix_count = nullptr;       // [0] fix-up entries, [1] slow tiles, [2] entries that went through the lean kernel's lists
-        FixEntry* d_fix_sh = nullptr;              // the lean kernel's FIX_SHARDS lists of FIX_SHARD_CAP entries (64 MB)
+        FixEntry* d_fix_sh = nullptr; size_t fix_sh_cap = 0;   // the lean kernel's FIX_SHARDS lists (entries in all; sized by the batch)
+        unsigned int fix_sh_per = 0;               // ... entries per list
         unsigned int* d_fix_sh_count = nullptr;    // ... their counters, FIX_SHARD_STRIDE words apart
         uint2* d_evrec = nullptr; size_t evrec_cap = 0;
         uint32_t* d_tile_so = nullptr; size_t tile_cap = 0;

@@ -141,8 +141,6 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
         CHK(hipMalloc(&S.d_fix_count, (4 + FIX_SHARDS) * sizeof(unsigned int)));
         CHK(hipMemset(S.d_fix_count, 0, (4 + FIX_SHARDS) * sizeof(unsigned int)));
         if (cfg->mode == SQG_MODE_CERTIFIED && c->use_kmer_streams) {
-            CHK(hipMalloc(&S.d_fix_sh, (size_t)FIX_SHARDS * FIX_SHARD_CAP * sizeof(FixEntry)));
-            CHK(hipMemset(S.d_fix_sh, 0, (size_t)FIX_SHARDS * FIX_SHARD_CAP * sizeof(FixEntry)));      // (tags of no batch)
             CHK(hipMalloc(&S.d_fix_sh_count, (size_t)FIX_SHARDS * FIX_SHARD_STRIDE * sizeof(unsigned int)));          // (counters, FIX_SHARD_STRIDE words apart)
             CHK(hipMemset(S.d_fix_sh_count, 0, (size_t)FIX_SHARDS * FIX_SHARD_STRIDE * sizeof(unsigned int)));
         }

@@ -270,13 +270,24 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         if ((rc = ensure(c, (void**)&Z.d_sig, &Z.sig_cap, need_samples + 64, sizeof(int16_t)))) return rc;
         if (certified && c->use_kmer_streams) {
             if ((rc = ensure(c, (void**)&Z.d_fix, &Z.fix_cap, (c->force_fix ? need_samples : need_samples / 256) + 65536, sizeof(FixEntry)))) return rc;
+            // the lean kernel's lists: four times the undecided samples a batch of this size expects (5e-4 of its samples on the profiles
+            // measured), at least FIX_SHARD_CAP_MIN per list -- a list that is full falls back to the ONE global list, whose counter
+            // serialises the sample kernel (65536-read batches ran at 15.7 instead of 9.6 ms with lists of a fixed 2048 entries)
+            const double expect = (double)b->n_events * (std::fabs(p.dwell_mean) + 1.0) * 2.0e-3;
+            const size_t per = std::max<size_t>(FIX_SHARD_CAP_MIN, (size_t)(expect / FIX_SHARDS) + 1);
+            if (per > Z.fix_sh_per) {
+                const size_t cap0 = Z.fix_sh_cap;
+                if ((rc = ensure(c, (void**)&Z.d_fix_sh, &Z.fix_sh_cap, (size_t)FIX_SHARDS * (per + per / 4), sizeof(FixEntry)))) return rc;
+                if (Z.fix_sh_cap != cap0) HIPCHK(c, hipMemsetAsync(Z.d_fix_sh, 0, Z.fix_sh_cap * sizeof(FixEntry), c->stream));   // (tags of no batch)
+                Z.fix_sh_per = (unsigned int)std::min<size_t>(Z.fix_sh_cap / FIX_SHARDS, 0x7fffffffu);
+            }
         }
     }
 
     hipStream_t tail = c->stream2;                               // the stream the batch's last kernel runs on
     if (n > 0 && b->n_chains > 0) {
         P.sig = S.d_sig; P.fix = S.d_fix; P.fix_count = S.d_fix_count;
-        P.fix_sh = S.d_fix_sh; P.fix_sh_count = S.d_fix_sh_count; P.fix_sh_stat = S.d_fix_count + 4; P.fix_tag = (int)(b->run_idx & 0x3fffffff) + 1;
+        P.fix_sh = S.d_fix_sh; P.fix_sh_cap = S.fix_sh_per; P.fix_sh_count = S.d_fix_sh_count; P.fix_sh_stat = S.d_fix_count + 4; P.fix_tag = (int)(b->run_idx & 0x3fffffff) + 1;
         P.fix_cap = (unsigned int)std::min<size_t>(S.fix_cap, 0xffffffffu);
         const bool rna_prefix = (c->cfg.flags & SQG_RNA) && (c->cfg.flags & SQG_PREFIX);
         P.shift_len = rna_prefix ? (int)strlen(kAdaptorRna) * (int)p.dwell_mean : 0;

@@ -238,8 +238,9 @@ struct SigParams {
     FixEntry* fix;               // certified mode: undecided samples
     unsigned int* fix_count;
     unsigned int fix_cap;
-    FixEntry* fix_sh;            // ... of the lean kernel: FIX_SHARDS lists of FIX_SHARD_CAP entries (a workgroup appends to list blockIdx % FIX_SHARDS:
+    FixEntry* fix_sh;            // ... of the lean kernel: FIX_SHARDS lists of fix_sh_cap entries (a workgroup appends to list blockIdx % FIX_SHARDS:
     unsigned int* fix_sh_count;  // one returning atomic per item with undecided samples, on one of FIX_SHARDS counters 128 B apart)
+    unsigned int fix_sh_cap;     // entries per list (sized by the batch: >= FIX_SHARD_CAP_MIN, four times the fix-ups a batch of its size expects)
     unsigned int* fix_sh_stat;   // [FIX_SHARDS] entries k_fixup took from each list
     int fix_tag;                 // FixEntry.pad of this batch's entries (a list's count may include entries that went to the global list instead)
     uint2* evrec;                // per event {stream state at its first draw, k-mer rank}
@@ -289,7 +290,7 @@ struct SigParams {
 #define EVR_REL_BITS 14          // SigParams.evrec32: an event's slot within its (link, partition) -- staging keeps a link below 2^14 events --
                                  // under the 18 bits of a 9-mer rank
 #define FIX_SHARDS 1024          // (a single counter: 90 000 returning device-scope atomics per batch on one address run at ~40 ns each and
-#define FIX_SHARD_CAP 2048       // stretch the sample kernel from 2.4 to 5.8 ms: measured)
+#define FIX_SHARD_CAP_MIN 2048   // stretch the sample kernel from 2.4 to 5.8 ms: measured; a list that is full sends its items to that one list)
 #define FIX_SHARD_STRIDE 32      // words between two counters
 #define PART_SUB_BITS 12         // a partition's sub-row: 4096 streams, 16 KiB of LDS (the size of a whole 6-mer row).  (2048-stream
                                  // partitions were measured: k_part_hand runs 16 wavefronts per CU instead of 8, but the scatter's runs

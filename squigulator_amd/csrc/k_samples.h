@@ -474,8 +474,8 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
             unsigned int at0 = 0;
             if (lane == 0) at0 = atomicAdd(P.fix_sh_count + sh * FIX_SHARD_STRIDE, (unsigned int)nfix);
             at0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)at0);
-            FixEntry* dst = P.fix_sh + (size_t)sh * FIX_SHARD_CAP + at0;
-            bool room = at0 + (unsigned int)nfix <= FIX_SHARD_CAP;
+            FixEntry* dst = P.fix_sh + (size_t)sh * P.fix_sh_cap + at0;
+            bool room = at0 + (unsigned int)nfix <= P.fix_sh_cap;
             if (!room) {                                               // the list is full (forced fix-ups in tests): the global list
                 if (lane == 0) at0 = atomicAdd(P.fix_count, (unsigned int)nfix);
                 at0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)at0);
@@ -694,8 +694,8 @@ __device__ static inline void fixup_one(const SigParams& P, const FixEntry& fe) 
 // global list (the generic kernel's samples, and what did not fit a list)
 __global__ __launch_bounds__(256) void k_fixup(const SigParams P) {
     if (P.fix_sh) {
-        const unsigned int ns = min(P.fix_sh_count[blockIdx.x * FIX_SHARD_STRIDE], (unsigned int)FIX_SHARD_CAP);
-        const FixEntry* lst = P.fix_sh + (size_t)blockIdx.x * FIX_SHARD_CAP;
+        const unsigned int ns = min(P.fix_sh_count[blockIdx.x * FIX_SHARD_STRIDE], P.fix_sh_cap);
+        const FixEntry* lst = P.fix_sh + (size_t)blockIdx.x * P.fix_sh_cap;
         unsigned int mine = 0;
 #if SQG_ABL_FIXK != 1
         for (unsigned int i = threadIdx.x; i < ns; i += 256) {
