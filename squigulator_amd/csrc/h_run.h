@@ -289,6 +289,9 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         P.sig = S.d_sig; P.fix = S.d_fix; P.fix_count = S.d_fix_count;
         P.fix_sh = S.d_fix_sh; P.fix_sh_cap = S.fix_sh_per; P.fix_sh_count = S.d_fix_sh_count; P.fix_sh_stat = S.d_fix_count + 4; P.fix_tag = (int)(b->run_idx & 0x3fffffff) + 1;
         P.fix_cap = (unsigned int)std::min<size_t>(S.fix_cap, 0xffffffffu);
+        if (b->run_idx < 8 && getenv("SQG_VERBOSE"))
+            fprintf(stderr, "[sqg] batch %lld slot %d: sig %p part %p evrec %p part_state %p dwell %p bases %p seglen %p\n", (long long)b->run_idx, b->slot,
+                    (void*)S.d_sig, (void*)S.d_part, (void*)S.d_evrec, (void*)S.d_part_state, (void*)S.d_dwell, (void*)b->d_bases, (void*)S.d_seglen);
         const bool rna_prefix = (c->cfg.flags & SQG_RNA) && (c->cfg.flags & SQG_PREFIX);
         P.shift_len = rna_prefix ? (int)strlen(kAdaptorRna) * (int)p.dwell_mean : 0;
         {   // int16_t off = 30*dig/range (src/genread.c:82): double -> int16 as the CPU does it
