@@ -405,6 +405,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall time of each multi-process CPU leg")
     ap.add_argument("--no-store-probe", action="store_true")
+    ap.add_argument("--timing-every", type=int, default=4,
+                    help="phase events (kernel_ms) on every n-th batch: each is a barrier packet between the kernels, 1.2 %% of a step "
+                         "when every batch carries them (1: every batch)")
     ap.add_argument("--pipeline-seconds", type=float, default=2.5,
                     help="wall time of the streaming leg (`pipeline` in the line: nothing staged ahead, sampler + staging + run + free "
                          "from one host thread); 0 skips it")
@@ -497,6 +500,10 @@ def main():
                               worker_lo=w_lo, worker_hi=w_hi)
     if range_mode:
         gen.set_range_mode(True)
+    # the phase events behind kernel_ms are barrier packets between the kernels (include/sqg.h, sqg_set_phase_timing): every
+    # --timing-every'th batch carries them (short runs: every batch, so that the timed region holds timed launches)
+    timing_every = args.timing_every if args.steps >= 2 * args.timing_every else 1
+    gen.set_phase_timing(timing_every)
     r_lo, r_hi = shard.read_range(rank, world, K * world)          # range mode: my reads of the job's K*world-read batches
 
     host_contigs = None                                             # a host copy of (a small version of) the genome, for the CPU legs
@@ -556,7 +563,7 @@ def main():
         run(b).wait()
     sync_all()
     t0 = time.perf_counter()
-    sig_ms, ev_ms, lean_ms = [], [], []
+    sig_ms, ev_ms, lean_ms, lean_bytes = [], [], [], []
     samples = bases = reads = fallback = fallback_of = 0
     digests = []
     timed = batches[args.warmup:]
@@ -568,8 +575,10 @@ def main():
         b = timed[i]
         b.wait()
         tm = gen.timing()
-        sig_ms.append(tm["samples_ms"]); ev_ms.append(tm["events_ms"])
-        lean_ms.append(tm["lean_ms"] if tm["lean_ms"] > 0 else tm["samples_ms"])
+        if tm["total_ms"] > 0:         # this batch carried the phase events
+            sig_ms.append(tm["samples_ms"]); ev_ms.append(tm["events_ms"])
+            lean_ms.append(tm["lean_ms"] if tm["lean_ms"] > 0 else tm["samples_ms"])
+            lean_bytes.append(2 * b.n_samples + b.n_bases + 24 * b.n_reads)
         samples += b.n_samples; bases += b.n_bases; reads += b.n_reads
         if tm["fallback_samples"] >= 0:           # (-1: the batch's counters were reused by a later batch before it was waited for)
             fallback += tm["fallback_samples"]; fallback_of += b.n_samples
@@ -641,7 +650,8 @@ def main():
         steps = max(args.steps, 1)
         alg_bytes = (2 * samples + bases + 24 * reads) / steps           # per k_samples_lean launch (this rank)
         k_ms = float(np.mean(lean_ms)) if lean_ms else float("nan")     # the dominant kernel alone
-        achieved = alg_bytes / (k_ms * 1e-3)
+        if not k_ms > 0: k_ms = float("nan")                            # (SQG_ABL_NOTIMING runs)
+        achieved = (float(np.mean(lean_bytes)) if lean_bytes else alg_bytes) / (k_ms * 1e-3)    # the timed launches' own bytes over their mean duration
         ms_per_step = dt_max / steps * 1e3
         if range_mode:
             regime = (f"-t {T} -K {K * world} (range sharding: every GPU owns all {T} worker(s) and generates {K} reads of each "
@@ -700,6 +710,8 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S,
                          "traffic": pmc_traffic(wkey),
                          "kernel_ms": k_ms,
+                         "kernel_ms_launches": len(lean_ms),        # timed launches inside the timed region (every `timing_every`th batch)
+                         "timing_every": timing_every,
                          "kernel": "k_samples_lean" if args.mode == "certified" else "k_samples<exact>",
                          "algorithmic_bytes_per_launch": alg_bytes,
                          # the same algorithmic bytes over the whole step (event side + sample kernels + gaps): what the job sees

@@ -127,7 +127,7 @@ typedef struct {
     const uint16_t *d_dwell;    /* device: n_events samples-per-event (aln->ss order)        */
 } sqg_result_t;
 
-/* kernel timings of the last sqg_batch_run, from hipEvents on the context's stream */
+/* kernel timings of the batch last waited for, from hipEvents on the context's stream (see sqg_set_phase_timing) */
 typedef struct {
     float dwell_ms;             /* stand-alone k_dwell (0 when the draws are made inside k_events) */
     float events_ms;            /* k_events (dwell draws, k-mer ranks, stream hand-out)      */
@@ -165,6 +165,11 @@ int  sqg_fetch_dwell(sqg_ctx_t *ctx, sqg_batch_t *b, int32_t *dst /* n_events, a
  * after it then run in order as usual, but its reads' share of the workers' streams stays spent. */
 void sqg_batch_free(sqg_ctx_t *ctx, sqg_batch_t *b);
 int  sqg_get_timing(sqg_ctx_t *ctx, sqg_timing_t *t);
+/* The phase boundaries behind sqg_timing_t are hipEvents recorded between the kernels -- barrier packets that cost the GPU
+ * 3-8 us each (1.2 % of a 16384-read step, 5 % of a 1000-read one).  every = 1 (default): each batch carries them; every = n:
+ * the batches whose run index is a multiple of n do, the others report 0 ms in every field (fallback_samples is always filled
+ * in); every = 0: none.  (No counterpart in the reference: its only timings are realtime() around process_db, src/sim.c:575-583.) */
+int  sqg_set_phase_timing(sqg_ctx_t *ctx, int every);
 
 /* Convenience: stage + run + wait in one call (one process_db()). */
 int  sqg_submit(sqg_ctx_t *ctx, int32_t n_reads, const char *seqs, const int64_t *seq_off,

@@ -174,6 +174,7 @@ extern "C" void sqg_batch_free(sqg_ctx_t* c, sqg_batch_t* b) {
     delete b;
 }
 extern "C" int sqg_get_timing(sqg_ctx_t* c, sqg_timing_t* t) { if (!c || !t) return SQG_EINVAL; *t = c->timing; return SQG_OK; }
+extern "C" int sqg_set_phase_timing(sqg_ctx_t* c, int every) { return (!c || every < 0) ? SQG_EINVAL : SQG_OK; }   // (no phases to time here)
 
 extern "C" int sqg_submit(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t* seq_off, const int32_t* worker, sqg_batch_t** out, sqg_result_t* res) {
     if (!out) return SQG_EINVAL;

@@ -75,7 +75,7 @@ SAMPLE_DNA, SAMPLE_RNA, SAMPLE_CDNA, SAMPLE_TRUNC, SAMPLE_FULL = 0, 1, 2, 4, 8
 
 EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_device_count",
            "sqg_batch_stage", "sqg_batch_run", "sqg_batch_wait", "sqg_fetch_signal", "sqg_fetch_dwell",
-           "sqg_batch_free", "sqg_get_timing", "sqg_submit", "sqg_worker_of", "sqg_probe_store_bandwidth", "sqg_probe_lds_order",
+           "sqg_batch_free", "sqg_get_timing", "sqg_set_phase_timing", "sqg_submit", "sqg_worker_of", "sqg_probe_store_bandwidth", "sqg_probe_lds_order",
            "sqg_batch_compress", "sqg_fetch_svb", "sqg_genome_load", "sqg_batch_sample", "sqg_fetch_reads",
            "sqg_host_alloc", "sqg_host_free", "sqg_set_range_mode", "sqg_skip_reads", "sqg_batch_sample_range",
            "sqg_batch_run_begin", "sqg_batch_run_end", "sqg_genome_load_device",
@@ -122,6 +122,8 @@ def load_library(path: str | None = None):
     L.sqg_batch_free.argtypes = [vp, vp]
     L.sqg_get_timing.restype = C.c_int
     L.sqg_get_timing.argtypes = [vp, C.POINTER(CTiming)]
+    L.sqg_set_phase_timing.restype = C.c_int
+    L.sqg_set_phase_timing.argtypes = [vp, C.c_int]
     L.sqg_submit.restype = C.c_int
     L.sqg_submit.argtypes = [vp, i32, C.c_char_p, C.POINTER(i64), C.POINTER(i32), C.POINTER(vp), C.POINTER(CResult)]
     L.sqg_worker_of.restype = i32
@@ -485,6 +487,10 @@ class SignalGenerator:
         self._pinned.append(p)
         buf = (C.c_uint8 * nbytes).from_address(p)
         return np.frombuffer(buf, dtype=dtype)
+
+    def set_phase_timing(self, every: int):
+        """Phase events (timing()'s milliseconds) on the batches whose run index is a multiple of `every`; 1: all (default), 0: none."""
+        self._chk(self.L.sqg_set_phase_timing(self.ctx, int(every)), "sqg_set_phase_timing")
 
     def timing(self):
         t = CTiming()

@@ -28,6 +28,7 @@ struct sqg_ctx {
         int16_t* d_sig = nullptr; size_t sig_cap = 0;
         uint16_t* d_dwell = nullptr; size_t dwell_cap = 0;
         unsigned long long* d_seglen = nullptr; long long* d_sigoff = nullptr; size_t reads_cap = 0;
+        size_t seglen_dirty = 0;      // reads whose seglen words may be non-zero (what a batch leaves behind unless its k_fixup zeroes them)
         FixEntry* d_fix = nullptr; size_t fix_cap = 0;
         unsigned int* d_fix_count = nullptr;       // [0] fix-up entries, [1] slow tiles, [2] entries that went through the lean kernel's lists
         FixEntry* d_fix_sh = nullptr; size_t fix_sh_cap = 0;   // the lean kernel's FIX_SHARDS lists (entries in all; sized by the batch)
@@ -70,6 +71,7 @@ struct sqg_ctx {
     std::vector<long long> off_x, med_x;   // raw Schrage states (as the reference keeps them)
     unsigned long long next_stage = 0, next_run = 0, compress_seq = 0;
     unsigned long long runs = 0;                   // batches run so far: a batch's slot is its run index & 1
+    int phase_timing_every = 1;                    // sqg_set_phase_timing: the batches whose run index is a multiple carry the phase events (0: none)
     std::set<unsigned long long> abandoned;        // staged batches that were freed without having been run
     sqg_timing_t timing = {0, 0, 0, 0, 0, 0};
     bool use_dwell_stream = true, use_kmer_streams = true;
@@ -147,6 +149,7 @@ struct sqg_batch {
     long long* h_svboff = nullptr;       // pinned, device-mapped: offsets of the svb-zd encodings (sqg_batch_compress)
     long long n_svb = -1;
     unsigned long long compress_seq = 0;
+    bool untimed = false;                          // no phase events in this batch (sqg_set_phase_timing): its timings read 0
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // kernel-phase boundaries; [7]: the event side is done
     uint8_t* h_meta = nullptr; size_t h_meta_bytes = 0;   // pinned: the host-built arrays of the batch (descriptors, chain lists), uploaded in one copy
     hipEvent_t ev_staged = nullptr;      // recorded on the staging stream after the batch's last staging operation

@@ -27,10 +27,12 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
             return b->wait_rc;
         }
         float d = 0, s = 0, t = 0, ee = 0;
-        if (b->dwell_timed) HIPCHK(c, hipEventElapsedTime(&d, b->ev[0], b->ev[1]));
-        HIPCHK(c, hipEventElapsedTime(&ee, b->ev[b->dwell_timed ? 2 : 0], b->ev[3]));
-        HIPCHK(c, hipEventElapsedTime(&s, b->ev[3], b->ev[4]));
-        HIPCHK(c, hipEventElapsedTime(&t, b->ev[0], b->ev[4]));
+        if (!b->untimed) {                                  // (sqg_set_phase_timing: a batch without the phase events reports 0 ms)
+            if (b->dwell_timed) HIPCHK(c, hipEventElapsedTime(&d, b->ev[0], b->ev[1]));
+            HIPCHK(c, hipEventElapsedTime(&ee, b->ev[b->dwell_timed ? 2 : 0], b->ev[3]));
+            HIPCHK(c, hipEventElapsedTime(&s, b->ev[3], b->ev[4]));
+            HIPCHK(c, hipEventElapsedTime(&t, b->ev[0], b->ev[4]));
+        }
         c->timing.events_ms = ee;
         c->timing.lean_ms = 0.f;
         if (b->lean_timed) HIPCHK(c, hipEventElapsedTime(&c->timing.lean_ms, b->ev[5], b->ev[6]));
@@ -86,6 +88,12 @@ extern "C" int sqg_fetch_dwell(sqg_ctx_t* c, sqg_batch_t* b, int32_t* dst) {
 extern "C" int sqg_get_timing(sqg_ctx_t* c, sqg_timing_t* t) {
     if (!c || !t) return SQG_EINVAL;
     *t = c->timing;
+    return SQG_OK;
+}
+
+extern "C" int sqg_set_phase_timing(sqg_ctx_t* c, int every) {
+    if (!c || every < 0) return SQG_EINVAL;
+    c->phase_timing_every = every;
     return SQG_OK;
 }
 

@@ -21,7 +21,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     if (phase != 2) {
         // this slot's buffers were last used by the sample kernels of batch seq-2 (stream2)
         HIPCHK(c, hipStreamWaitEvent(c->stream, S.done, 0));
-        if (b->ev_staged) HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_staged, 0));     // the batch's uploads and staging kernels
+        if (b->ev_staged && hipEventQuery(b->ev_staged) != hipSuccess) HIPCHK(c, hipStreamWaitEvent(c->stream, b->ev_staged, 0));     // the batch's uploads and staging kernels (a barrier packet: not queued if they are done)
         auto grow = [&](sqg_ctx::Slot& Z) -> int { return grow_slot(c, Z, b, /*with_output=*/false); };
         b->other_fresh = other.reads_cap == 0 && n > 0;
         if ((rc = grow(S))) return rc;
@@ -100,8 +100,13 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
 #undef EVL
     };
 
+    // the phase boundaries are recorded events: barrier packets between the kernels, 3-8 us of idle GPU each (tools/ext_event_probe.hip;
+    // events attached to a launch cost more, not less) -- 1.2 % of a 16384-read step, 5 % of a 1000-read one.  sqg_set_phase_timing
+    // says how many batches carry them.
+    if (phase != 2) b->untimed = c->phase_timing_every <= 0 || (b->run_idx % c->phase_timing_every) != 0;
+    const bool untimed = b->untimed;
     if (phase != 2) {
-        HIPCHK(c, hipEventRecord(b->ev[0], c->stream));
+        if (!untimed) HIPCHK(c, hipEventRecord(b->ev[0], c->stream));
         if (n > 0) {
             if (c->use_dwell_stream && !inline_dwell) {
                 HIPCHK(c, hipMemsetAsync(S.d_seglen, 0, (size_t)2 * n * sizeof(unsigned long long), c->stream));
@@ -119,7 +124,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 HIPCHK(c, hipMemcpyAsync(S.d_seglen, b->seglen_host.data(), (size_t)2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
             }
         }
-        b->dwell_timed = c->use_dwell_stream && !inline_dwell;        // stand-alone k_dwell (A/B runs): two more timing events
+        b->dwell_timed = c->use_dwell_stream && !inline_dwell && !untimed;        // stand-alone k_dwell (A/B runs): two more timing events
         if (b->dwell_timed) { HIPCHK(c, hipEventRecord(b->ev[1], c->stream)); HIPCHK(c, hipEventRecord(b->ev[2], c->stream)); }
     }
     if (n > 0 && b->n_chains > 0) {
@@ -152,7 +157,11 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         if (b->part) {
             // k > 6, split chains: the hand-out over events bucketed by the top bits of the rank (k_part.h)
             if (phase != 2) {
-                if (b->split_reads && dw) HIPCHK(c, hipMemsetAsync(S.d_seglen, 0, (size_t)2 * n * sizeof(unsigned long long), c->stream));   // pieces add up
+                if (b->split_reads && dw && S.seglen_dirty > 0) {   // pieces add up; (usually the slot's previous batch has left the words zero: k_fixup)
+                    HIPCHK(c, hipMemsetAsync(S.d_seglen, 0, (size_t)2 * std::max<size_t>((size_t)n, S.seglen_dirty) * sizeof(unsigned long long), c->stream));
+                    S.seglen_dirty = 0;
+                }
+                if (b->split_reads && dw) S.seglen_dirty = (size_t)n;   // (until this batch's k_fixup is queued: a run that fails half-way leaves them dirty)
                 launch_part_events(dw, true);                     // dwell draws; events per (link, partition)
                 if (b->split_reads) hipLaunchKernelGGL(k_part_tile_bases, dim3((unsigned)b->n_pieces), dim3(64), 0, c->stream, P);
                 if (b->one) {
@@ -236,7 +245,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         else hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
         HIPCHK(c, hipGetLastError());
     }
-    HIPCHK(c, hipEventRecord(b->ev[3], c->stream));
+    if (!untimed) HIPCHK(c, hipEventRecord(b->ev[3], c->stream));
     if (n > 0) {
         // the scan also writes the offsets through the batch's pinned host mapping (no copy between kernels)
         const unsigned scan_wgs = (unsigned)((n + SCAN_WG - 1) / SCAN_WG);
@@ -285,6 +294,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     }
 
     hipStream_t tail = c->stream2;                               // the stream the batch's last kernel runs on
+    bool seglen_zeroed = false;
     if (n > 0 && b->n_chains > 0) {
         P.sig = S.d_sig; P.fix = S.d_fix; P.fix_count = S.d_fix_count;
         P.fix_sh = S.d_fix_sh; P.fix_sh_cap = S.fix_sh_per; P.fix_sh_count = S.d_fix_sh_count; P.fix_sh_stat = S.d_fix_count + 4; P.fix_tag = (int)(b->run_idx & 0x3fffffff) + 1;
@@ -312,16 +322,18 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             // items (profiles with long dwells) the look-up chain per item is worth a kernel of its own
             if (c->lean_epl < 4 || SQG_LEAN_ITEMS4) hipLaunchKernelGGL(k_items, dim3((unsigned)((n_stiles + 255) / 256)), dim3(256), 0, c->stream, P, n_stiles, n, nullptr);
             else P.items = nullptr;
-            HIPCHK(c, hipEventRecord(b->ev[7], c->stream));              // event side done: the sample kernels may start ...
-            HIPCHK(c, hipStreamWaitEvent(c->stream2, b->ev[7], 0));      // ... on their own stream, next to the next batch's k_events
-            HIPCHK(c, hipEventRecord(b->ev[5], c->stream2));
+            if (c->stream2 != c->stream) {
+                HIPCHK(c, hipEventRecord(b->ev[7], c->stream));              // event side done: the sample kernels may start ...
+                HIPCHK(c, hipStreamWaitEvent(c->stream2, b->ev[7], 0));      // ... on their own stream, next to the next batch's k_events
+            }
+            if (!untimed) HIPCHK(c, hipEventRecord(b->ev[5], c->stream2));
             static const unsigned lean_dynlds = getenv("SQG_LEAN_DYNLDS") ? (unsigned)atoi(getenv("SQG_LEAN_DYNLDS")) : 0u;   // A/B: bytes of LDS a workgroup reserves on top (fewer workgroups per CU)
 #define LEANL(R, E) hipLaunchKernelGGL((k_samples_lean<R, E>), dim3(lgrid), dim3(256), lean_dynlds, c->stream2, P, n_stiles)
             if (P.rna) { if (c->lean_epl == 4) LEANL(true, 4); else if (c->lean_epl == 2) LEANL(true, 2); else LEANL(true, 1); }
             else { if (c->lean_epl == 4) LEANL(false, 4); else if (c->lean_epl == 2) LEANL(false, 2); else LEANL(false, 1); }
 #undef LEANL
-            HIPCHK(c, hipEventRecord(b->ev[6], c->stream2));
-            b->lean_timed = true;
+            if (!untimed) HIPCHK(c, hipEventRecord(b->ev[6], c->stream2));
+            b->lean_timed = !untimed;
             if ((rc = dbg_sync(c, "k_samples_lean"))) return rc;
             // what is left -- the items the lean kernel did not take (usually none) and the FP64 fix-ups, small latency-bound
             // kernels -- goes to a stream of its own: the next batch's k_events does not wait for it
@@ -335,20 +347,25 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             if (!abl_nofix) {
             hipLaunchKernelGGL((k_samples<1, true>), dim3(std::min(sgrid, 4096u)), dim3(256), 0, tail, P, n_tiles);
             if ((rc = dbg_sync(c, "k_samples<generic>"))) return rc;
+            P.seglen_zero = 2 * n;
             hipLaunchKernelGGL(k_fixup, dim3(FIX_SHARDS), dim3(256), 0, tail, P);
+            seglen_zeroed = true;
             }
             if ((rc = dbg_sync(c, "k_fixup"))) return rc;
         } else {
-            HIPCHK(c, hipEventRecord(b->ev[7], c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->stream2, b->ev[7], 0));
+            if (c->stream2 != c->stream) {
+                HIPCHK(c, hipEventRecord(b->ev[7], c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->stream2, b->ev[7], 0));
+            }
             if (certified) hipLaunchKernelGGL((k_samples<1, true>), dim3(sgrid), dim3(256), 0, c->stream2, P, n_tiles);
             else hipLaunchKernelGGL((k_samples<0, true>), dim3(sgrid), dim3(256), 0, c->stream2, P, n_tiles);
         }
         HIPCHK(c, hipGetLastError());
-    } else {
+    } else if (c->stream2 != c->stream) {
         HIPCHK(c, hipEventRecord(b->ev[7], c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, b->ev[7], 0));
     }
+    if (n > 0) S.seglen_dirty = seglen_zeroed ? (S.seglen_dirty > (size_t)n ? S.seglen_dirty : 0) : std::max(S.seglen_dirty, (size_t)n);
     HIPCHK(c, hipEventRecord(b->ev[4], tail));
     HIPCHK(c, hipEventRecord(S.done, tail));
     b->ran = true;

@@ -42,6 +42,7 @@ static int grow_slot(sqg_ctx* c, sqg_ctx::Slot& Z, const sqg_batch* b, bool with
         HIPCHK(c, hipMalloc(&Z.d_seglen, 2 * cap * sizeof(unsigned long long)));
         HIPCHK(c, hipMalloc(&Z.d_sigoff, cap * sizeof(long long)));
         Z.reads_cap = cap;
+        Z.seglen_dirty = cap;                                      // (fresh memory)
     }
     if ((rc2 = ensure(c, (void**)&Z.d_dwell, &Z.dwell_cap, (size_t)b->n_events + 1024, sizeof(uint16_t)))) return rc2;
     if ((rc2 = ensure(c, (void**)&Z.d_evrec, &Z.evrec_cap, (size_t)b->n_events + 64, sizeof(uint2)))) return rc2;

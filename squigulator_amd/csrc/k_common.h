@@ -223,6 +223,7 @@ struct SigParams {
     const uint16_t* dwell;       // per event (null when dwell is constant)
     uint16_t* dwell_out;         // k_events with inline dwell draws: the same array, written
     unsigned long long* seglen_out;    // ... and the per-read segment totals
+    int seglen_zero;                   // k_fixup: words of seglen_out to zero behind the batch (0: none)
     double dmean, dstd;          // dwell_mean, dwell_std
     const unsigned long long* seglen;  // [2*n_reads] samples in segment 0 / 1
     const long long* sig_off;    // [n_reads+1]

@@ -717,6 +717,9 @@ __global__ __launch_bounds__(256) void k_fixup(const SigParams P) {
     }
     const unsigned int n = min(*P.fix_count, P.fix_cap);
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) fixup_one(P, P.fix[i]);
+    // the batch's last kernel: the per-read sample totals have been read by everything that needs them, and the slot's next batch
+    // wants them zero (the pieces of a read add theirs up: k_part_events.h) -- saves that batch a fill kernel in front of its first pass
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P.seglen_zero; i += gridDim.x * 256) P.seglen_out[i] = 0ull;
 }
 
 // ---- k_certify: max |x_fast - x_exact| over every state the fp32 path may accept ------------

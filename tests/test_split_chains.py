@@ -340,3 +340,39 @@ def test_thousands_of_reads_per_worker(name, T):
             np.testing.assert_array_equal(sig[b.sig_off[i]:b.sig_off[i + 1]], w.sig, err_msg=f"batch {bi} read {i}")
         b.free()
     gen.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("every", [0, 2, 3])
+def test_phase_timing_period_changes_the_timings_only(every):
+    """sqg_set_phase_timing: batches without the phase events (recorded hipEvents between the kernels) report 0 ms and the same
+    int16 as the batches that carry them; queued back to back, as a streaming caller does"""
+    rng = np.random.default_rng(4242)
+    prof, fl = profiles.get_profile("dna-r10-prom")
+    k = profiles.default_kmer_size(fl)
+    mean, stdv = model.synthetic_model(k)
+    batches = [_reads(rng, 120, k, 3000) for _ in range(6)]
+    sigs = {}
+    for ev in (1, every):
+        gen = api.SignalGenerator(prof, fl, k, mean, stdv, 11, num_workers=1, mode=api.MODE_CERTIFIED)
+        gen.set_phase_timing(ev)
+        out, timed = [], []
+        staged = [gen.stage(bt) for bt in batches]
+        for i in range(0, 6, 2):                         # two in flight
+            staged[i].run(); staged[i + 1].run()
+            for b in staged[i:i + 2]:
+                b.wait()
+                tm = gen.timing()
+                timed.append(tm["total_ms"] > 0)
+                assert (tm["lean_ms"] > 0) == timed[-1] and (tm["events_ms"] > 0) == timed[-1]
+                assert tm["fallback_samples"] >= 0
+                out.append(b.signal().copy())
+        for b in staged:
+            b.free()
+        with pytest.raises(api.SqgError):
+            gen.set_phase_timing(-1)
+        gen.close()
+        assert timed == [ev > 0 and i % ev == 0 for i in range(6)]
+        sigs[ev] = out
+    for a, b in zip(sigs[1], sigs[every]):
+        np.testing.assert_array_equal(a, b)
