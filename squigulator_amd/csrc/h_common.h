@@ -71,6 +71,7 @@ struct sqg_ctx {
     std::vector<long long> off_x, med_x;   // raw Schrage states (as the reference keeps them)
     unsigned long long next_stage = 0, next_run = 0, compress_seq = 0;
     unsigned long long runs = 0;                   // batches run so far: a batch's slot is its run index & 1
+    unsigned int* d_mid_done = nullptr;            // k_part_mid: offsets workgroups that have finished (the last one resets it)
     int phase_timing_every = 1;                    // sqg_set_phase_timing: the batches whose run index is a multiple carry the phase events (0: none)
     std::set<unsigned long long> abandoned;        // staged batches that were freed without having been run
     sqg_timing_t timing = {0, 0, 0, 0, 0, 0};

@@ -37,7 +37,7 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->fix_stream) (void)hipStreamSynchronize(ctx->fix_stream);
     (void)hipFree(ctx->d_pcnt); (void)hipFree(ctx->d_slice); (void)hipFree(ctx->d_phist);
-    (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_scan_part); (void)hipFree(ctx->d_xcounts); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_samp_scratch); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err);
+    (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_scan_part); (void)hipFree(ctx->d_xcounts); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_samp_scratch); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err); (void)hipFree(ctx->d_mid_done);
     for (auto& S : ctx->slot) {
         (void)hipFree(S.d_sig); (void)hipFree(S.d_dwell); (void)hipFree(S.d_seglen); (void)hipFree(S.d_sigoff);
         (void)hipFree(S.d_fix); (void)hipFree(S.d_fix_count); (void)hipFree(S.d_fix_sh); (void)hipFree(S.d_fix_sh_count);
@@ -124,6 +124,8 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     CHK(hipMalloc(&c->d_pow, pw.size() * sizeof(uint32_t)));
     CHK(hipMemcpy(c->d_pow, pw.data(), pw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     CHK(hipMalloc(&c->d_err, sizeof(unsigned int)));
+    CHK(hipMalloc(&c->d_mid_done, sizeof(unsigned int)));
+    CHK(hipMemset(c->d_mid_done, 0, sizeof(unsigned int)));
     CHK(hipMemset(c->d_err, 0, sizeof(unsigned int)));
     CHK(hipStreamCreateWithFlags(&c->stage_stream, hipStreamNonBlocking));
     // SQG_OVERLAP=1: the sample kernels get their own stream, so that the event kernels of the next batch run next to

@@ -163,18 +163,26 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 }
                 if (b->split_reads && dw) S.seglen_dirty = (size_t)n;   // (until this batch's k_fixup is queued: a run that fails half-way leaves them dirty)
                 launch_part_events(dw, true);                     // dwell draws; events per (link, partition)
-                if (b->split_reads) hipLaunchKernelGGL(k_part_tile_bases, dim3((unsigned)b->n_pieces), dim3(64), 0, c->stream, P);
+                static const bool mid_split = getenv("SQG_MID_SPLIT") != nullptr;   // A/B: the four small kernels between the passes, one by one
+                if (b->split_reads && (b->one || mid_split)) hipLaunchKernelGGL(k_part_tile_bases, dim3((unsigned)b->n_pieces), dim3(64), 0, c->stream, P);
                 if (b->one) {
                     // one partition: the pass above has written part[] in chain order; the slices of every worker chain's events
-                    hipLaunchKernelGGL(k_part_slices, dim3(1), dim3(1024), 0, c->stream, pstart, b->d_wchain_total, (int)n_pairs, b->slice_len, pfirst);
-                    hipLaunchKernelGGL(k_part_slice_bounds, dim3((pgrid + 255) / 256), dim3(256), 0, c->stream, pstart, b->d_wchain_total, (int)n_pairs, b->slice_len, pfirst, slice_lo, slice_hi);
+                    hipLaunchKernelGGL(k_part_slices, dim3(1), dim3(1024), 0, c->stream, pstart, b->d_wchain_total, (int)n_pairs, b->slice_len, pfirst, slice_lo, slice_hi);
                     HIPCHK(c, hipGetLastError());
                     if ((rc = dbg_sync(c, "k_part_events<one>/k_part_slices"))) return rc;
                 } else {
-                    hipLaunchKernelGGL(k_part_offsets, dim3((unsigned)n_part, (unsigned)b->n_wchains), dim3(1024), 0, c->stream, c->d_pcnt,
-                                       c->d_pcnt + (size_t)b->n_chains * n_part, n_part, b->n_chains, b->d_wlink_off, ptotal);
-                    hipLaunchKernelGGL(k_part_slices, dim3(1), dim3(1024), 0, c->stream, pstart, ptotal, (int)n_pairs, b->slice_len, pfirst);
-                    hipLaunchKernelGGL(k_part_slice_bounds, dim3((pgrid + 255) / 256), dim3(256), 0, c->stream, pstart, ptotal, (int)n_pairs, b->slice_len, pfirst, slice_lo, slice_hi);
+                    if (mid_split) {
+                        hipLaunchKernelGGL(k_part_offsets, dim3((unsigned)n_part, (unsigned)b->n_wchains), dim3(1024), 0, c->stream, c->d_pcnt,
+                                           c->d_pcnt + (size_t)b->n_chains * n_part, n_part, b->n_chains, b->d_wlink_off, ptotal);
+                        hipLaunchKernelGGL(k_part_slices, dim3(1), dim3(1024), 0, c->stream, pstart, ptotal, (int)n_pairs, b->slice_len, pfirst, nullptr, nullptr);
+                        hipLaunchKernelGGL(k_part_slice_bounds, dim3((pgrid + 255) / 256), dim3(256), 0, c->stream, pstart, ptotal, (int)n_pairs, b->slice_len, pfirst, slice_lo, slice_hi);
+                    } else {
+                        // offsets per (partition, worker chain), the tile offsets of split reads, the slices and their bounds: one launch
+                        const int n_off = (int)n_pairs, n_pc = b->split_reads ? b->n_pieces : 0;
+                        hipLaunchKernelGGL(k_part_mid, dim3((unsigned)(n_off + (n_pc + 15) / 16)), dim3(1024), 0, c->stream, P, c->d_pcnt,
+                                           c->d_pcnt + (size_t)b->n_chains * n_part, n_part, b->n_chains, b->d_wlink_off, ptotal, pstart, (int)n_pairs, b->slice_len,
+                                           pfirst, slice_lo, slice_hi, n_off, n_pc, c->d_mid_done);
+                    }
                     HIPCHK(c, hipGetLastError());
                     if ((rc = dbg_sync(c, "k_events<count>/k_part_offsets"))) return rc;
                     launch_part_events(0, false);                 // every event to its slot (the dwell is in memory now)
@@ -191,7 +199,9 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             if (phase != 1) {
 #define SCANL(R_, G_) hipLaunchKernelGGL((k_part_scan<R_, G_>), dim3((unsigned)((c->num_kmer + R_ - 1) / R_), (unsigned)b->n_wchains), dim3(R_ * G_), 0, c->stream, \
                                         c->d_phist, c->d_rows, c->num_kmer, n_part, pfirst, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, direct ? 1 : 0, b->d_err)
+                static const int scan_g4 = getenv("SQG_SCAN_G4") ? atoi(getenv("SQG_SCAN_G4")) : 32;   // A/B knob
                 if ((long long)b->max_slices <= 8 * (long long)n_pairs) SCANL(256, 1);       // a slice or two per pair: one thread per rank walks them
+                else if ((long long)b->max_slices <= scan_g4 * (long long)n_pairs && (size_t)pg.x * pg.y >= 512) SCANL(64, 4);   // a dozen (small batches): 16 runs would be 16 x the wavefronts, most of them idle
                 else if ((size_t)pg.x * pg.y >= 512) SCANL(64, 16);
                 else SCANL(16, 64);
 #undef SCANL

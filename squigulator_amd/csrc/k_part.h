@@ -25,10 +25,10 @@
 // grid (partitions, worker chains), 1024 threads, each with a run of consecutive links of the chain.
 //   wlink_off[q]..wlink_off[q+1]   the links of worker chain q, in chain order
 // poff[l][p] <- the chain's events of partition p before link l; ptotal[q][p] <- all of them
-__global__ __launch_bounds__(1024) void k_part_offsets(const uint32_t* __restrict__ pcnt, uint32_t* __restrict__ poff, const int n_part, const int n_links,
-                                                       const int* __restrict__ wlink_off, uint32_t* __restrict__ ptotal) {
+__device__ static inline void part_offsets_body(const int p, const int q, const uint32_t* __restrict__ pcnt, uint32_t* __restrict__ poff, const int n_part,
+                                                const int n_links, const int* __restrict__ wlink_off, uint32_t* __restrict__ ptotal) {
     __shared__ uint32_t wsum[16];
-    const int p = blockIdx.x, q = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l0 = wlink_off[q], l1 = wlink_off[q + 1];
     const int per = (l1 - l0 + 1023) / 1024, la = min(l0 + tid * per, l1), lb = min(la + per, l1);
     uint32_t own = 0;                                             // my links' events of partition p
@@ -47,14 +47,20 @@ __global__ __launch_bounds__(1024) void k_part_offsets(const uint32_t* __restric
     }
     if (tid == 0) ptotal[(size_t)q * n_part + p] = total;
 }
+__global__ __launch_bounds__(1024) void k_part_offsets(const uint32_t* __restrict__ pcnt, uint32_t* __restrict__ poff, const int n_part, const int n_links,
+                                                       const int* __restrict__ wlink_off, uint32_t* __restrict__ ptotal) {
+    part_offsets_body(blockIdx.x, blockIdx.y, pcnt, poff, n_part, n_links, wlink_off, ptotal);
+}
 
 // The events of a (worker chain, partition) lie in part[] in the order the chain produces them; the hand-out walks them in that
 // order, and any cut of the run is as good as any other: it is cut into SLICES of slice_len events (the last one shorter), so
 // that a partition with many events (k-mers of poly-A tails, adaptors, satellite repeats) is simply more slices, not a longer one.
 // One workgroup: pstart[pair] <- the pair's first slot in part[] (pair = chain * n_part + partition: part[] is chain-major, then
 // partition-major), pfirst[pair] <- its first slice (pfirst[n_pairs] = number of slices); k_part_slice_bounds: the slots of slice s.  The host sized the tables for n_events / slice_len + n_pairs slices.
-__global__ __launch_bounds__(1024) void k_part_slices(uint32_t* __restrict__ pstart, const uint32_t* __restrict__ ptotal, const int n_pairs,
-                                                      const uint32_t slice_len, uint32_t* __restrict__ pfirst) {
+// (ptotal is read with agent-scope loads: in k_part_mid other workgroups of the same launch have written it)
+__device__ static inline uint32_t ptotal_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ static inline void part_slices_body(uint32_t* __restrict__ pstart, const uint32_t* ptotal, const int n_pairs,
+                                               const uint32_t slice_len, uint32_t* __restrict__ pfirst) {
     __shared__ uint32_t wsum[16], wtot[16];
     __shared__ uint32_t carry, carry_ev;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(1024) void k_part_slices(uint32_t* __restrict__ pst
     __syncthreads();
     for (int base = 0; base < n_pairs; base += 1024) {
         const int i = base + tid;
-        const uint32_t tot = i < n_pairs ? ptotal[i] : 0u;
+        const uint32_t tot = i < n_pairs ? ptotal_load(ptotal + i) : 0u;
         const uint32_t ns = (tot + slice_len - 1) / slice_len;
         const uint32_t incl = (uint32_t)wave_incl_scan_dpp((int)ns), incl_ev = (uint32_t)wave_incl_scan_dpp((int)tot);
         if (lane == 63) { wsum[wid] = incl; wtot[wid] = incl_ev; }
@@ -77,18 +83,32 @@ __global__ __launch_bounds__(1024) void k_part_slices(uint32_t* __restrict__ pst
     }
     if (tid == 0) pfirst[n_pairs] = carry;
 }
+// slice s: the pair it belongs to by bisection of pfirst, then its slots
+__device__ static inline void part_slice_bounds_one(const uint32_t s, const uint32_t* pstart, const uint32_t* ptotal, const int n_pairs,
+                                                    const uint32_t slice_len, const uint32_t* pfirst, uint32_t* __restrict__ slice_lo, uint32_t* __restrict__ slice_hi) {
+    int lo = 0, hi = n_pairs;                                      // the last pair with pfirst <= s (pairs without events share their successor's)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pfirst[mid] <= s) lo = mid; else hi = mid; }
+    const uint32_t k = s - pfirst[lo], st = pstart[lo];
+    slice_lo[s] = st + k * slice_len;
+    slice_hi[s] = st + min((k + 1) * slice_len, ptotal_load(ptotal + lo));
+}
+// One workgroup; with slice_lo given it goes on to the slices' bounds (what k_part_slice_bounds does with a thread per slice)
+__global__ __launch_bounds__(1024) void k_part_slices(uint32_t* pstart, const uint32_t* ptotal, const int n_pairs,
+                                                      const uint32_t slice_len, uint32_t* pfirst, uint32_t* slice_lo, uint32_t* slice_hi) {
+    part_slices_body(pstart, ptotal, n_pairs, slice_len, pfirst);
+    if (!slice_lo) return;
+    __syncthreads();                                               // (the workgroup's own stores: visible to it behind the barrier)
+    const uint32_t ns = pfirst[n_pairs];
+    for (uint32_t s = threadIdx.x; s < ns; s += 1024) part_slice_bounds_one(s, pstart, ptotal, n_pairs, slice_len, pfirst, slice_lo, slice_hi);
+}
 
-// one thread per slice (the host's bound): the pair it belongs to by bisection of pfirst, then its slots
+// one thread per slice (the host's bound)
 __global__ __launch_bounds__(256) void k_part_slice_bounds(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ ptotal, const int n_pairs,
                                                            const uint32_t slice_len, const uint32_t* __restrict__ pfirst,
                                                            uint32_t* __restrict__ slice_lo, uint32_t* __restrict__ slice_hi) {
     const uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s >= pfirst[n_pairs]) return;
-    int lo = 0, hi = n_pairs;                                      // the last pair with pfirst <= s (pairs without events share their successor's)
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pfirst[mid] <= s) lo = mid; else hi = mid; }
-    const uint32_t k = s - pfirst[lo], st = pstart[lo];
-    slice_lo[s] = st + k * slice_len;
-    slice_hi[s] = st + min((k + 1) * slice_len, ptotal[lo]);
+    part_slice_bounds_one(s, pstart, ptotal, n_pairs, slice_len, pfirst, slice_lo, slice_hi);
 }
 
 // grid: slices (the host's bound; the live ones are pfirst[n_pairs]), 256 threads.  phist[s][sub] <- samples the slice's events draw from the stream

@@ -345,8 +345,7 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
 // Reads cut into several pieces: the first pass wrote every piece's tile offsets relative to the piece's own first sample; the pieces
 // behind a read's first get the samples of the pieces before them added.  A read's pieces are consecutive in P.pieces.
 // grid: pieces, 64 threads.
-__global__ __launch_bounds__(64) void k_part_tile_bases(const SigParams P) {
-    const int pi = blockIdx.x;
+__device__ static inline void part_tile_bases_body(const SigParams& P, const int pi, const int lane) {
     const int4 pc = P.pieces[pi];
     if (pc.y == 0) return;
     uint32_t base = 0;
@@ -357,5 +356,35 @@ __global__ __launch_bounds__(64) void k_part_tile_bases(const SigParams P) {
         if (o.y == 0) break;
     }
     const ReadDesc rd = P.reads[pc.x];
-    for (int t = (pc.y >> 6) + (int)threadIdx.x; t < (pc.z + 63) >> 6; t += 64) P.tile_so[rd.tile_off + t] += base;
+    for (int t = (pc.y >> 6) + lane; t < (pc.z + 63) >> 6; t += 64) P.tile_so[rd.tile_off + t] += base;
+}
+__global__ __launch_bounds__(64) void k_part_tile_bases(const SigParams P) { part_tile_bases_body(P, blockIdx.x, threadIdx.x); }
+
+// What lies between the two event passes in ONE launch (each of the four kernels it replaces is a few microseconds of work behind
+// a launch: 25 us of a 1000-read batch's 360): workgroups [0, n_off) do k_part_offsets' (partition, worker chain) pairs, the
+// ones behind them k_part_tile_bases' pieces (a wavefront each); the offsets workgroup that finishes LAST -- a counter, agent-scope
+// release / acquire: the others' totals are then visible to it -- goes on to k_part_slices and the slices' bounds.
+__global__ __launch_bounds__(1024) void k_part_mid(const SigParams P, const uint32_t* __restrict__ pcnt, uint32_t* __restrict__ poff, const int n_part, const int n_links,
+                                                   const int* __restrict__ wlink_off, uint32_t* ptotal, uint32_t* pstart, const int n_pairs, const uint32_t slice_len,
+                                                   uint32_t* pfirst, uint32_t* slice_lo, uint32_t* slice_hi, const int n_off, const int n_pieces, unsigned int* done) {
+    __shared__ int last;
+    const int g = blockIdx.x;
+    if (g >= n_off) {
+        const int pi = (g - n_off) * 16 + (int)(threadIdx.x >> 6);
+        if (pi < n_pieces) part_tile_bases_body(P, pi, threadIdx.x & 63);
+        return;
+    }
+    part_offsets_body(g % n_part, g / n_part, pcnt, poff, n_part, n_links, wlink_off, ptotal);
+    __syncthreads();                                               // (thread 0 has stored the pair's total)
+    if (threadIdx.x == 0) {
+        const unsigned int before = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = before + 1u == (unsigned int)n_off;
+        if (last) __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (for the next launch: the stream orders them)
+    }
+    __syncthreads();
+    if (!last) return;
+    part_slices_body(pstart, ptotal, n_pairs, slice_len, pfirst);
+    __syncthreads();
+    const uint32_t ns = pfirst[n_pairs];
+    for (uint32_t s = threadIdx.x; s < ns; s += 1024) part_slice_bounds_one(s, pstart, ptotal, n_pairs, slice_len, pfirst, slice_lo, slice_hi);
 }
