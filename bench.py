@@ -405,9 +405,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall time of each multi-process CPU leg")
     ap.add_argument("--no-store-probe", action="store_true")
-    ap.add_argument("--timing-every", type=int, default=4,
+    ap.add_argument("--timing-every", type=int, default=3,
                     help="phase events (kernel_ms) on every n-th batch: each is a barrier packet between the kernels, 1.2 %% of a step "
-                         "when every batch carries them (1: every batch)")
+                         "when every batch carries them (1: every batch; odd: the timed launches alternate between the context's two slots)")
     ap.add_argument("--pipeline-seconds", type=float, default=2.5,
                     help="wall time of the streaming leg (`pipeline` in the line: nothing staged ahead, sampler + staging + run + free "
                          "from one host thread); 0 skips it")

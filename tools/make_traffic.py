@@ -16,7 +16,8 @@ if key is None:                                            # the workload key of
     for ln in open(os.path.join(src, "trace.log")):
         if ln.startswith('{"metric"'):
             key = json.loads(ln)["roofline"]["workload_key"]
-rnd = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+_m = __import__("re").search(r"r(\d+)$", os.path.basename(dst))
+rnd = int(sys.argv[4]) if len(sys.argv) > 4 else int(_m.group(1)) if _m else None          # profiles/r03 -> 3
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f, name in (("pmc4", "FETCH_SIZE"), ("pmc5", "WRITE_SIZE")):
     path = os.path.join(src, f + "_counter_collection.csv")
