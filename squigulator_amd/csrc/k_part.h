@@ -27,23 +27,40 @@
 // poff[l][p] <- the chain's events of partition p before link l; ptotal[q][p] <- all of them
 __device__ static inline void part_offsets_body(const int p, const int q, const uint32_t* __restrict__ pcnt, uint32_t* __restrict__ poff, const int n_part,
                                                 const int n_links, const int* __restrict__ wlink_off, uint32_t* __restrict__ ptotal) {
+    // An exclusive scan over the chain's links, 64 consecutive links per wavefront and step (whole lines in, whole lines out: with a
+    // run of consecutive links per THREAD -- 22 of them at 22000 links per batch -- every load and store instruction touched 64 lines:
+    // 25 us for 1.4 M words), a wavefront's steps four at a time (their loads in flight together).
     __shared__ uint32_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int l0 = wlink_off[q], l1 = wlink_off[q + 1];
-    const int per = (l1 - l0 + 1023) / 1024, la = min(l0 + tid * per, l1), lb = min(la + per, l1);
-    uint32_t own = 0;                                             // my links' events of partition p
-    pcnt += (size_t)p * n_links; poff += (size_t)p * n_links;     // (partition-major: a thread's links are consecutive words)
-    for (int l = la; l < lb; l++) own += pcnt[l];
-    const uint32_t incl = (uint32_t)wave_incl_scan_dpp((int)own);
-    if (lane == 63) wsum[wid] = incl;
+    const int chunk = (((l1 - l0 + 15) >> 4) + 63) & ~63;         // links per wavefront
+    const int wa = min(l0 + wid * chunk, l1), wb = min(wa + chunk, l1);
+    pcnt += (size_t)p * n_links; poff += (size_t)p * n_links;     // (partition-major)
+    uint32_t own = 0;
+    for (int base = wa; base < wb; base += 256) {
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = pcnt[min(base + 64 * j + lane, n_links - 1)];   // (unconditional: a conditional load is waited for before the next is issued)
+#pragma unroll
+        for (int j = 0; j < 4; j++) own += base + 64 * j + lane < wb ? v[j] : 0u;
+    }
+    for (int o = 32; o > 0; o >>= 1) own += (uint32_t)__shfl_xor((int)own, o);
+    if (lane == 0) wsum[wid] = own;
     __syncthreads();
-    uint32_t before = 0, total = 0;
-    for (int w = 0; w < 16; w++) { if (w < wid) before += wsum[w]; total += wsum[w]; }
-    uint32_t at = before + incl - own;
-    for (int l = la; l < lb; l++) {
-        const uint32_t cnt = pcnt[l];
-        poff[l] = at;
-        at += cnt;
+    uint32_t carry = 0, total = 0;
+    for (int w = 0; w < 16; w++) { if (w < wid) carry += wsum[w]; total += wsum[w]; }
+    for (int base = wa; base < wb; base += 256) {
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = pcnt[min(base + 64 * j + lane, n_links - 1)];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int l = base + 64 * j + lane;
+            const uint32_t cnt = l < wb ? v[j] : 0u;
+            const uint32_t incl = (uint32_t)wave_incl_scan_dpp((int)cnt);
+            if (l < wb) poff[l] = carry + incl - cnt;
+            carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
     }
     if (tid == 0) ptotal[(size_t)q * n_part + p] = total;
 }
@@ -92,14 +109,34 @@ __device__ static inline void part_slice_bounds_one(const uint32_t s, const uint
     slice_lo[s] = st + k * slice_len;
     slice_hi[s] = st + min((k + 1) * slice_len, ptotal_load(ptotal + lo));
 }
+// the bounds of all slices by the one workgroup that has just written pfirst / pstart (part_slices_body): few pairs (one worker chain
+// of 9-mers: 64): the tables in LDS, the bisection there
+#define PART_BOUNDS_LDS 1024
+__device__ static inline void part_slice_bounds_wg(const uint32_t* pstart, const uint32_t* ptotal, const int n_pairs, const uint32_t slice_len,
+                                                   const uint32_t* pfirst, uint32_t* __restrict__ slice_lo, uint32_t* __restrict__ slice_hi) {
+    __shared__ uint32_t s_first[PART_BOUNDS_LDS + 1], s_start[PART_BOUNDS_LDS], s_total[PART_BOUNDS_LDS];
+    __syncthreads();                                               // (the workgroup's own stores: visible to it behind the barrier)
+    const uint32_t ns = pfirst[n_pairs];
+    if (n_pairs > PART_BOUNDS_LDS) {
+        for (uint32_t s = threadIdx.x; s < ns; s += 1024) part_slice_bounds_one(s, pstart, ptotal, n_pairs, slice_len, pfirst, slice_lo, slice_hi);
+        return;
+    }
+    for (int i = threadIdx.x; i < n_pairs; i += 1024) { s_first[i] = pfirst[i]; s_start[i] = pstart[i]; s_total[i] = ptotal_load(ptotal + i); }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < ns; s += 1024) {
+        int lo = 0, hi = n_pairs;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_first[mid] <= s) lo = mid; else hi = mid; }
+        const uint32_t k = s - s_first[lo], st = s_start[lo];
+        slice_lo[s] = st + k * slice_len;
+        slice_hi[s] = st + min((k + 1) * slice_len, s_total[lo]);
+    }
+}
 // One workgroup; with slice_lo given it goes on to the slices' bounds (what k_part_slice_bounds does with a thread per slice)
 __global__ __launch_bounds__(1024) void k_part_slices(uint32_t* pstart, const uint32_t* ptotal, const int n_pairs,
                                                       const uint32_t slice_len, uint32_t* pfirst, uint32_t* slice_lo, uint32_t* slice_hi) {
     part_slices_body(pstart, ptotal, n_pairs, slice_len, pfirst);
     if (!slice_lo) return;
-    __syncthreads();                                               // (the workgroup's own stores: visible to it behind the barrier)
-    const uint32_t ns = pfirst[n_pairs];
-    for (uint32_t s = threadIdx.x; s < ns; s += 1024) part_slice_bounds_one(s, pstart, ptotal, n_pairs, slice_len, pfirst, slice_lo, slice_hi);
+    part_slice_bounds_wg(pstart, ptotal, n_pairs, slice_len, pfirst, slice_lo, slice_hi);
 }
 
 // one thread per slice (the host's bound)

@@ -384,7 +384,5 @@ __global__ __launch_bounds__(1024) void k_part_mid(const SigParams P, const uint
     __syncthreads();
     if (!last) return;
     part_slices_body(pstart, ptotal, n_pairs, slice_len, pfirst);
-    __syncthreads();
-    const uint32_t ns = pfirst[n_pairs];
-    for (uint32_t s = threadIdx.x; s < ns; s += 1024) part_slice_bounds_one(s, pstart, ptotal, n_pairs, slice_len, pfirst, slice_lo, slice_hi);
+    part_slice_bounds_wg(pstart, ptotal, n_pairs, slice_len, pfirst, slice_lo, slice_hi);
 }
