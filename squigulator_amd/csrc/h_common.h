@@ -8,16 +8,66 @@ static uint32_t lcg_pow(uint32_t base, unsigned long long e) {
     return r;
 }
 
+// A few helper threads that live as long as the context (staging shares the per-read libm draws of a batch with them): starting a
+// thread costs 0.4 ms in the containers this runs in -- a third of the work it would take over -- waking a sleeping one less.
+struct HostPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv, done_cv;
+    std::vector<std::function<void()>> jobs;       // not yet taken
+    int pending = 0;                               // taken or not, not yet finished
+    bool stop = false;
+    void worker() {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [&] { return stop || !jobs.empty(); });
+            if (stop) return;
+            std::function<void()> job = std::move(jobs.back());
+            jobs.pop_back();
+            lk.unlock();
+            job();
+            lk.lock();
+            if (--pending == 0) done_cv.notify_all();
+        }
+    }
+    // hands `js` to the helpers (started on first use, as many as the largest request so far) and returns; wait() blocks until they are done
+    void post(std::vector<std::function<void()>> js) {
+        std::unique_lock<std::mutex> lk(m);
+        while (th.size() < js.size()) th.emplace_back([this] { worker(); });
+        pending += (int)js.size();
+        for (auto& j : js) jobs.push_back(std::move(j));
+        lk.unlock();
+        cv.notify_all();
+    }
+    void wait() { std::unique_lock<std::mutex> lk(m); done_cv.wait(lk, [&] { return pending == 0; }); }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 struct sqg_ctx {
+    HostPool pool_threads;
     sqg_cfg_t cfg;
     int k = 0, num_kmer = 0, T = 0, wlo = 0, whi = 0, nw = 0;
     hipStream_t stream = nullptr;
     uint32_t* d_rows = nullptr;
     float2* d_model = nullptr;
     uint32_t* d_pow = nullptr;
+    std::vector<uint32_t> h_pow;                   // the jump tables on the host (staging: a worker's time stream moves past a read's events)
+    // a^(2n) from three table look-ups (k_common.h: lcg_jump2) -- square-and-multiply took 100 ns of staging's 140 per read
+    uint32_t jump2(unsigned long long n) const {
+        if (n >> 32) return lcg_pow(lcg_mul(LCG_A, LCG_A), n);
+        uint32_t r = h_pow[2 * POW_N + (size_t)(n & (POW_N - 1))];
+        const uint32_t hi = (uint32_t)(n >> 10) & (POW_N - 1), hi2 = (uint32_t)(n >> 20);
+        if (hi) r = lcg_mul(r, h_pow[3 * POW_N + hi]);
+        if (hi2) r = lcg_mul(r, h_pow[4 * POW_N + hi2]);
+        return r;
+    }
     unsigned int* d_err = nullptr;                 // the read sampler's error word (sqg_batch_sample* read and clear it synchronously);
                                                    // the kernels of a batch report into the batch's own word
     unsigned long long scan_tickets = 0;           // k_scan launches so far: every launch gets a ticket of its own

@@ -123,6 +123,7 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     }
     CHK(hipMalloc(&c->d_pow, pw.size() * sizeof(uint32_t)));
     CHK(hipMemcpy(c->d_pow, pw.data(), pw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->h_pow = pw;
     CHK(hipMalloc(&c->d_err, sizeof(unsigned int)));
     CHK(hipMalloc(&c->d_mid_done, sizeof(unsigned int)));
     CHK(hipMemset(c->d_mid_done, 0, sizeof(unsigned int)));

@@ -105,7 +105,7 @@ static void skip_read(sqg_ctx* c, int w, long long n_events) {
         (void)host_nrng(p.median_before_mean, p.median_before_std, &c->med_x[(size_t)w]);
     }
     if (c->use_dwell_stream)
-        c->time_c[(size_t)w] = lcg_mul(c->time_c[(size_t)w], lcg_pow(lcg_mul(LCG_A, LCG_A), (unsigned long long)n_events));
+        c->time_c[(size_t)w] = lcg_mul(c->time_c[(size_t)w], c->jump2((unsigned long long)n_events));
 }
 
 extern "C" int sqg_skip_reads(sqg_ctx_t* c, int32_t n, const int64_t* seq_len, const int32_t* worker) {

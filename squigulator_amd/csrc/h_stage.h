@@ -320,45 +320,79 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         for (int q = 0; q < b->n_chains; q++) chain_order[(size_t)cnt[(size_t)cls(chain_ev[(size_t)q])]++] = q;
     }
 
-    const uint32_t a2 = lcg_mul(LCG_A, LCG_A);
     const bool no_lean = getenv("SQG_TEST_NO_LEAN") != nullptr;
     // the workers' scalar streams advance below; a staging that fails afterwards (allocation) puts them back
     const std::vector<uint32_t> snap_time = c->time_c;
     const std::vector<long long> snap_off = c->off_x, snap_med = c->med_x;
-    // the per-read scalar draws (host libm, so that `offset` / `median_before` are the doubles the CPU reference prints):
-    // chains are independent, a few host threads share them
-    auto chain_range = [&](int q_lo, int q_hi) {
-        for (int q = q_lo; q < q_hi; q++)
-            for (int ci = wchain_off[(size_t)q]; ci < wchain_off[(size_t)q + 1]; ci++) {   // batch order within the worker
-                const int i = chain_reads[(size_t)ci];
-                ReadDesc& d = rd[(size_t)i];
-                const size_t w = (size_t)d.worker;
-                if (c->cfg.flags & SQG_IDEAL) {                   // src/gensig.c:311-313
-                    d.offset = p.offset_mean; b->median[(size_t)i] = p.median_before_mean;
-                } else {                                          // src/gensig.c:315-316
-                    d.offset = host_nrng(p.offset_mean, p.offset_std, &c->off_x[w]);
-                    b->median[(size_t)i] = host_nrng(p.median_before_mean, p.median_before_std, &c->med_x[w]);
-                }
-                b->offset[(size_t)i] = d.offset;
-                d.fast = (c->cfg.mode == SQG_MODE_CERTIFIED && c->use_kmer_streams && c->dwell_hi <= (double)MULT_N && !no_lean &&
-                          c->amp_floor - d.offset > 4.0 && c->amp_ceil - d.offset < 65000.0) ? 1 : 0;
-                d.time_c0 = c->time_c[w];
-                if (c->use_dwell_stream)                          // two draws per event (src/gensig.c:255)
-                    c->time_c[w] = lcg_mul(c->time_c[w], lcg_pow(a2, (unsigned long long)(d.ne0 + d.ne1)));
+    // the per-read scalar draws (host libm, so that `offset` / `median_before` are the doubles the CPU reference prints): 2 x 16384
+    // log / sqrt / cos per batch, 0.8 ms on one thread.  chain_reads[] lists the reads worker chain by worker chain, in batch order
+    // within a chain; the helper threads of the context take ranges [lo, hi) of it and leave the draws in two compact arrays (they
+    // touch nothing else: the descriptors sit in this thread's cache).  A range that starts in the middle of a chain starts from the
+    // chain's streams moved past the reads before it: two steps of each per read (src/rand.h:87-94: nrng draws two uniforms, neither
+    // can be 0).  The streams themselves, the time stream and the descriptors are left to this thread.
+    const bool ideal = (c->cfg.flags & SQG_IDEAL) != 0;
+    std::vector<double> off_d, med_d;                              // by position in chain_reads
+    std::vector<int> rd_worker;                                    // ... and the worker of the read at that position
+    auto draw_range = [&](const int lo, const int hi) {
+        int ci = lo;
+        while (ci < hi) {
+            const size_t w = (size_t)rd_worker[(size_t)ci];
+            const int q = chain_of[w], c_lo = wchain_off[(size_t)q], c_hi = wchain_off[(size_t)q + 1];
+            long long off = snap_off[w], med = snap_med[w];
+            if (ci > c_lo) {
+                const uint32_t j = c->jump2((unsigned long long)(ci - c_lo));
+                off = (long long)lcg_mul(canon(off), j); med = (long long)lcg_mul(canon(med), j);
             }
+            const int stop = std::min(hi, c_hi);
+            for (; ci < stop; ci++) {
+                off_d[(size_t)ci] = host_nrng(p.offset_mean, p.offset_std, &off);                     // src/gensig.c:315
+                med_d[(size_t)ci] = host_nrng(p.median_before_mean, p.median_before_std, &med);       // src/gensig.c:316
+            }
+        }
     };
-    {
-        // (starting a thread costs about as much as the draws of 300 reads)
-        const int want = n_wchains >= 16384 ? 8 : n_wchains >= 6144 ? 4 : n_wchains >= 3072 ? 2 : 1;
-        const int nth = (int)std::min<unsigned>((unsigned)want, std::max(1u, std::thread::hardware_concurrency()));
-        if (nth <= 1) chain_range(0, n_wchains);
-        else {
-            std::vector<std::thread> th;
-            const int per = (n_wchains + nth - 1) / nth;
-            for (int t = 0; t < nth; t++) th.emplace_back(chain_range, std::min(t * per, n_wchains), std::min((t + 1) * per, n_wchains));
-            for (auto& t : th) t.join();
+    static const int forced_th = getenv("SQG_STAGE_THREADS") ? atoi(getenv("SQG_STAGE_THREADS")) : 0;   // A/B knob, tests
+    // (measured, 16384 reads per batch: 1.30 ms on one thread, 1.10 with two, 0.93 with four, 0.88 with six -- the helpers sleep for
+    // milliseconds between two batches and wake slowly)
+    const int want_th = ideal ? 1 : forced_th > 0 ? forced_th : n >= 8192 ? 4 : 1;
+    const int nth = (int)std::min<unsigned>((unsigned)std::min(want_th, std::max(n, 1)), std::max(1u, std::thread::hardware_concurrency()));
+    if (nth > 1) {
+        off_d.resize((size_t)n); med_d.resize((size_t)n); rd_worker.resize((size_t)n);
+        for (int ci = 0; ci < n; ci++) rd_worker[(size_t)ci] = rd[(size_t)chain_reads[(size_t)ci]].worker;
+        std::vector<std::function<void()>> jobs;
+        const int per = (n + nth - 1) / nth;
+        for (int t = 1; t < nth; t++) jobs.push_back([&, t] { draw_range(std::min(t * per, n), std::min((t + 1) * per, n)); });
+        c->pool_threads.post(std::move(jobs));
+        draw_range(0, std::min(per, n));
+        c->pool_threads.wait();
+    }
+    for (int q = 0; q < n_wchains; q++) {
+        const size_t w = (size_t)rd[(size_t)chain_reads[(size_t)wchain_off[(size_t)q]]].worker;
+        uint32_t tc = c->time_c[w];
+        for (int ci = wchain_off[(size_t)q]; ci < wchain_off[(size_t)q + 1]; ci++) {   // batch order within the worker
+            const int i = chain_reads[(size_t)ci];
+            ReadDesc& d = rd[(size_t)i];
+            if (ideal) {                                          // src/gensig.c:311-313
+                d.offset = p.offset_mean; b->median[(size_t)i] = p.median_before_mean;
+            } else if (nth > 1) {
+                d.offset = off_d[(size_t)ci]; b->median[(size_t)i] = med_d[(size_t)ci];
+            } else {                                              // src/gensig.c:315-316
+                d.offset = host_nrng(p.offset_mean, p.offset_std, &c->off_x[w]);
+                b->median[(size_t)i] = host_nrng(p.median_before_mean, p.median_before_std, &c->med_x[w]);
+            }
+            b->offset[(size_t)i] = d.offset;
+            d.fast = (c->cfg.mode == SQG_MODE_CERTIFIED && c->use_kmer_streams && c->dwell_hi <= (double)MULT_N && !no_lean &&
+                      c->amp_floor - d.offset > 4.0 && c->amp_ceil - d.offset < 65000.0) ? 1 : 0;
+            d.time_c0 = tc;
+            if (c->use_dwell_stream)                              // two draws per event (src/gensig.c:255)
+                tc = lcg_mul(tc, c->jump2((unsigned long long)(d.ne0 + d.ne1)));
+        }
+        c->time_c[w] = tc;
+        if (nth > 1) {                                            // the streams behind the chain's reads
+            const uint32_t j = c->jump2((unsigned long long)(wchain_off[(size_t)q + 1] - wchain_off[(size_t)q]));
+            c->off_x[w] = (long long)lcg_mul(canon(c->off_x[w]), j); c->med_x[w] = (long long)lcg_mul(canon(c->med_x[w]), j);
         }
     }
+    st_mark("per-read draws");
     if (!c->use_dwell_stream) {                           // constant dwell: lengths are known now
         const unsigned long long sps = (unsigned long long)(int)p.dwell_mean;
         b->seglen_host.resize((size_t)2 * n);

@@ -317,12 +317,15 @@ def test_every_batch_samples_the_lane_order_and_fails_loudly(name, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,T", [("dna-r9-prom", 1), ("dna-r10-prom", 3), ("dna-r9-prom", 4)])
-def test_thousands_of_reads_per_worker(name, T):
+@pytest.mark.parametrize("threads", [None, "2", "3", "7"])
+@pytest.mark.parametrize("name,T", [("dna-r9-prom", 1), ("dna-r10-prom", 3), ("dna-r9-prom", 4), ("rna004-prom", 2)])
+def test_thousands_of_reads_per_worker(name, T, threads, monkeypatch):
     """>= 4096 reads on <= 4 workers, two batches (carried streams): `offset`, `median_before` and every sample equal the oracle's serial
-    walk.  (Staging such a chain's per-read draws by blocks on several host threads -- every block's streams started by jump-ahead, a
-    read takes a fixed number of draws from each -- passes this test too and was measured: 4.4 instead of 3.1 ms of host time per
-    16384-read batch in this container, eight thread starts cost more than the draws; not taken.)"""
+    walk -- also when the per-read draws of staging are shared by the context's helper threads (from 8192 reads per batch on;
+    SQG_STAGE_THREADS forces it): a thread's range of the reads starts in the middle of a worker's chain, from the chain's streams moved past the reads before it
+    (a read takes a fixed number of draws from each)."""
+    if threads:
+        monkeypatch.setenv("SQG_STAGE_THREADS", threads)
     rng = np.random.default_rng(4242 + T)
     prof, fl = profiles.get_profile(name)
     k = profiles.default_kmer_size(fl)
