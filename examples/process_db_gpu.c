@@ -39,6 +39,8 @@ int main(int argc, char **argv) {
     sqg_ctx_t *ctx = NULL;
     int rc = sqg_create(&cfg, &ctx);
     if (rc) die(NULL, "sqg_create", rc);
+    /* this host never asks for sqg_get_timing: no phase events between the kernels (a few microseconds of idle GPU each) */
+    if ((rc = sqg_set_phase_timing(ctx, 0))) die(ctx, "sqg_set_phase_timing", rc);
 
     /* a 50-kb toy contig kept on the device; reads are drawn there as gen_read() would (src/genread.c:243-281) */
     const int glen = 50000;
