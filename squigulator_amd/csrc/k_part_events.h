@@ -36,6 +36,9 @@
 #ifndef PEV_PACK_SUMS
 #define PEV_PACK_SUMS 1                  // two tile sums per DPP scan (A/B)
 #endif
+#ifndef PEV_SCATTER_FASTRANK
+#define PEV_SCATTER_FASTRANK 0          // A/B: the scatter pass with the per-segment test of the rank look-up as well
+#endif
 #define PEV_HALO 24                      // bases behind the segment's own: 2 (k - 1) <= 16 (the k-mers of the RNA stall start k - 1 bases further on)
 #define PEV_WORDS ((PEV_SEG + PEV_HALO) / 16 + 2)
 
@@ -55,13 +58,22 @@ struct PevWave {
 };
 template <bool SCATTER>
 struct PevLds {
-    uint32_t jump[256];                  // a^(2j)
+    uint32_t jump[256];                  // 2 * a^(2j)
     uint8_t lut[256];                    // base -> 2-bit code (src/seq.h:14-27)
     PevWave<SCATTER> w[SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES];
 };
 
 // sum over the wavefront, in every lane's SGPR-to-be
 __device__ static inline int pev_wave_sum(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_dpp(v), 63); }
+// four of them, step by step side by side: a DPP step reads the register the step before wrote, which costs the chain two idle
+// cycles per step -- the other three chains fill them
+__device__ static inline void pev_wave_sum4(int (&v)[4]) {
+#define PEV_DPP_STEP(ctrl_, rows_) _Pragma("unroll") for (int i = 0; i < 4; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], ctrl_, rows_, 0xf, false);
+    PEV_DPP_STEP(0x111, 0xf) PEV_DPP_STEP(0x112, 0xf) PEV_DPP_STEP(0x114, 0xf) PEV_DPP_STEP(0x118, 0xf) PEV_DPP_STEP(0x142, 0xa) PEV_DPP_STEP(0x143, 0xc)
+#undef PEV_DPP_STEP
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = __builtin_amdgcn_readlane(v[i], 63);
+}
 
 // DW as in k_events: 0 = dwell from memory (or constant), 1 = drawn here, certified fp32 path, 2 = drawn here in FP64.
 // grid: ceil(links / waves per workgroup).  dump: first of 64 slots behind part[]'s last (a flush without a line writes there)
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
     static_assert(!SCATTER || DW == 0, "the second pass reads the dwells the first one drew");
     __shared__ PevLds<SCATTER> L;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int i = tid; i < 256; i += 64 * NWV) { L.jump[i] = P.pw[2 * POW_N + i]; L.lut[i] = (uint8_t)base_code((uint8_t)i); }
+    for (int i = tid; i < 256; i += 64 * NWV) { L.jump[i] = P.pw[2 * POW_N + i] << 1; L.lut[i] = (uint8_t)base_code((uint8_t)i); }   // (doubled: lcg_mul_dbl)
     __syncthreads();
     const int li = blockIdx.x * NWV + wid;
     if (li >= n_links) return;                                    // (no barrier below)
@@ -195,12 +207,25 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
             asm volatile("" ::: "memory");
             // ---- ranks
             uint32_t rank[PEV_EPL];
+            // (wave-uniform) does the read's second part -- the RNA stall behind the adaptor -- start inside this segment?  Else event j's
+            // k-mer starts at base j of the segment: word and shift depend on (q, lane) alone and cost the segment nothing (with the
+            // test per event: 9 of the pass's 60 VALU instructions per event)
+            const bool straddle = (SCATTER && !PEV_SCATTER_FASTRANK) || (rd.ne1 > 0 && s0 < rd.ne0 && s0 + PEV_SEG > rd.ne0);   // (the scatter pass is not short of VALU cycles, and the second copy of the loop costs it 15 registers)
+            if (!straddle) {
 #pragma unroll
-            for (int q = 0; q < PEV_EPL; q++) {
-                const int j = 64 * q + lane;
-                const int cb = j + ((!second && s0 + j >= rd.ne0) ? shift1 : 0);
-                const uint32_t hi = W.codes[cb >> 4], lo = W.codes[(cb >> 4) + 1];
-                rank[q] = (uint32_t)(((unsigned long long)hi << 32 | lo) >> (64 - 2 * (cb & 15) - 2 * k)) & kmask;
+                for (int q = 0; q < PEV_EPL; q++) {
+                    const int cb = 64 * q + lane;
+                    const uint32_t hi = W.codes[cb >> 4], lo = W.codes[(cb >> 4) + 1];
+                    rank[q] = (uint32_t)(((unsigned long long)hi << 32 | lo) >> (64 - 2 * (cb & 15) - 2 * k)) & kmask;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < PEV_EPL; q++) {
+                    const int j = 64 * q + lane;
+                    const int cb = j + ((!second && s0 + j >= rd.ne0) ? shift1 : 0);
+                    const uint32_t hi = W.codes[cb >> 4], lo = W.codes[(cb >> 4) + 1];
+                    rank[q] = (uint32_t)(((unsigned long long)hi << 32 | lo) >> (64 - 2 * (cb & 15) - 2 * k)) & kmask;
+                }
             }
             // ---- dwells
             uint32_t c_blk[PEV_EPL / 4];                              // ... at the segment's 256th, 512th, ... event (scalar)
@@ -213,7 +238,7 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
                 const bool valid = PEV_IN(j);
                 if (DW != 0 && valid) {
                     // event s0 + j uses draws 2j+1, 2j+2 of the time stream after the segment's first state
-                    const uint32_t c1 = lcg_mul(c_blk[q >> 2], L.jump[64 * (q & 3) + lane]);
+                    const uint32_t c1 = lcg_mul_dbl(c_blk[q >> 2], L.jump[64 * (q & 3) + lane]);
                     bool decided = false;
                     int v = 0;
                     if (DW == 1) {
@@ -225,9 +250,14 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
                     }
                     if (!decided) v = dwell_exact(c1, P.dstd, P.dmean);      // src/gensig.c:255
                     v = max(v, 1 - v);                                       // src/gensig.c:256
-                    if (P.dwell_unbounded && v > 65535) { atomicOr(P.err, 1u); v = 65535; }
                     sps[q] = v;
                     P.dwell_out[rd.ev_off + s0 + j] = (uint16_t)v;
+                }
+            }
+            if (DW != 0 && P.dwell_unbounded) {                    // (wave-uniform, rare profile: dwells beyond 16 bits are reported and clamped: a test per segment, not per draw)
+#pragma unroll
+                for (int q = 0; q < PEV_EPL; q++) {
+                    if (PEV_IN(64 * q + lane) && sps[q] > 65535) { atomicOr(P.err, 1u); sps[q] = 65535; P.dwell_out[rd.ev_off + s0 + 64 * q + lane] = (uint16_t)65535; }
                 }
             }
             if (DW) c_seg = (uint32_t)__builtin_amdgcn_readfirstlane((int)lcg_mul(c_seg, a2seg));
@@ -237,11 +267,13 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
                 // while 64 dwells fit 16 bits: 7 of the pass's 69 instructions per event)
                 uint32_t tsum[PEV_EPL];
                 if (PEV_PACK_SUMS && P.dwell_pack) {
+                    static_assert(PEV_EPL == 8, "four packed sums");
+                    int two[4];
 #pragma unroll
-                    for (int q = 0; q < PEV_EPL; q += 2) {
-                        const uint32_t two = (uint32_t)pev_wave_sum((int)((uint32_t)sps[q] | ((uint32_t)sps[q + 1] << 16)));
-                        tsum[q] = two & 0xffffu; tsum[q + 1] = two >> 16;
-                    }
+                    for (int h = 0; h < 4; h++) two[h] = (int)((uint32_t)sps[2 * h] | ((uint32_t)sps[2 * h + 1] << 16));
+                    pev_wave_sum4(two);
+#pragma unroll
+                    for (int h = 0; h < 4; h++) { tsum[2 * h] = (uint32_t)two[h] & 0xffffu; tsum[2 * h + 1] = (uint32_t)two[h] >> 16; }
                 } else {
 #pragma unroll
                     for (int q = 0; q < PEV_EPL; q++) tsum[q] = (uint32_t)pev_wave_sum(sps[q]);
