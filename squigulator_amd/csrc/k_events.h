@@ -323,7 +323,7 @@ struct EvLds {
     uint2 pbase[PART ? (NT / 64) * PART_MAX : 1];   // per (wavefront, partition), scatter pass: {slot, position in the segment's
                                                     // partition-sorted order} of the wavefront's first event of the partition
     uint2 sorted[PART ? SEG : 1];            // the segment's events in partition-sorted order: {slot, record}
-    uint32_t jump[EV_JUMP_N];   // a^(2j), j < EV_JUMP_N
+    uint32_t jump[EV_JUMP_N];   // 2 * a^(2j), j < EV_JUMP_N
     uint8_t codes[SEG + EV_HALO + 4];  // 2-bit base codes of the segment
     uint8_t lut[256];           // base -> 2-bit code (src/seq.h:14-27)
     int wsum[NT / 64];
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
     __shared__ long long n1_sh;
     constexpr int NW = NT / 64, SEG = NT * EPT, HT = 2 * SEG, TL = 64 / EPT;   // TL: lanes per 64-event tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int i = tid; i < EV_JUMP_N; i += NT) L.jump[i] = P.pw[2 * POW_N + i];
+    for (int i = tid; i < EV_JUMP_N; i += NT) L.jump[i] = P.pw[2 * POW_N + i] << 1;   // (doubled: lcg_mul_dbl, two instructions less per product)
     for (int i = tid; i < 256; i += NT) L.lut[i] = (uint8_t)(P.meth ? meth_code((uint8_t)i) : base_code((uint8_t)i));
 
     const int chain = P.chain_order[blockIdx.x];
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
                     uint32_t cs = c_seg_hi[0];
 #pragma unroll
                     for (int h2 = 1; h2 < ID_HI; h2++) cs = (id_ / EV_JUMP_N == h2) ? c_seg_hi[h2] : cs;
-                    const uint32_t c1 = lcg_mul(cs, L.jump[id_ % EV_JUMP_N]);
+                    const uint32_t c1 = lcg_mul_dbl(cs, L.jump[id_ % EV_JUMP_N]);
                     bool decided = false;
                     int v = 0;
                     if (DW == 1) {
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
                             const uint32_t n_old = atomicAdd(&row[rank[q]], total[q]);
                             const unsigned long long sv = (unsigned long long)seed_w + rank[q];
                             uint32_t cb = (uint32_t)(sv >= LCG_M ? sv - LCG_M : sv);
-                            if (n_old) cb = lcg_mul(cb, n_old < EV_JUMP_N ? L.jump[n_old] : lcg_jump2(P.pw, n_old));
+                            if (n_old) cb = lcg_mul_dbl(cb, n_old < EV_JUMP_N ? L.jump[n_old] : lcg_jump2(P.pw, n_old) << 1);
                             c_row[q] = cb;
                             L.st[id] = cb;
                         }
@@ -651,11 +651,11 @@ __global__ __launch_bounds__(NT, (NT > 256 ? 4 : SQG_EVENT_WAVES)) void k_events
                     if (EV_IN(e0 + q)) {
                         if (DIRECT) {
                             const uint32_t n = first[q] ? total[q] : prior[q];                  // > 0: every event has >= 1 sample
-                            const uint32_t m = lcg_mul(c_row[q], n < EV_JUMP_N ? L.jump[n] : lcg_jump2(P.pw, n));
+                            const uint32_t m = lcg_mul_dbl(c_row[q], n < EV_JUMP_N ? L.jump[n] : lcg_jump2(P.pw, n) << 1);
                             if (first[q]) { c_ev[q] = c_row[q]; L.row[rank[q]] = m; }
                             else c_ev[q] = m;
                         } else if (first[q]) c_ev[q] = c_row[q];
-                        else c_ev[q] = lcg_mul(L.st[fid[q]], prior[q] < EV_JUMP_N ? L.jump[prior[q]] : lcg_jump2(P.pw, prior[q]));
+                        else c_ev[q] = lcg_mul_dbl(L.st[fid[q]], prior[q] < EV_JUMP_N ? L.jump[prior[q]] : lcg_jump2(P.pw, prior[q]) << 1);
                     }
                 }
             }
