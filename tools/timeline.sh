@@ -3,7 +3,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/timeline
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT -o tl -- python $GRAFT_REPO_ROOT/bench.py ${TL_LIB:+--lib $TL_LIB} --steps 3 --warmup 1 --no-cpu-baseline --no-store-probe "$@" > $OUT/tl.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT -o tl -- python $GRAFT_REPO_ROOT/bench.py ${TL_LIB:+--lib $TL_LIB} --steps 3 --warmup 1 --no-cpu-baseline --no-store-probe "$@" > $OUT/tl.log 2>&1
 python - <<PY
 import csv, glob
 rows = []
