@@ -8,16 +8,16 @@ cd /tmp && export TMPDIR=/tmp
 BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-store-probe --pipeline-seconds 0 $*"
 # the stats pass runs the bench exactly as the driver does (defaults; CPU legs included): its kernel averages are the ones
 # the bench line's roofline.kernel_ms has to agree with
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python $GRAFT_REPO_ROOT/bench.py $* > $OUT/trace.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT -o pmc1 -- $BENCH > $OUT/pmc1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $OUT -o pmc2 -- $BENCH > $OUT/pmc2.log 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM --kernel-trace --output-format csv -d $OUT -o pmc3 -- $BENCH > $OUT/pmc3.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python $GRAFT_REPO_ROOT/bench.py $* > $OUT/trace.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --kernel-trace --output-format csv -d $OUT -o pmc1 -- $BENCH > $OUT/pmc1.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $OUT -o pmc2 -- $BENCH > $OUT/pmc2.log 2>&1
+timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM --kernel-trace --output-format csv -d $OUT -o pmc3 -- $BENCH > $OUT/pmc3.log 2>&1
 ls -R $OUT | head -30
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in their own passes (TCC slots); the WRITE pass also runs the
 # bench's store probe (k_store_probe writes a known 1 GiB per launch) to calibrate WRITE_SIZE units
 BENCH2="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --pipeline-seconds 0 $*"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o pmc4 -- $BENCH2 > $OUT/pmc4.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o pmc5 -- $BENCH2 > $OUT/pmc5.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o pmc4 -- $BENCH2 > $OUT/pmc4.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o pmc5 -- $BENCH2 > $OUT/pmc5.log 2>&1
 # condense on the box (the raw traces of a default run -- timed steps + the streaming leg -- exceed what gpurun brings back):
 # $OUT/summary/<name>_{summary.md,kernel_stats.csv,traffic.json,bench_under_rocprof.json}; the big CSVs are dropped
 NAME=$(basename $OUT)

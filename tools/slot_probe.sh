@@ -3,7 +3,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/slot_probe
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-SQG_VERBOSE=1 rocprofv3 --kernel-trace --output-format csv -d $OUT -o sp -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-store-probe --pipeline-seconds 0 "$@" > $OUT/sp.log 2>&1
+SQG_VERBOSE=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o sp -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-store-probe --pipeline-seconds 0 "$@" > $OUT/sp.log 2>&1
 grep "\[sqg\] batch" $OUT/sp.log
 python - <<PY
 import csv, glob, collections
