@@ -382,6 +382,63 @@ def pipeline_leg(stage_one, run, n_batches):
     return samples, reads, dt, t_stage / max(n_batches, 1)
 
 
+def e2e_legs(gen, prof, flags, sample_batch, reads_per_batch, seconds):
+    """The other half of work_per_single_read / output_db (src/sim.c:602-611,630-641): what a host that drains the results gets
+    (SURVEY.md 8d / H5).  Three legs, one host thread each, batch i+1 sampled + staged + queued before batch i is consumed:
+    `pinned_int16` -- sqg_fetch_signal into sqg_host_alloc memory (raw int16 over PCIe); `pinned_svb` -- sqg_batch_compress (svb-zd on
+    the device, the signal field of a BLOW5 record) + sqg_fetch_svb; `blow5` -- sqg_blow5_write_batch into /dev/shm (record framing +
+    zlib on the host's threads: the bytes the reference writes).  Never `value`: PCIe and zlib are 20x and 1500x below the kernels."""
+    import torch
+    probe = sample_batch().run().wait()
+    cap = int(probe.n_samples * 1.4) + 65536
+    probe.free()
+    pin16 = gen.pinned(2 * cap, np.int16)
+    pin8 = gen.pinned(3 * cap, np.uint8)                   # (svb-zd: 1.0-1.3 B per sample on these signals; 3.25 at worst, checked by the binding)
+    ids = [b"S1_%d!c0!0!10000!+" % i for i in range(reads_per_batch)]
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    out = {"reads_per_batch": reads_per_batch,
+           "what": "one host thread: sample + stage + queue batch i+1, wait for batch i, drain it; samples/s of the drained batches"}
+    for kind in ("pinned_int16", "pinned_svb", "blow5"):
+        path = os.path.join(shm, f"sqg_bench_e2e_{os.getpid()}.blow5")
+        w = api.Blow5Writer(path, prof, flags, threads=0) if kind == "blow5" else None
+        samples = nb = nbytes = 0
+
+        def drain(b):
+            nonlocal nbytes
+            if kind == "pinned_int16":
+                b.signal(out=pin16); nbytes += 2 * b.n_samples
+            elif kind == "pinned_svb":
+                enc, _ = b.compress(fetch=True, out=pin8); nbytes += len(enc)
+            else:
+                w.write_batch(b, ids)
+        try:
+            cur = sample_batch().run()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            while True:
+                last = nb >= 1 and time.perf_counter() - t0 >= seconds
+                nxt = None if last else sample_batch().run()
+                cur.wait()
+                drain(cur)
+                samples += cur.n_samples; nb += 1
+                cur.free()
+                if nxt is None:
+                    break
+                cur = nxt
+            if w is not None:
+                nbytes = w.close(); w = None
+            dt = time.perf_counter() - t0
+        finally:
+            if w is not None:
+                w.close()
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        out[kind] = {"value": samples / dt, "unit": "samples/s", "seconds": dt, "batches": nb, "bytes_per_sample": nbytes / max(samples, 1)}
+    return out
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -411,6 +468,10 @@ def main():
     ap.add_argument("--pipeline-seconds", type=float, default=2.5,
                     help="wall time of the streaming leg (`pipeline` in the line: nothing staged ahead, sampler + staging + run + free "
                          "from one host thread); 0 skips it")
+    ap.add_argument("--e2e-seconds", type=float, default=1.0,
+                    help="wall time (at least two batches) of each end-to-end leg -- raw int16 into pinned host memory, svb-zd into pinned "
+                         "host memory, BLOW5 into /dev/shm (`e2e` in the line; N = 1 only); 0 skips them")
+    ap.add_argument("--e2e-batch-reads", type=int, default=2048, help="reads per batch of the end-to-end legs")
     ap.add_argument("--workers-per-gpu", type=int, default=None,
                     help="W > 0: the job has T = N*W virtual workers, W per GPU (sharded by worker, no data-path collective), and every "
                          "batch of N*K reads is split over them as the reference's static partition does (src/thread.c:80-99): "
@@ -502,7 +563,7 @@ def main():
         gen.set_range_mode(True)
     # the phase events behind kernel_ms are barrier packets between the kernels (include/sqg.h, sqg_set_phase_timing): every
     # --timing-every'th batch carries them (short runs: every batch, so that the timed region holds timed launches)
-    timing_every = args.timing_every if args.steps >= 2 * args.timing_every else 1
+    timing_every = max(1, args.timing_every) if args.steps >= 2 * max(1, args.timing_every) else 1
     gen.set_phase_timing(timing_every)
     r_lo, r_hi = shard.read_range(rank, world, K * world)          # range mode: my reads of the job's K*world-read batches
 
@@ -639,6 +700,17 @@ def main():
         pipe = pipeline_leg(stage_one, run, n_pipe)
         sync_all()
 
+    e2e = None
+    if args.e2e_seconds > 0 and world == 1 and not range_mode and not args.digest:
+        for b in batches[:args.warmup] + [b for b in timed if b is not None]:
+            b.free()
+        batches, timed = [], []
+        Ke = min(args.e2e_batch_reads, K)
+        we = workers[:Ke] if not W else np.minimum(w_lo + np.arange(Ke, dtype=np.int32) // max(Ke // W, 1), w_hi - 1).astype(np.int32)
+        sync_all()
+        e2e = e2e_legs(gen, prof, flags, lambda: gen.sample(Ke, we), Ke, args.e2e_seconds)
+        sync_all()
+
     ptot = torch.tensor(list(pipe[:3]) if pipe else [0.0, 0.0, 1.0], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
     if use_dist:
         pmx = ptot.clone()
@@ -649,9 +721,10 @@ def main():
     if rank == 0:
         steps = max(args.steps, 1)
         alg_bytes = (2 * samples + bases + 24 * reads) / steps           # per k_samples_lean launch (this rank)
-        k_ms = float(np.mean(lean_ms)) if lean_ms else float("nan")     # the dominant kernel alone
-        if not k_ms > 0: k_ms = float("nan")                            # (SQG_ABL_NOTIMING runs)
-        achieved = (float(np.mean(lean_bytes)) if lean_bytes else alg_bytes) / (k_ms * 1e-3)    # the timed launches' own bytes over their mean duration
+        k_ms = float(np.mean(lean_ms)) if lean_ms else None             # the dominant kernel alone
+        if k_ms is not None and not k_ms > 0:
+            k_ms = None                                                 # (no timed launch in the region: null in the line, never NaN)
+        achieved = None if k_ms is None else (float(np.mean(lean_bytes)) if lean_bytes else alg_bytes) / (k_ms * 1e-3)    # the timed launches' own bytes over their mean duration
         ms_per_step = dt_max / steps * 1e3
         if range_mode:
             regime = (f"-t {T} -K {K * world} (range sharding: every GPU owns all {T} worker(s) and generates {K} reads of each "
@@ -664,6 +737,7 @@ def main():
         wkey = f"{args.workload}|{args.profile}|W={W}|batch_reads={K}|rlen={args.rlen}|mode={args.mode}"
         from squigulator_amd import build as _build
         lib_path = api.LOADED_PATH or _build.LIB
+        lib_info = api.build_info(api.load_library(lib_path))      # what the loaded library says it was built from (stamped by build.py)
         out = {
             "metric": "simulated raw samples/sec",
             "value": tot_samples / dt_max,
@@ -686,8 +760,9 @@ def main():
                 "pore_model": "synthetic stand-in table (built-in ONT tables absent from the reference mount)",
             },
             "library": {"path": os.path.relpath(lib_path, ROOT), "sha256_16": _build.file_hash(lib_path),
-                        "source_hash": _build.source_hash(), "in_tree": os.path.abspath(lib_path) == os.path.abspath(_build.LIB),
-                        "stale": _build.needs_build()},
+                        "source_hash": _build.source_hash(), "built_from": lib_info.get("source_hash"), "dev": lib_info.get("dev") == "1",
+                        "in_tree": os.path.abspath(lib_path) == os.path.abspath(_build.LIB),
+                        "stale": lib_info.get("source_hash") != _build.source_hash()},
             # the N ranks' own clocks around the same K steps (value uses the slowest) and what torch.distributed says the world is
             "ranks": {"world_size": dist.get_world_size() if use_dist else 1, "backend": dist.get_backend() if use_dist else None,
                       "ms_per_step_min": dt_min / steps * 1e3, "ms_per_step_max": dt_max / steps * 1e3},
@@ -697,6 +772,7 @@ def main():
                 "host_stage_ms_per_batch": pipe[3] * 1e3, "vs_value": float(ptot[0]) / float(ptot[2]) / (tot_samples / dt_max),
                 "what": "nothing staged ahead: one host thread per GPU samples (device-side gen_read) + stages batch i+1, queues it, "
                         "waits for batch i and frees it; two batches in flight, results left in HBM"},
+            "e2e": e2e,
             "reads_per_s": tot_reads / dt_max,
             # samples the fp32 path left to FP64, over the batches whose counters were still theirs when they were waited for
             "fp64_fixup_frac": (fallback / fallback_of if fallback_of else None) if args.mode == "certified" else None,
@@ -706,8 +782,8 @@ def main():
                           # the NEXT batch's event kernels and are stretched by them, so this span is longer than the kernels in it
                           "k_scan..k_fixup* (span; fix-ups overlap the next batch's event side)": float(np.mean(sig_ms)) if sig_ms else None,
                           "event side (k_events, k_part_*)": float(np.mean(ev_ms)) if ev_ms else None},
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S,
+            "roofline": {"bound": "hbm", "achieved": None if achieved is None else achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9,
+                         "unit": "GB/s", "frac": None if achieved is None else achieved / HBM_PEAK_BYTES_PER_S,
                          "traffic": pmc_traffic(wkey),
                          "kernel_ms": k_ms,
                          "kernel_ms_launches": len(lean_ms),        # timed launches inside the timed region (every `timing_every`th batch)

@@ -143,6 +143,9 @@ void sqg_destroy(sqg_ctx_t *ctx);
 const char *sqg_last_error(const sqg_ctx_t *ctx);   /* "" if none */
 const char *sqg_strerror(int code);
 int  sqg_device_count(void);                        /* <0: HIP unusable */
+/* "source_hash=<16 hex digits>;dev=<0|1>": the sources the library was built from (squigulator_amd/build.py) and whether it is
+ * the development build, the only one that reads A/B and test knobs from the environment (tools/README.md) */
+const char *sqg_build_info(void);
 
 /* Stage one batch: sequences are the reads exactly as gen_read() returns them.
  *   seqs     concatenated read bytes (ASCII; IUPAC handled as src/seq.h:14-27)
@@ -170,6 +173,12 @@ int  sqg_get_timing(sqg_ctx_t *ctx, sqg_timing_t *t);
  * the batches whose run index is a multiple of n do, the others report 0 ms in every field (fallback_samples is always filled
  * in); every = 0: none.  (No counterpart in the reference: its only timings are realtime() around process_db, src/sim.c:575-583.) */
 int  sqg_set_phase_timing(sqg_ctx_t *ctx, int every);
+/* Host threads (the calling one included) that share the per-read `offset` / `median_before` draws of sqg_batch_stage /
+ * sqg_batch_sample (host libm: src/gensig.c:315-316).  n = 0 (default): automatic -- four from 8192 reads per batch on, never more
+ * than the CPUs the process may use (affinity mask, cgroup quota); n in 1..64: exactly n.  A host that drives one context per GPU
+ * divides its CPU budget by the number of contexts (the reference's counterpart is -t, src/thread.c:73-116).  The draws are the
+ * same doubles for every n.  Returns the number of threads the context's last staging call used (0: none yet), < 0 on error. */
+int  sqg_set_stage_threads(sqg_ctx_t *ctx, int n);
 
 /* Convenience: stage + run + wait in one call (one process_db()). */
 int  sqg_submit(sqg_ctx_t *ctx, int32_t n_reads, const char *seqs, const int64_t *seq_off,

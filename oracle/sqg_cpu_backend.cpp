@@ -67,6 +67,7 @@ extern "C" const char* sqg_strerror(int code) {
 }
 extern "C" const char* sqg_last_error(const sqg_ctx_t* c) { return c ? c->err.c_str() : ""; }
 extern "C" int sqg_device_count(void) { return 1; }        /* "the CPU" */
+extern "C" const char* sqg_build_info(void) { return "source_hash=cpu-backend;dev=0"; }
 extern "C" int32_t sqg_worker_of(int32_t i, int32_t n_rec, int32_t T) { return (T <= 1 || n_rec <= 0) ? 0 : orc_worker_of(i, n_rec, T); }
 
 extern "C" void sqg_destroy(sqg_ctx_t* c) {
@@ -174,6 +175,7 @@ extern "C" void sqg_batch_free(sqg_ctx_t* c, sqg_batch_t* b) {
     delete b;
 }
 extern "C" int sqg_get_timing(sqg_ctx_t* c, sqg_timing_t* t) { if (!c || !t) return SQG_EINVAL; *t = c->timing; return SQG_OK; }
+extern "C" int sqg_set_stage_threads(sqg_ctx_t* c, int n) { return (!c || n < 0 || n > 64) ? SQG_EINVAL : 1; }   // (one thread stages here)
 extern "C" int sqg_set_phase_timing(sqg_ctx_t* c, int every) { return (!c || every < 0) ? SQG_EINVAL : SQG_OK; }   // (no phases to time here)
 
 extern "C" int sqg_submit(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t* seq_off, const int32_t* worker, sqg_batch_t** out, sqg_result_t* res) {

@@ -80,24 +80,46 @@ EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_d
            "sqg_host_alloc", "sqg_host_free", "sqg_set_range_mode", "sqg_skip_reads", "sqg_batch_sample_range",
            "sqg_batch_run_begin", "sqg_batch_run_end", "sqg_genome_load_device",
            "sqg_blow5_open", "sqg_blow5_write", "sqg_blow5_write_batch", "sqg_blow5_close", "sqg_blow5_last_error",
-           "sqg_genome_set_meth")
+           "sqg_genome_set_meth", "sqg_build_info", "sqg_set_stage_threads")
 
-_lib = None
+# Environment knobs only the development build of the library reads (csrc/h_common.h: SQG_DEV_ENV; tools/README.md).  The release
+# library ignores them, so a process that sets one -- a test forcing a code path, an A/B script -- gets libsqg_hip_dev.so.
+DEV_KNOBS = ("SQG_SEPARATE_DWELL", "SQG_EVENTS_WIDE_MAX", "SQG_MID_SPLIT", "SQG_SCAN_G4", "SQG_TEST_ORDER_FAULT", "SQG_LEAN_GRID",
+             "SQG_LEAN_DYNLDS", "SQG_FIX_INLINE", "SQG_ABL_NOFIX", "SQG_SAMPLER_SERIAL", "SQG_OVERLAP", "SQG_PART_CLAIMS",
+             "SQG_TEST_DELTA_X", "SQG_LEAN_EPL", "SQG_TEST_ROW_TURNS", "SQG_PART_WG_EVENTS", "SQG_SPLIT_CHAINS", "SQG_NO_PART",
+             "SQG_PART_SLICE", "SQG_TEST_NO_LEAN", "SQG_STAGE_THREADS")
+
+_libs = {}                  # absolute path -> loaded library
 LOADED_PATH = None          # the library the last load_library() call opened (bench.py prints it with its hash)
+
+
+def dev_knobs_set() -> list:
+    return [k for k in DEV_KNOBS if k in os.environ]
+
+
+def default_library_path() -> str:
+    """SQG_LIB (A/B testing of kernel build variants), else the development build if the environment holds one of its knobs,
+    else the release library"""
+    return os.environ.get("SQG_LIB") or (_build.LIB_DEV if dev_knobs_set() else _build.LIB)
+
+
+def build_info(L) -> dict:
+    """sqg_build_info() as a dict: {"source_hash": ..., "dev": "0"|"1"}"""
+    return dict(kv.split("=", 1) for kv in L.sqg_build_info().decode().split(";") if "=" in kv)
 
 
 def load_library(path: str | None = None):
     """dlopen the HIP library; raises if it has not been built (no fallback)."""
-    global _lib
-    if _lib is not None and path is None:
-        return _lib
-    path = path or os.environ.get("SQG_LIB") or _build.LIB   # SQG_LIB: A/B testing of kernel build variants
+    path = os.path.abspath(path or default_library_path())
+    global LOADED_PATH
+    if path in _libs:
+        LOADED_PATH = path
+        return _libs[path]
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build it with `python -m squigulator_amd.build` "
                            "(there is no CPU fallback for the signal path)")
     L = C.CDLL(path)
-    global LOADED_PATH
-    LOADED_PATH = os.path.abspath(path)
+    LOADED_PATH = path
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     L.sqg_create.restype = C.c_int
     L.sqg_create.argtypes = [C.POINTER(CCfg), C.POINTER(vp)]
@@ -171,8 +193,11 @@ def load_library(path: str | None = None):
     L.sqg_blow5_close.argtypes = [vp, C.POINTER(i64)]
     L.sqg_blow5_last_error.restype = C.c_char_p
     L.sqg_blow5_last_error.argtypes = [vp]
-    if path == _build.LIB:
-        _lib = L
+    L.sqg_set_stage_threads.restype = C.c_int
+    L.sqg_set_stage_threads.argtypes = [vp, C.c_int]
+    L.sqg_build_info.restype = C.c_char_p
+    L.sqg_build_info.argtypes = []
+    _libs[path] = L
     return L
 
 
@@ -340,6 +365,8 @@ class Batch:
         off = np.ctypeslib.as_array(r.svb_off, shape=(self.n_reads + 1,)).copy()
         if not fetch:
             return None, off
+        if out is not None and len(out) < r.n_bytes:
+            raise ValueError("destination too small for the batch's encodings")
         out = np.empty(r.n_bytes, np.uint8) if out is None else out[:r.n_bytes]
         self.gen._chk(self.gen.L.sqg_fetch_svb(self.gen.ctx, self.handle, out.ctypes.data), "sqg_fetch_svb")
         return out, off
@@ -487,6 +514,13 @@ class SignalGenerator:
         self._pinned.append(p)
         buf = (C.c_uint8 * nbytes).from_address(p)
         return np.frombuffer(buf, dtype=dtype)
+
+    def set_stage_threads(self, n: int) -> int:
+        """Host threads that share a batch's per-read libm draws at staging (0: automatic); returns how many the last staging used."""
+        rc = self.L.sqg_set_stage_threads(self.ctx, int(n))
+        if rc < 0:
+            self._chk(rc, "sqg_set_stage_threads")
+        return rc
 
     def set_phase_timing(self, every: int):
         """Phase events (timing()'s milliseconds) on the batches whose run index is a multiple of `every`; 1: all (default), 0: none."""

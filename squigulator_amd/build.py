@@ -1,6 +1,11 @@
 """Build the HIP shared library in-tree (no JIT cache: the .so must travel with the repo snapshot).
 
-    python -m squigulator_amd.build          # -> squigulator_amd/csrc/libsqg_hip.so
+    python -m squigulator_amd.build          # -> squigulator_amd/csrc/libsqg_hip.so      (release: the product)
+                                             #    squigulator_amd/csrc/libsqg_hip_dev.so  (-DSQG_DEV: reads the A/B and test knobs
+                                             #    of tools/README.md from the environment; tests that force a code path, tools/)
+
+Both carry the sha256 of the sources they were built from (`SQG_SOURCE_HASH=...;` in the file, sqg_build_info() at run time); a
+library is rebuilt when that stamp differs from the tree's -- not by file times, which a checkout or a copy to the GPU box changes.
 
 hipcc cross-compiles gfx950 code objects without a GPU, so this also runs in the CPU-only
 build container.  -fno-slp-vectorize: the SLP pass pairs the two events a k_events thread handles into v_pk_* ops that need
@@ -17,6 +22,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsqg_hip.so")
+LIB_DEV = os.path.join(CSRC, "libsqg_hip_dev.so")
 SOURCES = [os.path.join(CSRC, "sqg_hip.hip")]
 import glob
 import hashlib
@@ -56,24 +62,66 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found: the HIP extension cannot be built")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(p) > t for p in SOURCES + headers())
+_MARK = b"SQG_SOURCE_HASH="
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
-        return LIB
-    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-slp-vectorize", "-Wall", "-Wno-unused-result", "-o", LIB] + SOURCES + ["-lz"]
+def stamped_hash(lib: str) -> str | None:
+    """the source hash a built library carries (read from the file: no dlopen, no HIP runtime), None if it has none"""
+    try:
+        with open(lib, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    i = blob.find(_MARK)
+    if i < 0:
+        return None
+    j = blob.find(b";", i)
+    return blob[i + len(_MARK):j].decode("ascii", "replace") if 0 <= j - i <= 64 else None
+
+
+def needs_build(lib: str = LIB) -> bool:
+    return stamped_hash(lib) != source_hash()
+
+
+def flags(dev: bool = False, extra=()) -> list:
+    """the hipcc line, without output and sources (tools/ build their A/B variants from it: `python -m squigulator_amd.build --flags`)"""
+    fl = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize",
+          "-Wall", "-Wno-unused-result", f'-DSQG_SOURCE_HASH="{source_hash()}"']
+    if dev:
+        fl.append("-DSQG_DEV")
+    return fl + list(extra)
+
+
+def build_variant(out: str, dev: bool = True, extra=(), verbose: bool = True) -> str:
+    cmd = [hipcc_path()] + flags(dev, extra) + ["-o", out] + SOURCES + ["-lz"]
     if verbose:
         print("[squigulator_amd.build]", " ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    return out
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """both libraries (two independent hipcc runs, side by side); returns the release one"""
+    todo = [(LIB, False), (LIB_DEV, True)]
+    todo = [(o, d) for o, d in todo if force or needs_build(o)]
+    procs = []
+    for out, dev in todo:
+        cmd = [hipcc_path()] + flags(dev) + ["-o", out] + SOURCES + ["-lz"]
+        if verbose:
+            print("[squigulator_amd.build]", " ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    for out, _ in todo:
+        if stamped_hash(out) != source_hash():
+            raise RuntimeError(f"{out}: the built library does not carry the tree's source hash")
     return LIB
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    if "--flags" in sys.argv:
+        print(" ".join(flags(dev=True)))
+    else:
+        build(force="--force" in sys.argv)
+        print(LIB)

@@ -16,6 +16,7 @@
 //             i32 read_number | u8 start_mux | u64 start_time [| u8 end_reason]    (slow5_rec_to_mem, slow5.c:3928-4072;
 //             set_record_primary_fields / set_record_aux_fields, src/gensig.c:171-223)
 #pragma once
+#include "h_cpus.h"
 
 #include <zlib.h>
 
@@ -74,7 +75,7 @@ extern "C" int sqg_blow5_open(const char* path, const sqg_profile_t* profile, ui
         return SQG_EIO;
     }
     w->profile = *profile; w->flags = flags;
-    w->threads = threads > 0 ? threads : (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    w->threads = threads > 0 ? threads : std::min(16, usable_cpus());
     const std::string h = blow5_header(*profile, flags);
     if (fwrite(h.data(), 1, h.size(), w->fp) != h.size()) {
         fprintf(stderr, "[sqg] sqg_blow5_open: cannot write the header of %s: %s\n", path, strerror(errno));

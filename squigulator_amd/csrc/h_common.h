@@ -2,6 +2,32 @@
 // Host side of include/sqg.h; included by sqg_hip.hip (one translation unit with the kernels), in the order listed there.
 #pragma once
 
+// Development knobs -- A/B kernels, forced code paths, fault injection, timing-only ablations that produce wrong results -- are read
+// from the environment ONLY by the -DSQG_DEV build (libsqg_hip_dev.so: tests that have to force a path, tools/).  The release
+// library (libsqg_hip.so) does not contain their names: a host program's environment cannot steer it (tests/test_release_build.py).
+// SQG_VERBOSE, SQG_DEBUG_SYNC and SQG_STAGE_TIMING (diagnostics on stderr, results untouched) stay in both.
+#if defined(SQG_DEV)
+#define SQG_DEV_ENV(name) getenv(name)
+#else
+#define SQG_DEV_ENV(name) (static_cast<const char*>(nullptr))
+#endif
+static inline int dev_env_int(const char* v, int dflt) { return v ? atoi(v) : dflt; }
+
+// sha256 (16 hex digits) over the sources this library was built from (squigulator_amd/build.py: source_hash()), stamped by the build;
+// build.py finds it by its marker without loading the library, bench.py reads it through sqg_build_info()
+#ifndef SQG_SOURCE_HASH
+#define SQG_SOURCE_HASH "unstamped"
+#endif
+extern "C" const char sqg_source_hash_marker[] = "SQG_SOURCE_HASH=" SQG_SOURCE_HASH ";";
+#if defined(SQG_DEV)
+static const char kBuildInfo[] = "source_hash=" SQG_SOURCE_HASH ";dev=1";
+#else
+static const char kBuildInfo[] = "source_hash=" SQG_SOURCE_HASH ";dev=0";
+#endif
+extern "C" const char* sqg_build_info(void) { return kBuildInfo; }
+
+#include "h_cpus.h"      // usable_cpus()
+
 static uint32_t lcg_pow(uint32_t base, unsigned long long e) {
     uint32_t r = 1, b = base;
     while (e) { if (e & 1) r = lcg_mul(r, b); b = lcg_mul(b, b); e >>= 1; }
@@ -70,6 +96,7 @@ struct sqg_ctx {
     }
     unsigned int* d_err = nullptr;                 // the read sampler's error word (sqg_batch_sample* read and clear it synchronously);
                                                    // the kernels of a batch report into the batch's own word
+    unsigned long long fix_tickets = 0;            // k_fixup launches so far: the tag of the launch's list entries
     unsigned long long scan_tickets = 0;           // k_scan launches so far: every launch gets a ticket of its own
     // Everything a batch's kernels write lives in one of two SLOTS (batch seq & 1): a batch's results stay valid while
     // the next one runs (sqg_batch_wait / sqg_fetch_* of batch i do not wait for batch i+1), and with SQG_OVERLAP=1 the
@@ -122,6 +149,8 @@ struct sqg_ctx {
     unsigned long long next_stage = 0, next_run = 0, compress_seq = 0;
     unsigned long long runs = 0;                   // batches run so far: a batch's slot is its run index & 1
     unsigned int* d_mid_done = nullptr;            // k_part_mid: offsets workgroups that have finished (the last one resets it)
+    int stage_threads = 0;                         // sqg_set_stage_threads: host threads that share a batch's per-read libm draws (0: automatic)
+    int stage_threads_last = 0;                    // ... and how many the last staging call used
     int phase_timing_every = 1;                    // sqg_set_phase_timing: the batches whose run index is a multiple carry the phase events (0: none)
     std::set<unsigned long long> abandoned;        // staged batches that were freed without having been run
     sqg_timing_t timing = {0, 0, 0, 0, 0, 0};
@@ -210,7 +239,7 @@ struct sqg_batch {
     unsigned long long slot_gen = 0;     // generation of the slot when this batch took it (results are stale once it differs)
     int slot = 0;                        // which of the context's two buffer sets this batch runs in
     unsigned long long run_idx = 0;      // how many batches had been run before this one
-    bool ran = false, waited = false, lean_timed = false, dwell_timed = false;
+    bool ran = false, waited = false, lean_timed = false, dwell_timed = false, fixup_launched = false;
     bool staged = false;                 // staging completed: the batch holds a place in the run order
     bool begun = false, other_fresh = false;   // sqg_batch_run_begin has run; the other slot had never held a batch then
 };

@@ -132,7 +132,7 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     // SQG_OVERLAP=1: the sample kernels get their own stream, so that the event kernels of the next batch run next to
     // them.  Both are VALU-bound: measured +2 % with earlier kernels, -2..4 % with the current ones, and it stretches every
     // kernel's duration -- the default keeps one stream and clean per-kernel timings.  Batches are double-buffered either way.
-    if (getenv("SQG_OVERLAP")) CHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    if (SQG_DEV_ENV("SQG_OVERLAP")) CHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     else c->stream2 = c->stream;
     {   // lowest priority: the fix-ups fill the gaps of the next batch's k_events, they must not take its slots
         int prio_lo = 0, prio_hi = 0;
@@ -151,7 +151,7 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
         CHK(hipEventCreateWithFlags(&S.sampled, hipEventDisableTiming));
         CHK(hipEventRecord(S.done, c->stream2));
     }
-    if (c->use_kmer_streams && !getenv("SQG_PART_CLAIMS") && !(cfg->flags & SQG_ORDER_FREE)) {
+    if (c->use_kmer_streams && !SQG_DEV_ENV("SQG_PART_CLAIMS") && !(cfg->flags & SQG_ORDER_FREE)) {
         // the hand-out over bucketed events by ordered LDS atomics (few workers).  Three lines of defence (k_part.h): an allow-list of
         // architectures on which the property was verified offline (2e8 fetch-adds, tests/test_split_chains.py, tools/stress_few.py:
         // ordered against order-free kernels over 4e11 samples); this check on THIS device, in the production shape (4096-entry
@@ -191,7 +191,7 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
         c->delta_x = m * 1.25f + 1.0e-7f;
         if (getenv("SQG_VERBOSE")) fprintf(stderr, "[sqg] certified fp32 deviate: max |x_fp32 - x_fp64| over all states = %.3e, bound used %.3e\n", (double)m, (double)c->delta_x);
         // testing knob: inflate the bound so that (almost) every sample takes the FP64 fix-up path
-        if (const char* ov = getenv("SQG_TEST_DELTA_X")) { c->delta_x = (float)atof(ov); c->force_fix = true; }
+        if (const char* ov = SQG_DEV_ENV("SQG_TEST_DELTA_X")) { c->delta_x = (float)atof(ov); c->force_fix = true; }
         // table-wide quantities of the lean kernel (same eps formula as k_samples<1, GENERIC>, per k-mer)
         const double kd = cfg->profile.digitisation / cfg->profile.range;
         double lo = 1e300, hi = -1e300, eps_max = 0;
@@ -219,7 +219,7 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
             const double nev = 64.0 * epl;
             if (nev * mu + 6.0 * std::sqrt(nev) * sg <= 0.97 * LEAN_MAX_SAMPLES) { c->lean_epl = epl; break; }
         }
-        if (const char* ov = getenv("SQG_LEAN_EPL")) { const int v = atoi(ov); if (v == 1 || v == 2 || v == 4) c->lean_epl = v; }   // A/B knob
+        if (const char* ov = SQG_DEV_ENV("SQG_LEAN_EPL")) { const int v = atoi(ov); if (v == 1 || v == 2 || v == 4) c->lean_epl = v; }   // A/B knob
     }
 
     // per-(worker,k-mer) stream states
@@ -236,7 +236,7 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
             // that one returning atomic add per k-mer bin replaces a load and a store; the state is seed * a^(2*count)
             // (test hook SQG_TEST_ROW_TURNS=t: start every count at t*(M-1)/2, which is the same stream position; t = 3
             // makes the first batch normalise the counts, t = 2 exercises the top of the jump tables)
-            const char* turns_env = getenv("SQG_TEST_ROW_TURNS");
+            const char* turns_env = SQG_DEV_ENV("SQG_TEST_ROW_TURNS");
             const int turns = turns_env ? std::min(3, std::max(0, atoi(turns_env))) : 0;
             CHK(hipMemsetD32Async((hipDeviceptr_t)c->d_rows, (int)((unsigned)turns * LCG_ORD2), (size_t)total, c->stream));
             c->row_bound = (double)turns * (double)LCG_ORD2 + (turns == 3 ? (double)LCG_ORD2 : 0.0);

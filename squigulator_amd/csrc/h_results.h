@@ -40,7 +40,7 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
         if (c->cfg.mode == SQG_MODE_CERTIFIED && !slot_is_mine(c, b)) nfix = -1;   // the slot's counters belong to a later batch by now: not known
         if (c->cfg.mode == SQG_MODE_CERTIFIED && slot_is_mine(c, b)) {
             unsigned int cnt[4 + FIX_SHARDS];                // the counters and the lists' statistics in one read-back
-            const bool lists = S.d_fix_sh_count != nullptr;
+            const bool lists = S.d_fix_sh_count != nullptr && b->fixup_launched;   // (an empty batch launches no k_fixup: the words are an earlier batch's)
             HIPCHK(c, hipMemcpy(cnt, S.d_fix_count, (lists ? 4 + FIX_SHARDS : 4) * sizeof(unsigned int), hipMemcpyDeviceToHost));
             nfix = cnt[0];                                  // the global list ...
             if (lists) for (int i = 0; i < FIX_SHARDS; i++) nfix += cnt[4 + i];   // ... + the lean kernel's lists (a word per list, written by k_fixup)
@@ -95,6 +95,12 @@ extern "C" int sqg_set_phase_timing(sqg_ctx_t* c, int every) {
     if (!c || every < 0) return SQG_EINVAL;
     c->phase_timing_every = every;
     return SQG_OK;
+}
+
+extern "C" int sqg_set_stage_threads(sqg_ctx_t* c, int n) {
+    if (!c || n < 0 || n > 64) return SQG_EINVAL;
+    c->stage_threads = n;
+    return c->stage_threads_last;
 }
 
 extern "C" int sqg_submit(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t* seq_off,

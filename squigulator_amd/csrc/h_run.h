@@ -30,7 +30,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     const bool other_fresh = b->other_fresh;
 
     // Dwell draws are made inside k_events (SQG_SEPARATE_DWELL=1 keeps the stand-alone k_dwell for A/B runs).
-    static const bool separate_dwell = getenv("SQG_SEPARATE_DWELL") != nullptr;
+    const bool separate_dwell = SQG_DEV_ENV("SQG_SEPARATE_DWELL") != nullptr;
     const bool inline_dwell = c->use_dwell_stream && !separate_dwell;
     const bool direct = c->num_kmer <= 4096;                    // the worker's whole row of stream states fits in LDS
     if (phase != 2 && !direct && c->use_kmer_streams && n > 0) {
@@ -86,7 +86,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     // few chains (the reference's default -K 1000 with one worker per read): a chain is a sequence of segments, each with
     // its barriers and LDS round trips, and there are not enough chains to hide them -- 1024 threads per chain walk it in a
     // quarter of the steps
-    const int wide_max = getenv("SQG_EVENTS_WIDE_MAX") ? atoi(getenv("SQG_EVENTS_WIDE_MAX")) : 1200;   // A/B knob
+    const int wide_max = dev_env_int(SQG_DEV_ENV("SQG_EVENTS_WIDE_MAX"), 1200);   // A/B knob
     auto launch_events = [&](int dw, bool hist) {
         const dim3 g((unsigned)b->n_chains);
         const bool wide = !hist && b->n_chains <= wide_max;
@@ -163,7 +163,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 }
                 if (b->split_reads && dw) S.seglen_dirty = (size_t)n;   // (until this batch's k_fixup is queued: a run that fails half-way leaves them dirty)
                 launch_part_events(dw, true);                     // dwell draws; events per (link, partition)
-                static const bool mid_split = getenv("SQG_MID_SPLIT") != nullptr;   // A/B: the four small kernels between the passes, one by one
+                const bool mid_split = SQG_DEV_ENV("SQG_MID_SPLIT") != nullptr;   // A/B: the four small kernels between the passes, one by one
                 if (b->split_reads && (b->one || mid_split)) hipLaunchKernelGGL(k_part_tile_bases, dim3((unsigned)b->n_pieces), dim3(64), 0, c->stream, P);
                 if (b->one) {
                     // one partition: the pass above has written part[] in chain order; the slices of every worker chain's events
@@ -199,7 +199,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             if (phase != 1) {
 #define SCANL(R_, G_) hipLaunchKernelGGL((k_part_scan<R_, G_>), dim3((unsigned)((c->num_kmer + R_ - 1) / R_), (unsigned)b->n_wchains), dim3(R_ * G_), 0, c->stream, \
                                         c->d_phist, c->d_rows, c->num_kmer, n_part, pfirst, b->d_wlink_worker, before, c->d_pow, P.seed_base, P.seed_step, direct ? 1 : 0, b->d_err)
-                static const int scan_g4 = getenv("SQG_SCAN_G4") ? atoi(getenv("SQG_SCAN_G4")) : 32;   // A/B knob
+                const int scan_g4 = dev_env_int(SQG_DEV_ENV("SQG_SCAN_G4"), 32);   // A/B knob
                 if ((long long)b->max_slices <= 8 * (long long)n_pairs) SCANL(256, 1);       // a slice or two per pair: one thread per rank walks them
                 else if ((long long)b->max_slices <= scan_g4 * (long long)n_pairs && (size_t)pg.x * pg.y >= 512) SCANL(64, 4);   // a dozen (small batches): 16 runs would be 16 x the wavefronts, most of them idle
                 else if ((size_t)pg.x * pg.y >= 512) SCANL(64, 16);
@@ -210,7 +210,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                     if (direct) hipLaunchKernelGGL(k_rows_advance<true>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
                     else hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
                 }
-                const int order_fault = getenv("SQG_TEST_ORDER_FAULT") ? 1 : 0;         // (tests: the per-batch order check has to fire)
+                const int order_fault = SQG_DEV_ENV("SQG_TEST_ORDER_FAULT") ? 1 : 0;         // (tests: the per-batch order check has to fire)
                 if (c->lds_ordered) hipLaunchKernelGGL(k_part_hand_ord, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, b->d_err, order_fault);
                 else if (c->dwell_hi >= (double)PART_JT) hipLaunchKernelGGL(k_part_hand<true>, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);
                 else hipLaunchKernelGGL(k_part_hand<false>, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);
@@ -307,7 +307,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     bool seglen_zeroed = false;
     if (n > 0 && b->n_chains > 0) {
         P.sig = S.d_sig; P.fix = S.d_fix; P.fix_count = S.d_fix_count;
-        P.fix_sh = S.d_fix_sh; P.fix_sh_cap = S.fix_sh_per; P.fix_sh_count = S.d_fix_sh_count; P.fix_sh_stat = S.d_fix_count + 4; P.fix_tag = (int)(b->run_idx & 0x3fffffff) + 1;
+        P.fix_sh = S.d_fix_sh; P.fix_sh_cap = S.fix_sh_per; P.fix_sh_count = S.d_fix_sh_count; P.fix_sh_stat = S.d_fix_count + 4; P.fix_tag = (int)(++c->fix_tickets & 0x3fffffffull) + 1;   // (a tag per launch, also when a batch is run again after a failed run: stale entries of the first attempt must not match)
         P.fix_cap = (unsigned int)std::min<size_t>(S.fix_cap, 0xffffffffu);
         if (b->run_idx < 8 && getenv("SQG_VERBOSE"))
             fprintf(stderr, "[sqg] batch %lld slot %d: sig %p part %p evrec %p part_state %p dwell %p bases %p seglen %p\n", (long long)b->run_idx, b->slot,
@@ -329,7 +329,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             P.slow_tiles = S.d_slow;
             const int n_stiles = (int)b->n_stiles;
             unsigned lgrid = (unsigned)((n_stiles + 3) / 4);
-            static const int lean_grid_cap = getenv("SQG_LEAN_GRID") ? atoi(getenv("SQG_LEAN_GRID")) : 0;   // A/B knob
+            const int lean_grid_cap = dev_env_int(SQG_DEV_ENV("SQG_LEAN_GRID"), 0);   // A/B knob
             if (lean_grid_cap > 0) lgrid = std::min(lgrid, (unsigned)lean_grid_cap);
             // work items of 256 events (4 per lane) look their descriptor up themselves, on the scalar unit; with shorter
             // items (profiles with long dwells) the look-up chain per item is worth a kernel of its own
@@ -340,7 +340,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 HIPCHK(c, hipStreamWaitEvent(c->stream2, b->ev[7], 0));      // ... on their own stream, next to the next batch's k_events
             }
             if (!untimed) HIPCHK(c, hipEventRecord(b->ev[5], c->stream2));
-            static const unsigned lean_dynlds = getenv("SQG_LEAN_DYNLDS") ? (unsigned)atoi(getenv("SQG_LEAN_DYNLDS")) : 0u;   // A/B: bytes of LDS a workgroup reserves on top (fewer workgroups per CU)
+            const unsigned lean_dynlds = (unsigned)dev_env_int(SQG_DEV_ENV("SQG_LEAN_DYNLDS"), 0);   // A/B: bytes of LDS a workgroup reserves on top (fewer workgroups per CU)
 #define LEANL(R, E) hipLaunchKernelGGL((k_samples_lean<R, E>), dim3(lgrid), dim3(256), lean_dynlds, c->stream2, P, n_stiles)
             if (P.rna) { if (c->lean_epl == 4) LEANL(true, 4); else if (c->lean_epl == 2) LEANL(true, 2); else LEANL(true, 1); }
             else { if (c->lean_epl == 4) LEANL(false, 4); else if (c->lean_epl == 2) LEANL(false, 2); else LEANL(false, 1); }
@@ -350,19 +350,20 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             if ((rc = dbg_sync(c, "k_samples_lean"))) return rc;
             // what is left -- the items the lean kernel did not take (usually none) and the FP64 fix-ups, small latency-bound
             // kernels -- goes to a stream of its own: the next batch's k_events does not wait for it
-            static const bool fix_inline = getenv("SQG_FIX_INLINE") != nullptr;   // A/B: the left-over kernels on the batch's own stream
+            const bool fix_inline = SQG_DEV_ENV("SQG_FIX_INLINE") != nullptr;   // A/B: the left-over kernels on the batch's own stream
             HIPCHK(c, hipEventRecord(S.sampled, c->stream2));
             if (!fix_inline) {
                 HIPCHK(c, hipStreamWaitEvent(c->fix_stream, S.sampled, 0));
                 tail = c->fix_stream;
             }
-            static const bool abl_nofix = getenv("SQG_ABL_NOFIX") != nullptr;   // timing-only ablation (results are wrong): what the left-over kernels cost the step
+            const bool abl_nofix = SQG_DEV_ENV("SQG_ABL_NOFIX") != nullptr;   // timing-only ablation (results are wrong): what the left-over kernels cost the step
             if (!abl_nofix) {
             hipLaunchKernelGGL((k_samples<1, true>), dim3(std::min(sgrid, 4096u)), dim3(256), 0, tail, P, n_tiles);
             if ((rc = dbg_sync(c, "k_samples<generic>"))) return rc;
             P.seglen_zero = 2 * n;
             hipLaunchKernelGGL(k_fixup, dim3(FIX_SHARDS), dim3(256), 0, tail, P);
             seglen_zeroed = true;
+            b->fixup_launched = true;                                // (its per-list statistics words are this batch's)
             }
             if ((rc = dbg_sync(c, "k_fixup"))) return rc;
         } else {

@@ -151,7 +151,7 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
     // staging stream drained, so nothing of the previous call is still in use)
     int max_m = 0;
     for (int q = 0; q < n_chains; q++) max_m = std::max(max_m, chain_off[(size_t)q + 1] - chain_off[(size_t)q]);
-    const bool concurrent = n > 0 && !(c->genome.flags & SQG_SAMPLE_FULL) && max_m >= 16 && !getenv("SQG_SAMPLER_SERIAL");
+    const bool concurrent = n > 0 && !(c->genome.flags & SQG_SAMPLE_FULL) && max_m >= 16 && !SQG_DEV_ENV("SQG_SAMPLER_SERIAL");
     std::vector<long long> att_off((size_t)n_chains + 1, 0);
     long long max_a = 0;
     if (concurrent)    // long chains: the attempts are evaluated concurrently, 25 % more than the acceptance rate seen so far asks for

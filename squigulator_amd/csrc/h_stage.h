@@ -176,17 +176,17 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     std::vector<Piece> pieces;
     // the hand-out over bucketed events (k_part.h) instead of per-link rows: k > 6 (up to PART_MAX partitions of 4096 streams), and
     // k <= 6 as its one-partition case -- nothing to bucket, the events stay in chain order -- on devices with ordered LDS atomics
-    const bool part_one = c->num_kmer <= PART_SUB && c->lds_ordered && !(c->cfg.flags & SQG_METH) && !getenv("SQG_PART_WG_EVENTS");
-    const char* split_env = getenv("SQG_SPLIT_CHAINS");
+    const bool part_one = c->num_kmer <= PART_SUB && c->lds_ordered && !(c->cfg.flags & SQG_METH) && !SQG_DEV_ENV("SQG_PART_WG_EVENTS");
+    const char* split_env = SQG_DEV_ENV("SQG_SPLIT_CHAINS");
     const int forced = split_env ? atoi(split_env) : -1;
-    bool part_ok = ((c->num_kmer > PART_SUB && c->num_kmer <= PART_MAX * PART_SUB) || part_one) && nev < 4294967000LL && !getenv("SQG_NO_PART");
+    bool part_ok = ((c->num_kmer > PART_SUB && c->num_kmer <= PART_MAX * PART_SUB) || part_one) && nev < 4294967000LL && !SQG_DEV_ENV("SQG_NO_PART");
     // ... when the events outweigh the tables: every (worker chain, partition) costs at least one 16-KiB table in three passes
     // (hundreds of workers with a read or two each: the per-link rows, or no cut at all, are the better choice)
     if (forced < 0 && !c->range_mode && nev < (long long)n_wchains * (part_one ? 1 : (c->num_kmer + PART_SUB - 1) >> PART_SUB_BITS) * 1024) part_ok = false;
     {
         // (bucketed hand-out: a link is one wavefront of k_part_events -- 8 per SIMD -- and may hold pieces of reads, so that a few
         // long reads are worth cutting as well; one workgroup of k_events and whole reads otherwise)
-        const bool wave_links = part_ok && c->lds_ordered && !(c->cfg.flags & SQG_METH) && !getenv("SQG_PART_WG_EVENTS");
+        const bool wave_links = part_ok && c->lds_ordered && !(c->cfg.flags & SQG_METH) && !SQG_DEV_ENV("SQG_PART_WG_EVENTS");
         const bool multi = n > n_wchains;
         const bool want = c->range_mode ? n > 0 : forced >= 0 ? (forced > 0 && (multi || wave_links))
                                                               : ((multi || (wave_links && n_wchains <= 16)) && n_wchains < (wave_links && part_one ? 2048 : 1024) && nev >= 65536);   // (measured: from 2048 / 1024 chains on, one workgroup of k_events per chain is as fast or faster)
@@ -268,7 +268,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         const int n_part = (c->num_kmer + PART_SUB - 1) >> PART_SUB_BITS;
         link_q.assign((size_t)b->n_chains, 0);
         for (int q = 0; q < n_wchains; q++) for (int l = wlink_off[(size_t)q]; l < wlink_off[(size_t)q + 1]; l++) link_q[(size_t)l] = q;
-        const char* senv = getenv("SQG_PART_SLICE");
+        const char* senv = SQG_DEV_ENV("SQG_PART_SLICE");
         // at most 4096 slices (a whole number of rounds of 4 wavefronts per CU for k_part_hand_ord), whole steps of the hand-out
         const long long n_pairs = (long long)n_wchains * n_part, want = std::max<long long>(1024, 4096 - n_pairs);
         long long len = senv ? atoll(senv) : ((nev + want - 1) / want + PART_STEP - 1) / PART_STEP * PART_STEP;
@@ -320,7 +320,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         for (int q = 0; q < b->n_chains; q++) chain_order[(size_t)cnt[(size_t)cls(chain_ev[(size_t)q])]++] = q;
     }
 
-    const bool no_lean = getenv("SQG_TEST_NO_LEAN") != nullptr;
+    const bool no_lean = SQG_DEV_ENV("SQG_TEST_NO_LEAN") != nullptr;
     // the workers' scalar streams advance below; a staging that fails afterwards (allocation) puts them back
     const std::vector<uint32_t> snap_time = c->time_c;
     const std::vector<long long> snap_off = c->off_x, snap_med = c->med_x;
@@ -350,11 +350,14 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
             }
         }
     };
-    static const int forced_th = getenv("SQG_STAGE_THREADS") ? atoi(getenv("SQG_STAGE_THREADS")) : 0;   // A/B knob, tests
     // (measured, 16384 reads per batch: 1.30 ms on one thread, 1.10 with two, 0.93 with four, 0.88 with six -- the helpers sleep for
-    // milliseconds between two batches and wake slowly)
-    const int want_th = ideal ? 1 : forced_th > 0 ? forced_th : n >= 8192 ? 4 : 1;
-    const int nth = (int)std::min<unsigned>((unsigned)std::min(want_th, std::max(n, 1)), std::max(1u, std::thread::hardware_concurrency()));
+    // milliseconds between two batches and wake slowly).  sqg_set_stage_threads fixes the number (a host that runs one context per GPU
+    // on a CPU quota shared by eight of them); automatic: four from 8192 reads per batch on, never more than the CPUs this process may use.
+    const int dev_th = dev_env_int(SQG_DEV_ENV("SQG_STAGE_THREADS"), 0);       // (development build: A/B runs)
+    const int forced_th = dev_th > 0 ? dev_th : c->stage_threads;
+    const int want_th = ideal ? 1 : forced_th > 0 ? forced_th : n >= 8192 ? std::min(4, usable_cpus()) : 1;
+    const int nth = std::max(1, std::min(want_th, std::max(n, 1)));
+    c->stage_threads_last = nth;
     if (nth > 1) {
         off_d.resize((size_t)n); med_d.resize((size_t)n); rd_worker.resize((size_t)n);
         for (int ci = 0; ci < n; ci++) rd_worker[(size_t)ci] = rd[(size_t)chain_reads[(size_t)ci]].worker;

@@ -93,7 +93,17 @@ def test_bench_line_carries_the_contract():
     assert pl["vs_value"] == pytest.approx(pl["value"] / d["value"], rel=1e-9) and pl["vs_value"] > 0.3
     lib = d["library"]
     assert lib["in_tree"] is True and lib["stale"] is False and len(lib["sha256_16"]) == 16 and len(lib["source_hash"]) == 16
+    assert lib["built_from"] == lib["source_hash"] and lib["dev"] is False          # the release library, stamped with the tree's hash
     assert d["ranks"]["world_size"] == 1 and d["ranks"]["ms_per_step_min"] == pytest.approx(d["ms_per_step"], rel=1e-9)
+    # round 4: the end-to-end legs (src/sim.c:602-611,630-641): raw int16 / svb-zd into pinned host memory, BLOW5 into /dev/shm
+    e = d["e2e"]
+    for leg in ("pinned_int16", "pinned_svb", "blow5"):
+        assert e[leg]["unit"] == "samples/s" and e[leg]["value"] > 0 and e[leg]["batches"] >= 2 and e[leg]["seconds"] >= 1.0, (leg, e[leg])
+    assert e["pinned_int16"]["bytes_per_sample"] == 2.0 and 0.5 < e["pinned_svb"]["bytes_per_sample"] < 2.0
+    assert 0.4 < e["blow5"]["bytes_per_sample"] < e["pinned_svb"]["bytes_per_sample"]      # (zlib over the svb-zd bytes)
+    assert e["blow5"]["value"] < e["pinned_svb"]["value"] < d["value"]
+    if c["kind"] == "reference":
+        assert c["to_blow5"] > 0
 
 
 @pytest.mark.gpu

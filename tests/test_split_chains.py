@@ -322,10 +322,9 @@ def test_every_batch_samples_the_lane_order_and_fails_loudly(name, monkeypatch):
 def test_thousands_of_reads_per_worker(name, T, threads, monkeypatch):
     """>= 4096 reads on <= 4 workers, two batches (carried streams): `offset`, `median_before` and every sample equal the oracle's serial
     walk -- also when the per-read draws of staging are shared by the context's helper threads (from 8192 reads per batch on;
-    SQG_STAGE_THREADS forces it): a thread's range of the reads starts in the middle of a worker's chain, from the chain's streams moved past the reads before it
-    (a read takes a fixed number of draws from each)."""
-    if threads:
-        monkeypatch.setenv("SQG_STAGE_THREADS", threads)
+    sqg_set_stage_threads fixes the number): a thread's range of the reads starts in the middle of a worker's chain, from the chain's
+    streams moved past the reads before it (a read takes a fixed number of draws from each).  The call reports how many threads the
+    last staging used: the helper path must actually have run."""
     rng = np.random.default_rng(4242 + T)
     prof, fl = profiles.get_profile(name)
     k = profiles.default_kmer_size(fl)
@@ -335,13 +334,17 @@ def test_thousands_of_reads_per_worker(name, T, threads, monkeypatch):
     want = [orac.run_batch_seqs(bt, want_ss=False) for bt in batches]
     orac.close()
     gen = api.SignalGenerator(prof, fl, k, mean, stdv, 42, num_workers=T, mode=api.MODE_CERTIFIED)
+    assert gen.set_stage_threads(int(threads) if threads else 0) == 0          # nothing staged yet
     for bi, bt in enumerate(batches):
         b = gen.submit(bt)
+        assert gen.set_stage_threads(int(threads) if threads else 0) == (int(threads) if threads else 1)   # (automatic: one below 8192 reads)
         sig = b.signal()
         for i, w in enumerate(want[bi]):
             assert b.offset[i] == w.offset and b.median_before[i] == w.median_before, (bi, i)
             np.testing.assert_array_equal(sig[b.sig_off[i]:b.sig_off[i + 1]], w.sig, err_msg=f"batch {bi} read {i}")
         b.free()
+    with pytest.raises(api.SqgError):
+        gen.set_stage_threads(65)
     gen.close()
 
 
