@@ -261,6 +261,49 @@ def cpu_allowance():
     return aff, quota
 
 
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def pin_to_gpu_numa_node(device_index, local_rank, local_world):
+    """One process per GPU: keep this rank's host threads (the staging helpers, zlib) on the CPUs of the NUMA node its GPU hangs off,
+    and -- ranks that share a node -- on a slice of their own.  Best effort: returns what was done, or why nothing was."""
+    import torch
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            node = int(f.read())
+        if node < 0:
+            return {"pinned": False, "why": "the GPU reports no NUMA node", "pci": bdf}
+        with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+            cpus = sorted(set(_cpulist(f.read())) & set(os.sched_getaffinity(0)))
+        if not cpus:
+            return {"pinned": False, "why": "no usable CPU on the GPU's node", "pci": bdf, "numa_node": node}
+        # the ranks whose GPUs share this node (same answer on every one of them: the devices are enumerated alike)
+        mates = []
+        for d in range(min(local_world, torch.cuda.device_count())):
+            q = torch.cuda.get_device_properties(d)
+            try:
+                with open(f"/sys/bus/pci/devices/{q.pci_domain_id:04x}:{q.pci_bus_id:02x}:{q.pci_device_id:02x}.0/numa_node") as f:
+                    if int(f.read()) == node:
+                        mates.append(d)
+            except (OSError, ValueError):
+                pass
+        if device_index in mates and len(mates) > 1 and len(cpus) >= len(mates):
+            i, m = mates.index(device_index), len(mates)
+            cpus = cpus[len(cpus) * i // m:len(cpus) * (i + 1) // m]
+        os.sched_setaffinity(0, cpus)
+        return {"pinned": True, "pci": bdf, "numa_node": node, "cpus": len(cpus), "first_cpu": cpus[0]}
+    except (OSError, ValueError, AttributeError, RuntimeError) as e:
+        return {"pinned": False, "why": f"{type(e).__name__}: {e}"}
+
+
 def cpu_reference(prof, flags, k, mean, stdv, fasta_path, rlen, seconds=10.0):
     """The REFERENCE's own gensig.c/genread.c (oracle/_ref/ref_harness, compiled in the build container from the upstream
     sources where they lie), timed mode: every process loads the model and the FASTA, seeds its streams, then generates
@@ -489,6 +532,12 @@ def main():
                     help="initialise torch.distributed even for ONE rank (rendezvous on 127.0.0.1): the model broadcast, the barriers, the "
                          "reductions and -- with --job-workers -- the per-batch all-gather of the stream counts then run through the "
                          "chosen backend (nccl = RCCL) exactly as they do at N > 1 (tests: RCCL on a one-GPU box)")
+    ap.add_argument("--numa-pin", default="auto", choices=["auto", "on", "off"],
+                    help="keep the rank's host threads on the CPUs of its GPU's NUMA node (auto: when there is more than one rank and "
+                         "each has a GPU of its own)")
+    ap.add_argument("--genome-from-rank0", action="store_true",
+                    help="hg38-r10 / synth-r10 at N > 1: rank 0 alone makes (a real run: loads) the genome and broadcasts the bytes to the other "
+                         "GPUs -- one RCCL broadcast over xGMI -- instead of every rank synthesising its own copy (same bytes either way)")
     ap.add_argument("--digest", type=int, default=0,
                     help="D > 0 (tests): fetch every timed batch's signal and report, per batch, the sums of the reads' xxh64 digests "
                          "over D equal parts of the job's batch (N ranks report N*D/N parts each)")
@@ -522,6 +571,9 @@ def main():
     local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    pin = None
+    if args.numa_pin == "on" or (args.numa_pin == "auto" and world > 1 and args.backend == "nccl"):
+        pin = pin_to_gpu_numa_node(local_rank, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))   # before any helper thread exists
     use_dist = world > 1 or args.force_dist
     if use_dist:
         kw = {}
@@ -561,6 +613,15 @@ def main():
                               worker_lo=w_lo, worker_hi=w_hi)
     if range_mode:
         gen.set_range_mode(True)
+    # staging shares a batch's per-read libm draws with helper threads: this rank's share of the CPUs the job may use (the boxes of
+    # the pool: 16 for up to 8 ranks), four at most -- eight ranks x four threads would be twice the quota
+    aff, quota = cpu_allowance()
+    share = aff if (pin is not None and pin.get("pinned")) else aff // world      # (after pinning the affinity mask is this rank's own slice)
+    if quota:
+        share = min(share, int(quota) // world)
+    cpus_per_rank = max(1, share)
+    stage_threads = max(1, min(4, cpus_per_rank))
+    gen.set_stage_threads(stage_threads)
     # the phase events behind kernel_ms are barrier packets between the kernels (include/sqg.h, sqg_set_phase_timing): every
     # --timing-every'th batch carries them (short runs: every batch, so that the timed region holds timed launches)
     timing_every = max(1, args.timing_every) if args.steps >= 2 * max(1, args.timing_every) else 1
@@ -571,7 +632,18 @@ def main():
     sm = api.SAMPLE_RNA if wl_mode == "rna" else api.SAMPLE_DNA
     if args.workload in ("hg38-r10", "synth-r10"):
         mb = args.genome_mb if args.genome_mb is not None else (None if args.workload == "hg38-r10" else 64.0)
-        seq, lens = synthetic_genome_device(mb, dev)
+        if args.genome_from_rank0 and use_dist:
+            lens, _ = genome_layout(mb)
+            seq = synthetic_genome_device(mb, dev)[0] if rank == 0 else torch.empty(sum(lens), dtype=torch.uint8, device=dev)
+            if args.backend == "nccl":
+                dist.broadcast(seq, src=0)                             # RCCL over xGMI: the packed genome, once
+            else:
+                h = seq.cpu()
+                dist.broadcast(h, src=0)
+                seq.copy_(h)
+                del h
+        else:
+            seq, lens = synthetic_genome_device(mb, dev)
         torch.cuda.synchronize()
         gen.load_genome_device(seq.data_ptr(), lens, args.rlen, sm)
         genome_bases = int(sum(lens))
@@ -712,11 +784,14 @@ def main():
         sync_all()
 
     ptot = torch.tensor(list(pipe[:3]) if pipe else [0.0, 0.0, 1.0], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+    hst = torch.tensor([pipe[3] if pipe else 0.0, -(pipe[3] if pipe else 0.0)], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
     if use_dist:
         pmx = ptot.clone()
         dist.all_reduce(pmx, op=dist.ReduceOp.MAX)
         dist.all_reduce(ptot, op=dist.ReduceOp.SUM)
         ptot[2] = pmx[2]
+        dist.all_reduce(hst, op=dist.ReduceOp.MAX)                  # the slowest and (negated) the fastest rank's host time per batch
+    host_stage_max, host_stage_min = float(hst[0]), -float(hst[1])
 
     if rank == 0:
         steps = max(args.steps, 1)
@@ -765,11 +840,14 @@ def main():
                         "stale": lib_info.get("source_hash") != _build.source_hash()},
             # the N ranks' own clocks around the same K steps (value uses the slowest) and what torch.distributed says the world is
             "ranks": {"world_size": dist.get_world_size() if use_dist else 1, "backend": dist.get_backend() if use_dist else None,
+                      "numa_pin": pin, "genome": "broadcast from rank 0" if (args.genome_from_rank0 and use_dist) else "made on every rank",
                       "ms_per_step_min": dt_min / steps * 1e3, "ms_per_step_max": dt_max / steps * 1e3},
             "pipeline": None if pipe is None else {
                 "value": float(ptot[0]) / float(ptot[2]), "unit": "samples/s", "reads_per_s": float(ptot[1]) / float(ptot[2]),
                 "seconds": float(ptot[2]), "batches_per_gpu": n_pipe + 1, "ms_per_step": float(ptot[2]) / (n_pipe + 1) * 1e3,
-                "host_stage_ms_per_batch": pipe[3] * 1e3, "vs_value": float(ptot[0]) / float(ptot[2]) / (tot_samples / dt_max),
+                "host_stage_ms_per_batch": pipe[3] * 1e3, "host_stage_ms_per_batch_min": host_stage_min * 1e3,
+                "host_stage_ms_per_batch_max": host_stage_max * 1e3, "stage_threads": stage_threads, "cpus_per_rank": cpus_per_rank,
+                "vs_value": float(ptot[0]) / float(ptot[2]) / (tot_samples / dt_max),
                 "what": "nothing staged ahead: one host thread per GPU samples (device-side gen_read) + stages batch i+1, queues it, "
                         "waits for batch i and frees it; two batches in flight, results left in HBM"},
             "e2e": e2e,

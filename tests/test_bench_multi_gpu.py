@@ -52,6 +52,54 @@ def test_two_ranks_equal_one(name, single, dual):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,single,eight", [
+    # the node's size, by worker: -t 8 -K 2048, worker g = GPU g = the reads [256 g, 256 (g + 1)) of every batch
+    ("r10_by_worker", ["--genome-mb", 24, "--workers-per-gpu", 8, "--batch-reads", 2048, "--digest", 8],
+                      ["--genome-mb", 24, "--workers-per-gpu", 1, "--batch-reads", 256, "--digest", 1]),
+    # strict -t 1 over eight ranks: the 8-way all-gather of the stream counts, once per batch
+    ("r10_by_range", ["--genome-mb", 24, "--job-workers", 1, "--batch-reads", 2048, "--digest", 8],
+                     ["--genome-mb", 24, "--job-workers", 1, "--batch-reads", 256, "--digest", 1]),
+], ids=lambda v: v if isinstance(v, str) else None)
+def test_eight_ranks_equal_one(name, single, eight):
+    """world size 8 -- eight contexts, eight staging pools, shard.worker_range(r, 8, 8), the 8-way exchange -- sharing the box's GPU
+    (--backend gloo): read for read the single-rank run of the same job"""
+    one = _bench("--gpus", 1, *single)
+    many = _bench("--gpus", 8, "--backend", "gloo", *eight)
+    assert many["n_gpus"] == 8 and many["ranks"]["world_size"] == 8 and len(many["digest"]) == 2 and len(many["digest"][0]) == 8
+    assert one["digest"] == many["digest"], (one["digest"], many["digest"])
+    assert many["reads_per_s"] * many["ms_per_step"] * 1e-3 * many["steps"] == pytest.approx(2 * 2048, rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_eight_ranks_stream_on_the_box_cpu_quota():
+    """the streaming leg with eight ranks on the box's CPU quota (16 CPUs on the pool's boxes): every rank sizes its staging helpers
+    from its share of the quota (bench.py: sqg_set_stage_threads), reports its host time per batch, and the leg completes on every rank"""
+    d = _bench("--gpus", 8, "--backend", "gloo", "--genome-mb", 24, "--batch-reads", 512, "--workers-per-gpu", 1, "--pipeline-seconds", 0.5)
+    pl = d["pipeline"]
+    assert d["n_gpus"] == 8 and pl["value"] > 0 and pl["batches_per_gpu"] >= 9
+    assert 0 < pl["host_stage_ms_per_batch_min"] <= pl["host_stage_ms_per_batch"] <= pl["host_stage_ms_per_batch_max"]
+    assert 1 <= pl["stage_threads"] <= 4 and pl["cpus_per_rank"] >= 1
+
+
+@pytest.mark.gpu
+def test_genome_broadcast_from_rank0_and_numa_pin():
+    """SURVEY.md section 2, C1 at N > 1: rank 0 makes the genome, the other ranks receive its bytes (one broadcast); --numa-pin on keeps
+    a rank's host threads on its GPU's NUMA node.  Same reads, same signals as the plain run."""
+    args = ["--genome-mb", 24, "--workers-per-gpu", 1, "--batch-reads", 512, "--digest", 2]
+    plain = _bench("--gpus", 2, "--backend", "gloo", *args)
+    bc = _bench("--gpus", 2, "--backend", "gloo", "--genome-from-rank0", "--numa-pin", "on", *args)
+    assert plain["digest"] == bc["digest"]
+    assert bc["ranks"]["genome"] == "broadcast from rank 0" and plain["ranks"]["genome"] == "made on every rank"
+    pin = bc["ranks"]["numa_pin"]
+    assert isinstance(pin, dict) and (pin["pinned"] is True and pin["cpus"] >= 1 or pin["why"])
+    assert plain["ranks"]["numa_pin"] is None
+    rccl = _bench("--gpus", 1, "--force-dist", "--backend", "nccl", "--genome-from-rank0", "--genome-mb", 24, "--workers-per-gpu", 1,
+                  "--batch-reads", 1024, "--digest", 4)          # the broadcast through RCCL (one rank)
+    one = _bench("--gpus", 1, "--genome-mb", 24, "--workers-per-gpu", 1, "--batch-reads", 1024, "--digest", 4)
+    assert rccl["digest"] == one["digest"]
+
+
+@pytest.mark.gpu
 def test_gpus_flag_without_enough_devices_fails_loudly():
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):

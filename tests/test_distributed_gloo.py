@@ -1,4 +1,4 @@
-"""N>1 path on CPU: two processes over gloo.  Rank 0 owns the pore model and broadcasts it; every
+"""N>1 path on CPU: two -- and eight, the node's size -- processes over gloo.  Rank 0 owns the pore model and broadcasts it; every
 rank processes only the reads of the workers it owns (squigulator_amd.shard); gathering the shards
 must reproduce the single-process run bit for bit -- i.e. sharding workers over GPUs changes nothing.
 The per-rank compute stands in for the GPU kernel by calling the oracle (this is a test)."""
@@ -59,8 +59,8 @@ def _worker(rank, world, port, T, n_batches, K, out):
     o.close()
 
 
-@pytest.mark.parametrize("T,K", [(8, 8), (6, 13)])
-def test_two_rank_sharding_equals_single_process(T, K):
+@pytest.mark.parametrize("world,T,K", [(2, 8, 8), (2, 6, 13), (8, 8, 8), (8, 8, 21), (8, 11, 40)])
+def test_sharding_by_worker_equals_single_process(world, T, K):
     sys.path.insert(0, HERE)
     import orc
     from squigulator_amd import model, profiles, shard
@@ -68,10 +68,10 @@ def test_two_rank_sharding_equals_single_process(T, K):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, T, n_batches, K, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, T, n_batches, K, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = q.get(timeout=120)
+    got = q.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -127,9 +127,9 @@ def _range_worker(rank, world, port, T, K, out):
     o.close()
 
 
-@pytest.mark.parametrize("T,K", [(1, 9), (2, 7)])
-def test_range_sharding_exchange_gives_every_rank_the_counts_of_the_other_ranges(T, K):
-    """world size 2 over gloo: `before` is exactly what the reads ahead of a rank's range draw from each stream,
+@pytest.mark.parametrize("world,T,K", [(2, 1, 9), (2, 2, 7), (8, 1, 19), (8, 3, 8)])
+def test_range_sharding_exchange_gives_every_rank_the_counts_of_the_other_ranges(world, T, K):
+    """world sizes 2 and 8 over gloo (8: the all-gather of eight count vectors, a rank whose range is a single read): `before` is exactly what the reads ahead of a rank's range draw from each stream,
     `after` what the reads behind it draw"""
     sys.path.insert(0, HERE)
     import orc
@@ -137,10 +137,10 @@ def test_range_sharding_exchange_gives_every_rank_the_counts_of_the_other_ranges
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_range_worker, args=(r, 2, port, T, K, q)) for r in range(2)]
+    procs = [ctx.Process(target=_range_worker, args=(r, world, port, T, K, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(2)]
+    got = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
