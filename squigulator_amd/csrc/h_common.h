@@ -103,16 +103,13 @@ struct sqg_ctx {
     // event kernels of batch i+1 (stream) run while the sample kernels of batch i (stream2) are still busy.
     struct Slot {
         int16_t* d_sig = nullptr; size_t sig_cap = 0;
-        uint16_t* d_dwell = nullptr; size_t dwell_cap = 0;
-        unsigned long long* d_seglen = nullptr; long long* d_sigoff = nullptr; size_t reads_cap = 0;
-        size_t seglen_dirty = 0;      // reads whose seglen words may be non-zero (what a batch leaves behind unless its k_fixup zeroes them)
+        long long* d_sigoff = nullptr; size_t reads_cap = 0;
         FixEntry* d_fix = nullptr; size_t fix_cap = 0;
         unsigned int* d_fix_count = nullptr;       // [0] fix-up entries, [1] slow tiles, [2] entries that went through the lean kernel's lists
         FixEntry* d_fix_sh = nullptr; size_t fix_sh_cap = 0;   // the lean kernel's FIX_SHARDS lists (entries in all; sized by the batch)
         unsigned int fix_sh_per = 0;               // ... entries per list
         unsigned int* d_fix_sh_count = nullptr;    // ... their counters, FIX_SHARD_STRIDE words apart
         uint2* d_evrec = nullptr; size_t evrec_cap = 0;
-        uint32_t* d_tile_so = nullptr; size_t tile_cap = 0;
         int* d_slow = nullptr; size_t slow_cap = 0;
         ItemDesc* d_items = nullptr; size_t items_cap = 0;          // [n_stiles] work items of the lean kernel (k_items)
         uint32_t* d_part = nullptr; size_t part_cap = 0;            // [n_events] bucketed events (k_part.h).  Per slot: with one partition
@@ -127,6 +124,18 @@ struct sqg_ctx {
         hipEvent_t done = nullptr;                 // recorded after the slot's last kernel (fix-ups included)
         hipEvent_t sampled = nullptr;              // recorded on stream2 after the slot's sample kernels, before the fix-ups
     } slot[2];
+    // What a batch's FIRST event pass writes -- the dwells, the first sample of every 64-event tile, the reads' sample totals -- lives in
+    // one of THREE sets (batch run index % 3): the first pass of batch i+1 may run inside the launch sequence of batch i (k_part_hand_count,
+    // h_run.h: precount), while batch i-1's dwells -- sqg_fetch_dwell, sqg_result_t.d_dwell -- are still promised to the host.
+    struct CountSet {
+        uint16_t* d_dwell = nullptr; size_t dwell_cap = 0;
+        uint32_t* d_tile_so = nullptr; size_t tile_cap = 0;
+        unsigned long long* d_seglen = nullptr; size_t seglen_cap = 0;
+        size_t seglen_dirty = 0;      // reads whose seglen words may be non-zero (what a batch leaves behind unless its k_fixup zeroes them)
+        unsigned long long gen = 0;   // bumped whenever a batch starts writing the set
+    } cset[3];
+    unsigned int* d_phc_q = nullptr;               // k_part_hand_count: {next slice, next link, wavefronts that have left} (the last one zeroes them)
+    std::deque<sqg_batch*> staged_q;               // staged, not yet run, in staging order (the batch behind the one being run: precount)
     hipStream_t stream2 = nullptr;                 // the sample kernels (k_samples_lean, generic); == stream unless SQG_OVERLAP=1
     hipStream_t fix_stream = nullptr;              // the FP64 fix-ups of batch i (two small kernels) run next to k_events of batch i+1
     unsigned long long* d_scan_part = nullptr; size_t scan_part_cap = 0;   // k_scan: {ticket, total} per workgroup
@@ -238,6 +247,9 @@ struct sqg_batch {
     int wait_rc = 0;                     // what the first sqg_batch_wait returned (latched)
     unsigned long long slot_gen = 0;     // generation of the slot when this batch took it (results are stale once it differs)
     int slot = 0;                        // which of the context's two buffer sets this batch runs in
+    int cset = 0;                        // ... and which of the three sets of first-pass outputs (run index % 3)
+    unsigned long long cset_gen = 0;     // generation of that set when this batch took it
+    bool precounted = false;             // its first event pass was run inside the launch sequence of the batch before it (into cset)
     unsigned long long run_idx = 0;      // how many batches had been run before this one
     bool ran = false, waited = false, lean_timed = false, dwell_timed = false, fixup_launched = false;
     bool staged = false;                 // staging completed: the batch holds a place in the run order

@@ -37,11 +37,12 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->fix_stream) (void)hipStreamSynchronize(ctx->fix_stream);
     (void)hipFree(ctx->d_pcnt); (void)hipFree(ctx->d_slice); (void)hipFree(ctx->d_phist);
-    (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_scan_part); (void)hipFree(ctx->d_xcounts); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_samp_scratch); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err); (void)hipFree(ctx->d_mid_done);
+    (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_scan_part); (void)hipFree(ctx->d_xcounts); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_samp_scratch); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err); (void)hipFree(ctx->d_mid_done); (void)hipFree(ctx->d_phc_q);
+    for (auto& Q : ctx->cset) { (void)hipFree(Q.d_dwell); (void)hipFree(Q.d_tile_so); (void)hipFree(Q.d_seglen); }
     for (auto& S : ctx->slot) {
-        (void)hipFree(S.d_sig); (void)hipFree(S.d_dwell); (void)hipFree(S.d_seglen); (void)hipFree(S.d_sigoff);
+        (void)hipFree(S.d_sig); (void)hipFree(S.d_sigoff);
         (void)hipFree(S.d_fix); (void)hipFree(S.d_fix_count); (void)hipFree(S.d_fix_sh); (void)hipFree(S.d_fix_sh_count);
-        (void)hipFree(S.d_evrec); (void)hipFree(S.d_tile_so); (void)hipFree(S.d_slow);
+        (void)hipFree(S.d_evrec); (void)hipFree(S.d_slow);
         (void)hipFree(S.d_items); (void)hipFree(S.d_part_state); (void)hipFree(S.d_part); (void)hipFree(S.d_lbase); (void)hipFree(S.d_tile_link);
         if (S.done) (void)hipEventDestroy(S.done);
         if (S.sampled) (void)hipEventDestroy(S.sampled);
@@ -127,6 +128,8 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     CHK(hipMalloc(&c->d_err, sizeof(unsigned int)));
     CHK(hipMalloc(&c->d_mid_done, sizeof(unsigned int)));
     CHK(hipMemset(c->d_mid_done, 0, sizeof(unsigned int)));
+    CHK(hipMalloc(&c->d_phc_q, 4 * sizeof(unsigned int)));
+    CHK(hipMemset(c->d_phc_q, 0, 4 * sizeof(unsigned int)));
     CHK(hipMemset(c->d_err, 0, sizeof(unsigned int)));
     CHK(hipStreamCreateWithFlags(&c->stage_stream, hipStreamNonBlocking));
     // SQG_OVERLAP=1: the sample kernels get their own stream, so that the event kernels of the next batch run next to

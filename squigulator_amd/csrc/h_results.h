@@ -5,6 +5,9 @@
 // the slot's buffers still hold this batch's results (two batches later they do not: range mode bumps the generation as soon
 // as sqg_batch_run_begin of a later batch starts writing them)
 static bool slot_is_mine(const sqg_ctx* c, const sqg_batch* b) { return c->slot[b->slot].gen == b->slot_gen; }
+// ... and the set of first-pass outputs (dwells) this batch's (three batches later it does not: the first pass of batch i+3 may run
+// inside sqg_batch_run of batch i+2)
+static bool cset_is_mine(const sqg_ctx* c, const sqg_batch* b) { return c->cset[b->cset].gen == b->cset_gen; }
 
 extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
     if (!c || !b || !b->ran) return SQG_EINVAL;
@@ -55,7 +58,7 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
         res->n_reads = b->n; res->n_events = b->n_events; res->n_samples = b->n_samples; res->n_bases = b->n_bases;
         res->sig_off = (const int64_t*)b->sig_off.data(); res->ev_off = (const int64_t*)b->ev_off.data();
         res->offset = b->offset.data(); res->median_before = b->median.data();
-        res->d_signal = mine ? S.d_sig : nullptr; res->d_dwell = (mine && c->use_dwell_stream) ? S.d_dwell : nullptr;
+        res->d_signal = mine ? S.d_sig : nullptr; res->d_dwell = (mine && c->use_dwell_stream && cset_is_mine(c, b)) ? c->cset[b->cset].d_dwell : nullptr;
     }
     return SQG_OK;
 }
@@ -72,7 +75,7 @@ extern "C" int sqg_fetch_signal(sqg_ctx_t* c, sqg_batch_t* b, int16_t* dst) {
 
 extern "C" int sqg_fetch_dwell(sqg_ctx_t* c, sqg_batch_t* b, int32_t* dst) {
     if (!c || !b || !b->ran || !dst) return SQG_EINVAL;
-    if (b->run_idx + 2 < c->runs || !slot_is_mine(c, b)) return SQG_ESEQUENCE;
+    if (b->run_idx + 2 < c->runs || !slot_is_mine(c, b) || !cset_is_mine(c, b)) return SQG_ESEQUENCE;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipEventSynchronize(b->ev[4]));
     if (!c->use_dwell_stream) {
@@ -80,7 +83,7 @@ extern "C" int sqg_fetch_dwell(sqg_ctx_t* c, sqg_batch_t* b, int32_t* dst) {
         return SQG_OK;
     }
     std::vector<uint16_t> tmp((size_t)b->n_events);
-    if (b->n_events) HIPCHK(c, hipMemcpy(tmp.data(), c->slot[b->slot].d_dwell, tmp.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
+    if (b->n_events) HIPCHK(c, hipMemcpy(tmp.data(), c->cset[b->cset].d_dwell, tmp.size() * sizeof(uint16_t), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < tmp.size(); i++) dst[i] = tmp[i];
     return SQG_OK;
 }

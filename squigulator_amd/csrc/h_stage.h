@@ -10,7 +10,11 @@ extern "C" void sqg_batch_free(sqg_ctx_t* ctx, sqg_batch_t* b) {
     }
     // never run (or only begun): the batches staged after it must not wait for it.  Its share of the workers' scalar streams
     // is spent all the same: what follows is no longer the reference's sequence.
-    if (ctx && b->staged && !b->ran) { if (b->begun && ctx->stream) (void)hipStreamSynchronize(ctx->stream); ctx->abandoned.insert(b->seq); }
+    if (ctx && b->staged && !b->ran) {
+        if ((b->begun || b->precounted) && ctx->stream) (void)hipStreamSynchronize(ctx->stream);   // (its first pass may be running: it reads the batch's block)
+        ctx->abandoned.insert(b->seq);
+    }
+    if (ctx) for (auto it = ctx->staged_q.begin(); it != ctx->staged_q.end(); ++it) if (*it == b) { ctx->staged_q.erase(it); break; }
     if (ctx && !b->ran && ctx->stage_stream) (void)hipStreamSynchronize(ctx->stage_stream);   // its uploads may still be in flight
     if (b->h_svboff) (void)hipHostFree(b->h_svboff);
     if (ctx && b->d_block && b->h_sigoff && b->ev[0] && ctx->pool.size() < 4) {
@@ -31,20 +35,28 @@ extern "C" void sqg_batch_free(sqg_ctx_t* ctx, sqg_batch_t* b) {
 
 // Per-slot device buffers for a batch of this geometry.  with_output: also the signal slab and the fix-up list, sized
 // by the hard bound on the dwell (skipped when that bound is unreasonable; sqg_batch_run then reads the scan back).
+static int grow_cset(sqg_ctx* c, sqg_ctx::CountSet& Q, const sqg_batch* b) {
+    int rc2;
+    const size_t n = (size_t)b->n;
+    if (2 * (n + 1) > Q.seglen_cap) {
+        if ((rc2 = ensure(c, (void**)&Q.d_seglen, &Q.seglen_cap, 2 * (n + 1 + n / 2), sizeof(unsigned long long)))) return rc2;
+        Q.seglen_dirty = Q.seglen_cap / 2;                         // (fresh memory)
+    }
+    if ((rc2 = ensure(c, (void**)&Q.d_dwell, &Q.dwell_cap, (size_t)b->n_events + 1024, sizeof(uint16_t)))) return rc2;
+    if ((rc2 = ensure(c, (void**)&Q.d_tile_so, &Q.tile_cap, (size_t)b->n_tiles + 64, sizeof(uint32_t)))) return rc2;
+    return SQG_OK;
+}
 static int grow_slot(sqg_ctx* c, sqg_ctx::Slot& Z, const sqg_batch* b, bool with_output) {
     int rc2;
     const int n = b->n;
     const bool certified = c->cfg.mode == SQG_MODE_CERTIFIED;
     if ((size_t)n + 1 > Z.reads_cap) {
         HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2));
-        (void)hipFree(Z.d_seglen); (void)hipFree(Z.d_sigoff); Z.d_seglen = nullptr; Z.d_sigoff = nullptr;
+        (void)hipFree(Z.d_sigoff); Z.d_sigoff = nullptr;
         const size_t cap = (size_t)n + 1 + (size_t)n / 2;
-        HIPCHK(c, hipMalloc(&Z.d_seglen, 2 * cap * sizeof(unsigned long long)));
         HIPCHK(c, hipMalloc(&Z.d_sigoff, cap * sizeof(long long)));
         Z.reads_cap = cap;
-        Z.seglen_dirty = cap;                                      // (fresh memory)
     }
-    if ((rc2 = ensure(c, (void**)&Z.d_dwell, &Z.dwell_cap, (size_t)b->n_events + 1024, sizeof(uint16_t)))) return rc2;
     if ((rc2 = ensure(c, (void**)&Z.d_evrec, &Z.evrec_cap, (size_t)b->n_events + 64, sizeof(uint2)))) return rc2;
     if (b->part && (rc2 = ensure(c, (void**)&Z.d_part, &Z.part_cap, (size_t)b->n_events + PART_SLACK, sizeof(uint32_t)))) return rc2;
     if (b->part && b->pieces && !b->one) {
@@ -52,7 +64,6 @@ static int grow_slot(sqg_ctx* c, sqg_ctx::Slot& Z, const sqg_batch* b, bool with
         if ((rc2 = ensure(c, (void**)&Z.d_tile_link, &Z.tile_link_cap, (size_t)b->n_tiles + 64, sizeof(int)))) return rc2;
     }
     if (b->part && (rc2 = ensure(c, (void**)&Z.d_part_state, &Z.part_state_cap, (size_t)b->n_events + PART_SLACK, sizeof(uint32_t)))) return rc2;
-    if ((rc2 = ensure(c, (void**)&Z.d_tile_so, &Z.tile_cap, (size_t)b->n_tiles + 64, sizeof(uint32_t)))) return rc2;
     if ((rc2 = ensure(c, (void**)&Z.d_slow, &Z.slow_cap, (size_t)b->n_tiles + 64, sizeof(int)))) return rc2;
     if (certified && c->use_kmer_streams) {
         if ((rc2 = ensure(c, (void**)&Z.d_items, &Z.items_cap, (size_t)b->n_stiles + 64, sizeof(ItemDesc)))) return rc2;
@@ -527,6 +538,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         if (Z.reads_cap == 0 && n > 0) { const int rg = grow_slot(c, Z, b, /*with_output=*/true); if (rg) return bail(rg); }
     c->next_stage++;
     b->staged = true;
+    c->staged_q.push_back(b);
     *out = b;
     return SQG_OK;
 }

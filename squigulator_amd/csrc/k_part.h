@@ -512,32 +512,36 @@ __global__ __launch_bounds__(64) void k_part_hand(const uint32_t* __restrict__ p
 // fails (sqg_batch_wait: SQG_EDEVICE).  fault (tests: SQG_TEST_ORDER_FAULT=1): the first two rows' atomics are issued in the
 // wrong order, which the check has to notice.
 #define PART_CHECK 128
-__global__ __launch_bounds__(64) void k_part_hand_ord(const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out,
-                                                      const uint32_t* __restrict__ slice_lo, const uint32_t* __restrict__ slice_hi,
-                                                      const uint32_t* __restrict__ n_slices,
-                                                      const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pw,
-                                                      unsigned int* __restrict__ err, const int fault) {
-    __shared__ uint32_t base[PART_SUB];                           // the streams' states as the slice finds them
-    __shared__ uint32_t cnt[PART_SUB];                            // samples handed out so far
-    __shared__ uint4 chk[PART_CHECK / 4];                         // the slice's first events, for the order check
-    __shared__ uint32_t lt0[PART_LT], lt1[PART_LT], lt2[PART_LT]; // a^(2j), a^(2 * 256 j), a^(2 * 65536 j), DOUBLED (lcg_mul_dbl)
-    constexpr int NR = HAND_STEP / 64;                            // records per lane and step
-    const int lane = threadIdx.x;
-    if (blockIdx.x >= *n_slices) return;
-    const uint4* src = reinterpret_cast<const uint4*>(phist + (size_t)blockIdx.x * PART_SUB);
-    for (int i = lane; i < PART_SUB / 4; i += 64) { reinterpret_cast<uint4*>(base)[i] = src[i]; reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0u, 0u, 0u, 0u); }
-    for (int i = lane; i < PART_LT; i += 64) {
-        lt0[i] = pw[2 * POW_N + i] << 1;
-        lt1[i] = ((i & 3) ? lcg_mul(pw[3 * POW_N + (i >> 2)], pw[2 * POW_N + 256 * (i & 3)]) : pw[3 * POW_N + (i >> 2)]) << 1;
-        lt2[i] = ((i & 15) ? lcg_mul(pw[4 * POW_N + (i >> 4)], pw[3 * POW_N + 64 * (i & 15)]) : pw[4 * POW_N + (i >> 4)]) << 1;
+struct HandLds {
+    uint32_t base[PART_SUB];                                      // the streams' states as the slice finds them
+    uint32_t cnt[PART_SUB];                                       // samples handed out so far
+    uint4 chk[PART_CHECK / 4];                                    // the slice's first events, for the order check
+    uint32_t lt0[PART_LT], lt1[PART_LT], lt2[PART_LT];            // a^(2j), a^(2 * 256 j), a^(2 * 65536 j), DOUBLED (lcg_mul_dbl)
+};
+__device__ static inline void hand_tables(HandLds& H, const uint32_t* __restrict__ pw, const int tid, const int nthreads) {
+    for (int i = tid; i < PART_LT; i += nthreads) {
+        H.lt0[i] = pw[2 * POW_N + i] << 1;
+        H.lt1[i] = ((i & 3) ? lcg_mul(pw[3 * POW_N + (i >> 2)], pw[2 * POW_N + 256 * (i & 3)]) : pw[3 * POW_N + (i >> 2)]) << 1;
+        H.lt2[i] = ((i & 15) ? lcg_mul(pw[4 * POW_N + (i >> 4)], pw[3 * POW_N + 64 * (i & 15)]) : pw[4 * POW_N + (i >> 4)]) << 1;
     }
-    const uint32_t lo = slice_lo[blockIdx.x], hi = slice_hi[blockIdx.x];
+}
+// One slice, one wavefront (H.lt* filled and visible).  No workgroup barrier inside: LDS instructions of a wavefront execute in order,
+// the fences keep the compiler from moving them.
+__device__ static __forceinline__ void hand_slice(HandLds& H, const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out, const uint32_t lo, const uint32_t hi,
+                                                  const uint32_t* __restrict__ phist_row, const uint32_t* __restrict__ pw, unsigned int* __restrict__ err, const int fault, const int lane) {
+    constexpr int NR = HAND_STEP / 64;                            // records per lane and step
+    uint32_t* const base = H.base; uint32_t* const cnt = H.cnt; uint4* const chk = H.chk;
+    uint32_t* const lt0 = H.lt0; uint32_t* const lt1 = H.lt1; uint32_t* const lt2 = H.lt2;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // (the slice before this one has read its tables)
+    const uint4* src = reinterpret_cast<const uint4*>(phist_row);
+    for (int i = lane; i < PART_SUB / 4; i += 64) { reinterpret_cast<uint4*>(base)[i] = src[i]; reinterpret_cast<uint4*>(cnt)[i] = make_uint4(0u, 0u, 0u, 0u); }
     const uint32_t* in = part + lo + lane;                          // (one address register; the records of a step sit at constant offsets)
     uint32_t* out_p = state_out + lo + lane;
     uint32_t cur[NR], nxt[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) cur[r] = in[64 * r];               // (unconditional: PART_SLACK entries behind the last slice)
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     // one step: event 64 r + lane is the lane's r-th -- instruction order, then lane order
     auto step = [&](auto full_tag, auto check_tag, const uint32_t left) {
         constexpr bool FULL = decltype(full_tag)::value, CHECK = decltype(check_tag)::value;
@@ -621,6 +625,18 @@ __global__ __launch_bounds__(64) void k_part_hand_ord(const uint32_t* __restrict
     else if (b < hi) { step(std::false_type{}, std::true_type{}, hi - b); b = hi; }
     for (; b + HAND_STEP <= hi; b += HAND_STEP) step(std::true_type{}, std::false_type{}, 0u);
     if (b < hi) step(std::false_type{}, std::false_type{}, hi - b);
+}
+
+__global__ __launch_bounds__(64) void k_part_hand_ord(const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out,
+                                                      const uint32_t* __restrict__ slice_lo, const uint32_t* __restrict__ slice_hi,
+                                                      const uint32_t* __restrict__ n_slices,
+                                                      const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pw,
+                                                      unsigned int* __restrict__ err, const int fault) {
+    __shared__ HandLds H;
+    const int lane = threadIdx.x;
+    if (blockIdx.x >= *n_slices) return;
+    hand_tables(H, pw, lane, 64);
+    hand_slice(H, part, state_out, slice_lo[blockIdx.x], slice_hi[blockIdx.x], phist + (size_t)blockIdx.x * PART_SUB, pw, err, fault, lane);
 }
 
 // Are the lanes of one LDS atomic that meet on an address served in ascending lane order, and successive instructions in

@@ -56,12 +56,18 @@ struct PevWave {
     uint32_t ring[SCATTER ? PART_MAX * PEV_RING : 1];    // (a segment that does not fit the rings borrows them as its sort buffer)
     uint2 tasks[SCATTER ? PEV_TASKS : 1];                // lines to write: {line, partition | first element << 8 | end element << 16}
 };
-template <bool SCATTER>
-struct PevLds {
+struct PevTables {                        // read-only, shared by the wavefronts of a workgroup
     uint32_t jump[256];                  // 2 * a^(2j)
     uint8_t lut[256];                    // base -> 2-bit code (src/seq.h:14-27)
+};
+template <bool SCATTER>
+struct PevLds {
+    PevTables t;
     PevWave<SCATTER> w[SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES];
 };
+__device__ static inline void pev_tables(PevTables& T, const uint32_t* __restrict__ pw, const int tid, const int nthreads) {
+    for (int i = tid; i < 256; i += nthreads) { T.jump[i] = pw[2 * POW_N + i] << 1; T.lut[i] = (uint8_t)base_code((uint8_t)i); }   // (doubled: lcg_mul_dbl)
+}
 
 // sum over the wavefront, in every lane's SGPR-to-be
 __device__ static inline int pev_wave_sum(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_dpp(v), 63); }
@@ -80,18 +86,13 @@ __device__ static inline void pev_wave_sum4(int (&v)[4]) {
 #define PEV_COUNT 0
 #define PEV_SCATTER 1
 #define PEV_ONE 2
+// One link, one wavefront: link li of the launch order (P.chain_order), tables T (pev_tables), wave-private LDS W.  No workgroup
+// barrier inside: the wavefronts of a workgroup -- of k_part_events, or of a kernel that runs links next to other work
+// (k_part_hand_count, below) -- walk their links independently.
 template <int DW, int MODE>
-__global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES), MODE == PEV_SCATTER ? 1 : PEV_COUNT_OCC) void k_part_events(const SigParams P, const int n_links, const uint32_t dump) {
+__device__ static __forceinline__ void pev_link(const SigParams& P, const PevTables& L, PevWave<MODE == PEV_SCATTER>& W, const int li, const uint32_t dump, const int lane) {
     constexpr bool SCATTER = MODE == PEV_SCATTER, ONE = MODE == PEV_ONE;
-    constexpr int NWV = SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES;
     static_assert(!SCATTER || DW == 0, "the second pass reads the dwells the first one drew");
-    __shared__ PevLds<SCATTER> L;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int i = tid; i < 256; i += 64 * NWV) { L.jump[i] = P.pw[2 * POW_N + i] << 1; L.lut[i] = (uint8_t)base_code((uint8_t)i); }   // (doubled: lcg_mul_dbl)
-    __syncthreads();
-    const int li = blockIdx.x * NWV + wid;
-    if (li >= n_links) return;                                    // (no barrier below)
-    PevWave<SCATTER>& W = L.w[wid];
     const int chain = P.chain_order[li];
     const int c_lo = P.chain_off[chain], c_hi = P.chain_off[chain + 1];
     const int k = P.k;
@@ -372,6 +373,74 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
     }
     if (SCATTER) flush(W.flu[lane], W.wslot[lane]);                 // what is left in the rings: each partition's last, partial line
     if (MODE == PEV_COUNT && lane < P.n_part) P.pcnt[(size_t)lane * P.n_links + chain] = W.wslot[lane];
+}
+
+template <int DW, int MODE>
+__global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES), MODE == PEV_SCATTER ? 1 : PEV_COUNT_OCC) void k_part_events(const SigParams P, const int n_links, const uint32_t dump) {
+    constexpr bool SCATTER = MODE == PEV_SCATTER;
+    constexpr int NWV = SCATTER ? PEV_WAVES_SCATTER : PEV_WAVES;
+    __shared__ PevLds<SCATTER> L;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    pev_tables(L.t, P.pw, tid, 64 * NWV);
+    __syncthreads();
+    const int li = blockIdx.x * NWV + wid;
+    if (li >= n_links) return;                                    // (no barrier below)
+    pev_link<DW, MODE>(P, L.t, L.w[wid], li, dump, lane);
+}
+
+// ---- the hand-out of batch i and the counting pass of batch i+1 in ONE launch ---------------------------------------------
+// k_part_hand_ord is bound by the 1.4 GB it moves, at one wavefront per SIMD (a slice's two 16-KiB tables leave room for four per
+// CU); the counting pass is bound by the VALU (the dwells' Box-Muller draws) and needs nothing but the staged reads of its batch.
+// Queued one behind the other each leaves idle what the other wants; kernels of two queues share this GPU worse than they follow
+// each other.  So, when the next batch is staged by the time a batch is run (sqg_batch_run, h_run.h): a persistent grid of
+// four workgroups per CU, in each ONE wavefront that takes slices of batch i (hand_slice) and THREE that take links of batch i+1
+// (pev_link<DW, COUNT>), both from a queue (a counter each: a wavefront that finishes takes the next), the hand-out wavefront on a
+// different SIMD in each of a CU's workgroups.  16 wavefronts per CU: what the counting pass' registers allow.
+//   q[0], q[1]  next slice, next link (zero at launch; the LAST wavefront to leave zeroes them again: q[2] counts the leavers)
+#define PHC_COUNT_WAVES 3
+__device__ static inline uint32_t phc_grab(unsigned int* ctr, const int lane) {
+    unsigned int v = 0;
+    if (lane == 0) v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+template <int DW>
+__global__ __launch_bounds__(64 * (1 + PHC_COUNT_WAVES), 1) void k_part_hand_count(
+        const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out, const uint32_t* __restrict__ slice_lo, const uint32_t* __restrict__ slice_hi,
+        const uint32_t* __restrict__ n_slices, const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pw, unsigned int* __restrict__ err, const int fault,
+        const SigParams Pn, const int n_links_n, const uint32_t dump_n, unsigned int* __restrict__ q) {
+    __shared__ HandLds H;
+    __shared__ PevTables T;
+    __shared__ PevWave<false> W[PHC_COUNT_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    hand_tables(H, pw, tid, 64 * (1 + PHC_COUNT_WAVES));
+    pev_tables(T, Pn.pw, tid, 64 * (1 + PHC_COUNT_WAVES));
+    __syncthreads();
+    // (workgroups 256 apart are the ones a CU holds together when 1024 of them are dispatched round-robin: XCD, then CU)
+    const int hw = (int)((blockIdx.x >> 8) & 3u) % (1 + PHC_COUNT_WAVES);
+    if (wid == hw) {
+        const uint32_t ns = *n_slices;
+        for (;;) {
+            const uint32_t sl = phc_grab(q, lane);
+            if (sl >= ns) break;
+            hand_slice(H, part, state_out, slice_lo[sl], slice_hi[sl], phist + (size_t)sl * PART_SUB, pw, err, fault, lane);
+        }
+    } else {
+        PevWave<false>& Wm = W[wid - (wid > hw ? 1 : 0)];
+        for (;;) {
+            const uint32_t li = phc_grab(q + 1, lane);
+            if (li >= (uint32_t)n_links_n) break;
+            pev_link<DW, PEV_COUNT>(Pn, T, Wm, (int)li, dump_n, lane);
+        }
+    }
+    if (lane == 0) {
+        const unsigned int gone = __hip_atomic_fetch_add(q + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone + 1u == gridDim.x * (1u + PHC_COUNT_WAVES)) {       // (everybody else has stopped asking: for the next launch, which the stream orders)
+            __hip_atomic_store(q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(q + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(q + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // Reads cut into several pieces: the first pass wrote every piece's tile offsets relative to the piece's own first sample; the pieces

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <mutex>
 #include <new>
