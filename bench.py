@@ -402,26 +402,29 @@ def parity_check(prof, flags, k, mean, stdv, contigs, rlen, n_reads, one_worker,
 
 
 def pipeline_leg(stage_one, run, n_batches):
-    """Nothing staged ahead: ONE host thread samples + stages batch i+1 (device-side gen_read, descriptors, links), queues it, waits
-    for batch i and frees it -- two batches in flight, results left in HBM.  Returns (samples, reads, seconds, host seconds spent
-    in the sampler + staging call per batch)."""
+    """Nothing staged ahead but the batch behind the one being queued: ONE host thread samples + stages batch i+2 (device-side gen_read,
+    descriptors, links), queues batch i+1 -- the library lets the first event pass of the staged batch behind it ride along with its
+    hand-out (include/sqg.h, sqg_batch_run) --, waits for batch i and frees it.  Two batches in flight, one staged, results left in HBM.
+    Returns (samples, reads, seconds, host seconds spent in the sampler + staging call per batch)."""
     cur = run(stage_one())
+    nxt = stage_one()
     samples = reads = 0
     t_stage = 0.0
     t0 = time.perf_counter()
     for _ in range(n_batches):
         a = time.perf_counter()
-        nxt = stage_one()
+        nn = stage_one()
         t_stage += time.perf_counter() - a
         run(nxt)
         cur.wait()
         samples += cur.n_samples; reads += cur.n_reads
         cur.free()
-        cur = nxt
+        cur, nxt = nxt, nn
     cur.wait()
     samples += cur.n_samples; reads += cur.n_reads
     dt = time.perf_counter() - t0
     cur.free()
+    nxt.free()                                                   # (staged, never run)
     return samples, reads, dt, t_stage / max(n_batches, 1)
 
 
@@ -848,8 +851,8 @@ def main():
                 "host_stage_ms_per_batch": pipe[3] * 1e3, "host_stage_ms_per_batch_min": host_stage_min * 1e3,
                 "host_stage_ms_per_batch_max": host_stage_max * 1e3, "stage_threads": stage_threads, "cpus_per_rank": cpus_per_rank,
                 "vs_value": float(ptot[0]) / float(ptot[2]) / (tot_samples / dt_max),
-                "what": "nothing staged ahead: one host thread per GPU samples (device-side gen_read) + stages batch i+1, queues it, "
-                        "waits for batch i and frees it; two batches in flight, results left in HBM"},
+                "what": "nothing staged ahead but one batch: one host thread per GPU samples (device-side gen_read) + stages batch i+2, queues batch i+1, "
+                        "waits for batch i and frees it; two batches in flight, one staged, results left in HBM"},
             "e2e": e2e,
             "reads_per_s": tot_reads / dt_max,
             # samples the fp32 path left to FP64, over the batches whose counters were still theirs when they were waited for

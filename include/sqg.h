@@ -157,7 +157,11 @@ const char *sqg_build_info(void);
 int  sqg_batch_stage(sqg_ctx_t *ctx, int32_t n_reads, const char *seqs,
                      const int64_t *seq_off, const int32_t *worker, sqg_batch_t **out);
 /* Launch the kernels for a staged batch (asynchronous on the context stream).
- * Batches must be run in the order they were staged. */
+ * Batches must be run in the order they were staged.
+ * If the NEXT batch is already staged when this one is run (few workers, k > 6: the bucketed hand-out), its first event pass --
+ * the dwell draws of src/gensig.c:254-257, which need nothing but the staged reads -- is launched inside this batch's sequence,
+ * sharing the GPU with this batch's stream hand-out (one is bound by the VALU, the other by memory).  A host that wants it stages
+ * batch i+1 before it runs batch i; nothing else changes: results, order, and what stays valid for how long. */
 int  sqg_batch_run(sqg_ctx_t *ctx, sqg_batch_t *b);
 /* Block until the batch has finished; fills *res. */
 int  sqg_batch_wait(sqg_ctx_t *ctx, sqg_batch_t *b, sqg_result_t *res);

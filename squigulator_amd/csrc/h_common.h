@@ -134,6 +134,7 @@ struct sqg_ctx {
         size_t seglen_dirty = 0;      // reads whose seglen words may be non-zero (what a batch leaves behind unless its k_fixup zeroes them)
         unsigned long long gen = 0;   // bumped whenever a batch starts writing the set
     } cset[3];
+    int num_cu = 256;                              // compute units of the device
     unsigned int* d_phc_q = nullptr;               // k_part_hand_count: {next slice, next link, wavefronts that have left} (the last one zeroes them)
     std::deque<sqg_batch*> staged_q;               // staged, not yet run, in staging order (the batch behind the one being run: precount)
     hipStream_t stream2 = nullptr;                 // the sample kernels (k_samples_lean, generic); == stream unless SQG_OVERLAP=1

@@ -128,6 +128,7 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     CHK(hipMalloc(&c->d_err, sizeof(unsigned int)));
     CHK(hipMalloc(&c->d_mid_done, sizeof(unsigned int)));
     CHK(hipMemset(c->d_mid_done, 0, sizeof(unsigned int)));
+    { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) c->num_cu = ncu; }
     CHK(hipMalloc(&c->d_phc_q, 4 * sizeof(unsigned int)));
     CHK(hipMemset(c->d_phc_q, 0, 4 * sizeof(unsigned int)));
     CHK(hipMemset(c->d_err, 0, sizeof(unsigned int)));

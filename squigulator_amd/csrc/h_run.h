@@ -3,6 +3,20 @@
 #pragma once
 
 // (sqg_batch_run_end), `before` / `after` being what the other ranges of the batch draw from each stream
+// what the first event pass of a batch (pev_link<DW, COUNT>) reads and writes: filled the same way for the batch being run and for the
+// batch behind it, whose pass may ride along with this batch's hand-out (precount below)
+static void count_params(sqg_ctx* c, const sqg_batch* b, sqg_ctx::CountSet& Q, const int n_part, SigParams& P) {
+    const sqg_profile_t& p = c->cfg.profile;
+    P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.chain_order = b->d_chain_order; P.bases = b->d_bases;
+    P.dwell = c->use_dwell_stream ? Q.d_dwell : nullptr; P.dwell_out = Q.d_dwell; P.seglen_out = Q.d_seglen; P.seglen = Q.d_seglen; P.tile_so = Q.d_tile_so;
+    P.dmean = p.dwell_mean; P.dstd = p.dwell_std; P.pw = c->d_pow; P.err = b->d_err; P.delta_x = c->delta_x;
+    P.k = c->k; P.num_kmer = c->num_kmer; P.const_sps = (int)p.dwell_mean;
+    P.dwell_unbounded = c->dwell_hi > 65535.0 ? 1 : 0;
+    P.dwell_pack = c->dwell_hi < 1024.0 ? 1 : 0;
+    P.pieces = b->d_pieces; P.piece_total = b->d_piece_total;
+    P.pcnt = c->d_pcnt; P.n_part = n_part; P.n_links = b->n_chains;
+}
+
 static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* before, const uint32_t* after) {
     if (!c || !b) return SQG_EINVAL;
     if (phase != 2) skip_abandoned(c);
@@ -13,9 +27,15 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     const int n = b->n;
     const bool certified = c->cfg.mode == SQG_MODE_CERTIFIED;
     int rc;
-    if (phase != 2) b->run_idx = c->runs;
+    if (phase != 2) {
+        b->run_idx = c->runs;
+        for (auto it = c->staged_q.begin(); it != c->staged_q.end(); ++it) if (*it == b) { c->staged_q.erase(it); break; }
+        if (b->precounted && b->cset != (int)(b->run_idx % 3)) b->precounted = false;     // (cannot happen: the batch behind the one that ran is this one)
+        if (!b->precounted) { b->cset = (int)(b->run_idx % 3); b->cset_gen = ++c->cset[b->cset].gen; }   // from here on the set's buffers belong to this batch
+    }
     b->slot = (int)(b->run_idx & 1);
     sqg_ctx::Slot& S = c->slot[b->slot];
+    sqg_ctx::CountSet& Q = c->cset[b->cset];
     if (phase != 2) b->slot_gen = ++S.gen;                      // from here on the slot's buffers belong to this batch
     sqg_ctx::Slot& other = c->slot[b->slot ^ 1];
     if (phase != 2) {
@@ -26,6 +46,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         b->other_fresh = other.reads_cap == 0 && n > 0;
         if ((rc = grow(S))) return rc;
         if (b->other_fresh && (rc = grow(other))) return rc;
+        if ((rc = grow_cset(c, Q, b))) return rc;
     }
     const bool other_fresh = b->other_fresh;
 
@@ -65,21 +86,16 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     P.part = S.d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = c->d_pcnt; P.poff = b->one ? b->d_link_slot : c->d_pcnt ? c->d_pcnt + (size_t)b->n_chains * n_part : nullptr; P.n_part = n_part; P.n_links = b->n_chains;
     P.link_q = b->d_link_q; P.pieces = b->d_pieces; P.piece_total = b->d_piece_total;
     P.one = b->one ? 1 : 0;
-    P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.bases = b->d_bases;
-    P.dwell = c->use_dwell_stream ? S.d_dwell : nullptr; P.dwell_out = S.d_dwell; P.seglen_out = S.d_seglen;
-    P.dmean = p.dwell_mean; P.dstd = p.dwell_std;
-    P.seglen = S.d_seglen; P.sig_off = S.d_sigoff; P.model = c->d_model; P.pw = c->d_pow; P.rows = c->d_rows;
+    count_params(c, b, Q, n_part, P);
+    P.sig_off = S.d_sigoff; P.model = c->d_model; P.pw = c->d_pow; P.rows = c->d_rows;
     P.seed_base = canon((long long)c->cfg.seed + (long long)c->wlo * ((long long)c->num_kmer + 10)); P.seed_step = canon((long long)c->num_kmer + 10);
-    P.err = b->d_err; P.dig = p.digitisation; P.range = p.range; P.kd = p.digitisation / p.range;
-    P.chain_order = b->d_chain_order; P.delta_x = c->delta_x; P.thr_all = c->thr_all;
-    P.k = c->k; P.num_kmer = c->num_kmer; P.const_sps = (int)p.dwell_mean;
+    P.dig = p.digitisation; P.range = p.range; P.kd = p.digitisation / p.range;
+    P.thr_all = c->thr_all;
     P.meth = (c->cfg.flags & SQG_METH) ? 1 : 0; P.num_kmer_pad = kmer_pad;
     P.meth_top = 1; for (int i = 1; i < c->k; i++) P.meth_top *= 5u;
     P.use_streams = c->use_kmer_streams ? 1 : 0;
-    P.dwell_unbounded = c->dwell_hi > 65535.0 ? 1 : 0;
-    P.dwell_pack = c->dwell_hi < 1024.0 ? 1 : 0;
     P.rna = (c->cfg.flags & SQG_RNA) ? 1 : 0;
-    P.evrec = S.d_evrec; P.tile_so = S.d_tile_so;
+    P.evrec = S.d_evrec;
     // bucketed hand-out with the wavefront-per-link passes: 4 B per event between the scatter pass and the sample kernels (k_part_events.h)
     if (b->part && b->pieces && !b->one) { P.evrec32 = reinterpret_cast<uint32_t*>(S.d_evrec); P.lbase = S.d_lbase; P.tile_link = S.d_tile_link; } P.tile_read = b->d_tile_read; P.stile_read = b->d_stile_read;
     constexpr int NT = SQG_EVENT_THREADS, NT_WIDE = 1024;
@@ -109,19 +125,19 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         if (!untimed) HIPCHK(c, hipEventRecord(b->ev[0], c->stream));
         if (n > 0) {
             if (c->use_dwell_stream && !inline_dwell) {
-                HIPCHK(c, hipMemsetAsync(S.d_seglen, 0, (size_t)2 * n * sizeof(unsigned long long), c->stream));
+                HIPCHK(c, hipMemsetAsync(Q.d_seglen, 0, (size_t)2 * n * sizeof(unsigned long long), c->stream));
                 const long long nblk = (b->n_events + DW_EPB - 1) / DW_EPB;
                 if (nblk > 0) {
                     if (certified)
                         hipLaunchKernelGGL(k_dwell<1>, dim3((unsigned)nblk), dim3(256), 0, c->stream, b->d_reads, n, b->d_blk_read,
-                                           b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, c->delta_x, S.d_dwell, S.d_seglen, b->d_err);
+                                           b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, c->delta_x, Q.d_dwell, Q.d_seglen, b->d_err);
                     else
                         hipLaunchKernelGGL(k_dwell<0>, dim3((unsigned)nblk), dim3(256), 0, c->stream, b->d_reads, n, b->d_blk_read,
-                                           b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, 0.f, S.d_dwell, S.d_seglen, b->d_err);
+                                           b->n_events, c->d_pow, p.dwell_mean, p.dwell_std, 0.f, Q.d_dwell, Q.d_seglen, b->d_err);
                 }
                 if ((rc = dbg_sync(c, "k_dwell"))) return rc;
             } else if (!c->use_dwell_stream) {
-                HIPCHK(c, hipMemcpyAsync(S.d_seglen, b->seglen_host.data(), (size_t)2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(Q.d_seglen, b->seglen_host.data(), (size_t)2 * n * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
             }
         }
         b->dwell_timed = c->use_dwell_stream && !inline_dwell && !untimed;        // stand-alone k_dwell (A/B runs): two more timing events
@@ -157,12 +173,14 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         if (b->part) {
             // k > 6, split chains: the hand-out over events bucketed by the top bits of the rank (k_part.h)
             if (phase != 2) {
-                if (b->split_reads && dw && S.seglen_dirty > 0) {   // pieces add up; (usually the slot's previous batch has left the words zero: k_fixup)
-                    HIPCHK(c, hipMemsetAsync(S.d_seglen, 0, (size_t)2 * std::max<size_t>((size_t)n, S.seglen_dirty) * sizeof(unsigned long long), c->stream));
-                    S.seglen_dirty = 0;
+                if (!b->precounted) {                             // (else: the pass ran next to the hand-out of the batch before this one)
+                    if (b->split_reads && dw && Q.seglen_dirty > 0) {   // pieces add up; (usually the set's previous batch has left the words zero: k_fixup)
+                        HIPCHK(c, hipMemsetAsync(Q.d_seglen, 0, (size_t)2 * std::max<size_t>((size_t)n, Q.seglen_dirty) * sizeof(unsigned long long), c->stream));
+                        Q.seglen_dirty = 0;
+                    }
+                    if (b->split_reads && dw) Q.seglen_dirty = (size_t)n;   // (until this batch's k_fixup is queued: a run that fails half-way leaves them dirty)
+                    launch_part_events(dw, true);                 // dwell draws; events per (link, partition)
                 }
-                if (b->split_reads && dw) S.seglen_dirty = (size_t)n;   // (until this batch's k_fixup is queued: a run that fails half-way leaves them dirty)
-                launch_part_events(dw, true);                     // dwell draws; events per (link, partition)
                 const bool mid_split = SQG_DEV_ENV("SQG_MID_SPLIT") != nullptr;   // A/B: the four small kernels between the passes, one by one
                 if (b->split_reads && (b->one || mid_split)) hipLaunchKernelGGL(k_part_tile_bases, dim3((unsigned)b->n_pieces), dim3(64), 0, c->stream, P);
                 if (b->one) {
@@ -211,7 +229,47 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                     else hipLaunchKernelGGL(k_rows_advance<false>, ag, dim3(256), 0, c->stream, c->d_rows, c->d_pow, n_rows, before, c->d_xcounts, after);
                 }
                 const int order_fault = SQG_DEV_ENV("SQG_TEST_ORDER_FAULT") ? 1 : 0;         // (tests: the per-batch order check has to fire)
-                if (c->lds_ordered) hipLaunchKernelGGL(k_part_hand_ord, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, b->d_err, order_fault);
+                // precount: the batch staged behind this one, if its first event pass can ride along with this batch's hand-out
+                // (k_part_hand_count, k_part_events.h): same kind of batch, nothing in between, the plain launch sequence
+                sqg_batch* nb = nullptr;
+                if (phase == 0 && c->lds_ordered && wave_links && !b->one && dw != 0 && !c->range_mode && !c->staged_q.empty() && !SQG_DEV_ENV("SQG_NO_PRECOUNT")) {
+                    sqg_batch* cand = c->staged_q.front();
+                    if (cand->seq > b->seq && cand->staged && !cand->ran && !cand->begun && !cand->precounted && cand->part && cand->pieces && !cand->one &&
+                        cand->n > 0 && cand->n_chains > 0) nb = cand;
+                }
+                if (nb) {
+                    const int ncs = (int)((b->run_idx + 1) % 3);
+                    sqg_ctx::CountSet& NQ = c->cset[ncs];
+                    if ((rc = grow_cset(c, NQ, nb))) return rc;
+                    if ((rc = ensure(c, (void**)&c->d_pcnt, &c->pcnt_cap, (size_t)2 * nb->n_chains * (size_t)n_part, sizeof(uint32_t)))) return rc;
+                    if (nb->ev_staged && hipEventQuery(nb->ev_staged) != hipSuccess) HIPCHK(c, hipStreamWaitEvent(c->stream, nb->ev_staged, 0));
+                    if (nb->split_reads && NQ.seglen_dirty > 0) {
+                        HIPCHK(c, hipMemsetAsync(NQ.d_seglen, 0, (size_t)2 * std::max<size_t>((size_t)nb->n, NQ.seglen_dirty) * sizeof(unsigned long long), c->stream));
+                        NQ.seglen_dirty = 0;
+                    }
+                    if (nb->split_reads) NQ.seglen_dirty = (size_t)nb->n;
+                    SigParams Pn;
+                    memset(&Pn, 0, sizeof Pn);
+                    count_params(c, nb, NQ, n_part, Pn);
+                    const dim3 fg((unsigned)(dev_env_int(SQG_DEV_ENV("SQG_PHC_GRID"), 4) * c->num_cu)), ft(64 * (1 + PHC_COUNT_WAVES));   // (A/B: workgroups per CU)
+                    // (development build, timing experiments: 1 -- the fused launch hands out only, the next batch's pass follows as a launch
+                    // of its own; 2 -- the plain hand-out first, the fused launch counts only)
+                    const int phc_abl = dev_env_int(SQG_DEV_ENV("SQG_PHC_ABL"), 0);
+                    if (phc_abl == 2) hipLaunchKernelGGL(k_part_hand_ord, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, b->d_err, order_fault);
+                    const uint32_t* const ns_ptr = phc_abl == 2 ? c->d_phc_q + 3 : pfirst + n_pairs;      // (word 3 of the queue block is always zero)
+                    const int nl_fused = phc_abl == 1 ? 0 : nb->n_chains;
+#define PHCL(D_) hipLaunchKernelGGL((k_part_hand_count<D_>), fg, ft, 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, ns_ptr, c->d_phist, c->d_pow, \
+                                    b->d_err, order_fault, Pn, nl_fused, (uint32_t)nb->n_events, c->num_cu)
+                    if (dw == 1) PHCL(1); else PHCL(2);
+#undef PHCL
+                    if (phc_abl == 1) {
+                        const dim3 g1((unsigned)((nb->n_chains + PEV_WAVES - 1) / PEV_WAVES)), t1(64 * PEV_WAVES);
+                        if (dw == 1) hipLaunchKernelGGL((k_part_events<1, PEV_COUNT>), g1, t1, 0, c->stream, Pn, nb->n_chains, (uint32_t)nb->n_events);
+                        else hipLaunchKernelGGL((k_part_events<2, PEV_COUNT>), g1, t1, 0, c->stream, Pn, nb->n_chains, (uint32_t)nb->n_events);
+                    }
+                    nb->precounted = true; nb->cset = ncs; nb->cset_gen = ++NQ.gen;
+                }
+                else if (c->lds_ordered) hipLaunchKernelGGL(k_part_hand_ord, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, b->d_err, order_fault);
                 else if (c->dwell_hi >= (double)PART_JT) hipLaunchKernelGGL(k_part_hand<true>, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);
                 else hipLaunchKernelGGL(k_part_hand<false>, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);
                 HIPCHK(c, hipGetLastError());
@@ -265,7 +323,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             if (c->scan_part_cap != cap0)                         // tickets start at 1: a fresh array must not hold one by accident
                 HIPCHK(c, hipMemsetAsync(c->d_scan_part, 0, c->scan_part_cap * sizeof(unsigned long long), c->stream));
         }
-        hipLaunchKernelGGL(k_scan, dim3(scan_wgs), dim3(SCAN_WG), 0, c->stream, S.d_seglen, n, S.d_sigoff, b->h_sigoff_dev,
+        hipLaunchKernelGGL(k_scan, dim3(scan_wgs), dim3(SCAN_WG), 0, c->stream, Q.d_seglen, n, S.d_sigoff, b->h_sigoff_dev,
                            b->d_err, S.d_fix_count, c->d_scan_part, ++c->scan_tickets, S.d_fix_sh_count);   // (a ticket per launch, also after a failed run)
         HIPCHK(c, hipGetLastError());
         if ((rc = dbg_sync(c, "k_scan"))) return rc;
@@ -311,7 +369,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         P.fix_cap = (unsigned int)std::min<size_t>(S.fix_cap, 0xffffffffu);
         if (b->run_idx < 8 && getenv("SQG_VERBOSE"))
             fprintf(stderr, "[sqg] batch %lld slot %d: sig %p part %p evrec %p part_state %p dwell %p bases %p seglen %p\n", (long long)b->run_idx, b->slot,
-                    (void*)S.d_sig, (void*)S.d_part, (void*)S.d_evrec, (void*)S.d_part_state, (void*)S.d_dwell, (void*)b->d_bases, (void*)S.d_seglen);
+                    (void*)S.d_sig, (void*)S.d_part, (void*)S.d_evrec, (void*)S.d_part_state, (void*)Q.d_dwell, (void*)b->d_bases, (void*)Q.d_seglen);
         if (b->run_idx < 8 && getenv("SQG_VERBOSE"))
             fprintf(stderr, "[sqg] batch %lld: %d reads, %lld events, %d links in %d worker chains, %d pieces, %lld slices of %u events at most\n", (long long)b->run_idx, n, (long long)b->n_events,
                     b->n_chains, b->n_wchains, b->n_pieces, (long long)b->max_slices, b->slice_len);
@@ -379,7 +437,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         HIPCHK(c, hipEventRecord(b->ev[7], c->stream));
         HIPCHK(c, hipStreamWaitEvent(c->stream2, b->ev[7], 0));
     }
-    if (n > 0) S.seglen_dirty = seglen_zeroed ? (S.seglen_dirty > (size_t)n ? S.seglen_dirty : 0) : std::max(S.seglen_dirty, (size_t)n);
+    if (n > 0) Q.seglen_dirty = seglen_zeroed ? (Q.seglen_dirty > (size_t)n ? Q.seglen_dirty : 0) : std::max(Q.seglen_dirty, (size_t)n);
     HIPCHK(c, hipEventRecord(b->ev[4], tail));
     HIPCHK(c, hipEventRecord(S.done, tail));
     b->ran = true;

@@ -536,6 +536,8 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     // slots that have never held a batch are sized now, so that not even the first run allocates
     for (auto& Z : c->slot)
         if (Z.reads_cap == 0 && n > 0) { const int rg = grow_slot(c, Z, b, /*with_output=*/true); if (rg) return bail(rg); }
+    for (auto& Q : c->cset)
+        if (Q.dwell_cap == 0 && n > 0) { const int rg = grow_cset(c, Q, b); if (rg) return bail(rg); }
     c->next_stage++;
     b->staged = true;
     c->staged_q.push_back(b);

@@ -394,52 +394,54 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
 // Queued one behind the other each leaves idle what the other wants; kernels of two queues share this GPU worse than they follow
 // each other.  So, when the next batch is staged by the time a batch is run (sqg_batch_run, h_run.h): a persistent grid of
 // four workgroups per CU, in each ONE wavefront that takes slices of batch i (hand_slice) and THREE that take links of batch i+1
-// (pev_link<DW, COUNT>), both from a queue (a counter each: a wavefront that finishes takes the next), the hand-out wavefront on a
-// different SIMD in each of a CU's workgroups.  16 wavefronts per CU: what the counting pass' registers allow.
-//   q[0], q[1]  next slice, next link (zero at launch; the LAST wavefront to leave zeroes them again: q[2] counts the leavers)
+// (pev_link<DW, COUNT>), the hand-out wavefront on a different SIMD in each of a CU's workgroups.  16 wavefronts per CU: what the counting pass' registers allow.
+#ifndef PHC_COUNT_WAVES
 #define PHC_COUNT_WAVES 3
-__device__ static inline uint32_t phc_grab(unsigned int* ctr, const int lane) {
-    unsigned int v = 0;
-    if (lane == 0) v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
+#endif
+#ifndef PHC_PRIO
+#define PHC_PRIO 0                       // A/B: the hand-out wavefront at a raised issue priority (s_setprio)
+#endif
 template <int DW>
-__global__ __launch_bounds__(64 * (1 + PHC_COUNT_WAVES), 1) void k_part_hand_count(
+__global__ __launch_bounds__(64 * (1 + PHC_COUNT_WAVES), 4) void k_part_hand_count(
         const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out, const uint32_t* __restrict__ slice_lo, const uint32_t* __restrict__ slice_hi,
         const uint32_t* __restrict__ n_slices, const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pw, unsigned int* __restrict__ err, const int fault,
-        const SigParams Pn, const int n_links_n, const uint32_t dump_n, unsigned int* __restrict__ q) {
+        const SigParams Pn, const int n_links_n, const uint32_t dump_n, const int ncu) {
     __shared__ HandLds H;
     __shared__ PevTables T;
     __shared__ PevWave<false> W[PHC_COUNT_WAVES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ int simd_of[1 + PHC_COUNT_WAVES];
     hand_tables(H, pw, tid, 64 * (1 + PHC_COUNT_WAVES));
     pev_tables(T, Pn.pw, tid, 64 * (1 + PHC_COUNT_WAVES));
+    // Which wavefront hands out: the one on SIMD j of the CU, j = this workgroup's place among the (four) workgroups its CU holds --
+    // workgroups one CU count apart, when four per CU are dispatched round-robin over XCDs, then CUs (measured: tools/hwid_probe.hip;
+    // a workgroup's wavefronts sit on four different SIMDs, in an order that differs from workgroup to workgroup: by wavefront INDEX two
+    // SIMDs of a CU got two hand-out wavefronts each and two none, 470 instead of 290 us for the hand-out alone).  The SIMD is read
+    // from the hardware (HW_REG_HW_ID bits 4-5); should no wavefront of the workgroup sit on SIMD j, the j-th does it.
+    if (lane == 0) simd_of[wid] = (int)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3u);
     __syncthreads();
-    // (workgroups 256 apart are the ones a CU holds together when 1024 of them are dispatched round-robin: XCD, then CU)
-    const int hw = (int)((blockIdx.x >> 8) & 3u) % (1 + PHC_COUNT_WAVES);
+    const int want = (int)((blockIdx.x / (unsigned)ncu) & 3u);
+    int hw = want % (1 + PHC_COUNT_WAVES);
+#pragma unroll
+    for (int w = PHC_COUNT_WAVES; w >= 0; w--) if (simd_of[w] == want) hw = w;
+    hw = __builtin_amdgcn_readfirstlane(hw);
+    // Work is dealt out statically, a stride of the grid apart (slices are of equal length, links of equal size, the launch order
+    // lists the longest first): a queue -- one counter for the slices, one for the links -- was measured first, and 30 000 returning
+    // atomics on one cache line took longer than the work they handed out (the fused launch 705 us against 296 + 285 for the two
+    // kernels one after the other)
     if (wid == hw) {
+#if PHC_PRIO
+        __builtin_amdgcn_s_setprio(PHC_PRIO);
+#endif
         const uint32_t ns = *n_slices;
-        for (;;) {
-            const uint32_t sl = phc_grab(q, lane);
-            if (sl >= ns) break;
+        for (uint32_t sl = blockIdx.x; sl < ns; sl += gridDim.x)
             hand_slice(H, part, state_out, slice_lo[sl], slice_hi[sl], phist + (size_t)sl * PART_SUB, pw, err, fault, lane);
-        }
     } else {
-        PevWave<false>& Wm = W[wid - (wid > hw ? 1 : 0)];
-        for (;;) {
-            const uint32_t li = phc_grab(q + 1, lane);
-            if (li >= (uint32_t)n_links_n) break;
-            pev_link<DW, PEV_COUNT>(Pn, T, Wm, (int)li, dump_n, lane);
-        }
-    }
-    if (lane == 0) {
-        const unsigned int gone = __hip_atomic_fetch_add(q + 2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (gone + 1u == gridDim.x * (1u + PHC_COUNT_WAVES)) {       // (everybody else has stopped asking: for the next launch, which the stream orders)
-            __hip_atomic_store(q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(q + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(q + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const int m = wid - (wid > hw ? 1 : 0);
+        PevWave<false>& Wm = W[m];
+        for (int li = (int)blockIdx.x * PHC_COUNT_WAVES + m; li < n_links_n; li += (int)gridDim.x * PHC_COUNT_WAVES)
+            pev_link<DW, PEV_COUNT>(Pn, T, Wm, li, dump_n, lane);
     }
 }
 
