@@ -92,3 +92,10 @@ def test_reference_host_with_the_gpu_library(cid, cmdline, ext, tmp_path):
     ldd = subprocess.run(["ldd", HOSTGPU], env=env, capture_output=True, text=True).stdout
     assert os.path.realpath(build.LIB) in [os.path.realpath(t.split("=>")[1].split("(")[0].strip()) for t in ldd.splitlines() if "libsqg_hip.so" in t]
     _compare(cmdline, ext, str(tmp_path), env, ("certified", "exact"))
+
+
+def test_integration_document_quotes_the_compiled_binding():
+    """INTEGRATION.md's binding is the text of oracle/ref_host_gpu.c (tools/sync_integration.py), not a copy that can drift"""
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sync_integration.py"), "--check"])
+    assert p.returncode == 0, "run tools/sync_integration.py"
