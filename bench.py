@@ -323,7 +323,7 @@ def cpu_reference(prof, flags, k, mean, stdv, fasta_path, rlen, seconds=10.0):
         def leg(nproc, secs, blow5):
             cfgs = []
             for i in range(nproc):
-                cfg = {"fasta": fasta_path, "model": mpath, "flags": flags, "amp_noise": 1.0, "seed": 1000 + 7919 * i,
+                cfg = {"fasta": fasta_path, "model": mpath, "flags": flags & ~profiles.SQ_ORDER_FREE, "amp_noise": 1.0, "seed": 1000 + 7919 * i,
                        "threads": 1, "batch": 1000, "nreads": 1, "rlen": rlen, "time_s": secs}
                 if blow5:
                     cfg["slow5"] = os.path.join(tmp, f"o{i}.blow5")
@@ -385,7 +385,7 @@ def parity_check(prof, flags, k, mean, stdv, contigs, rlen, n_reads, one_worker,
     rng = np.random.default_rng(1234)
     reads = sample_reads_host(contigs, n_reads, rlen, rng)
     workers = np.zeros(n_reads, np.int32) if one_worker else np.arange(n_reads, dtype=np.int32)
-    res, rate = cpu_port(prof, flags, k, mean, stdv, reads, workers, nthreads=min(os.cpu_count() or 1, 64))
+    res, rate = cpu_port(prof, flags & ~profiles.SQ_ORDER_FREE, k, mean, stdv, reads, workers, nthreads=min(os.cpu_count() or 1, 64))
     gen = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=int(workers.max()) + 1, mode=mode)
     b = gen.submit(reads, workers)
     sig = b.signal()
@@ -505,6 +505,9 @@ def main():
                     help="hg38-r10 / synth-r10: scale the synthetic genome to this many Mb (default: hg38's 3088 Mb; synth-r10: 64)")
     ap.add_argument("--profile", default=None, help="override the workload's -x preset")
     ap.add_argument("--mode", default="certified", choices=["exact", "certified"])
+    ap.add_argument("--order-free", action="store_true",
+                    help="SQG_ORDER_FREE in cfg.flags: the few-worker stream hand-out by the kernels that do not rely on lane-ordered LDS atomics "
+                         "(what a device that fails the create-time check falls back to): same bytes, slower -- how much is what this measures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall time of each multi-process CPU leg")
     ap.add_argument("--no-store-probe", action="store_true")
@@ -594,6 +597,8 @@ def main():
         args.profile = wl_profile
     prof, flags = profiles.get_profile(args.profile)
     flags |= wl_flags
+    if args.order_free:
+        flags |= profiles.SQ_ORDER_FREE
     k = profiles.default_kmer_size(flags)
     n_k = 1 << (2 * k)
     amode = api.MODE_EXACT if args.mode == "exact" else api.MODE_CERTIFIED
@@ -833,7 +838,7 @@ def main():
                 "workload": f"{wl_desc}; -x {args.profile} --seed 42 -r {args.rlen}, {regime}, {args.steps} batches "
                             f"({int(tot_reads)} reads)",
                 "genome_bases": genome_bases,
-                "reads_per_step_per_gpu": K, "kmer_size": k, "mode": args.mode,
+                "reads_per_step_per_gpu": K, "kmer_size": k, "mode": args.mode, "order_free": bool(args.order_free),
                 "reads": "gen_read on the device-resident genome (library sampler), as the reference with these options",
                 "pore_model": "synthetic stand-in table (built-in ONT tables absent from the reference mount)",
             },

@@ -78,6 +78,7 @@ struct HostPool {
 // ------------------------------------------------------------------------------------------
 struct sqg_ctx {
     HostPool pool_threads;
+    struct DrawAhead* draw_ahead = nullptr;        // few workers: their per-read scalar draws, made ahead of staging by a thread of its own (below)
     sqg_cfg_t cfg;
     int k = 0, num_kmer = 0, T = 0, wlo = 0, whi = 0, nw = 0;
     hipStream_t stream = nullptr;
@@ -181,6 +182,7 @@ struct sqg_ctx {
     uint8_t* d_meth = nullptr; uint8_t* d_meth_has = nullptr;   // --meth-freq (sqg_genome_set_meth): frequency byte per base, flag per contig
     uint32_t* d_meth_st = nullptr;                              // [nw] rand_meth stream states
     GenomeParams genome{};
+    uint32_t* h_samp = nullptr; size_t h_samp_cap = 0;          // pinned: the sampler streams' snapshot and the error word of a sqg_batch_sample call
     uint8_t* d_samp_scratch = nullptr; size_t samp_scratch_cap = 0;   // sqg_batch_sample: records, chain lists, attempt slots
     bool genome_loaded = false;
     std::vector<long long> h_contig_off;                        // host copy of the contig offsets
@@ -192,6 +194,7 @@ struct sqg_ctx {
     std::string err;
 };
 
+#define SQG_HRES_LL ((FIX_SHARDS + 8) / 2)          /* long longs at the end of a batch's mapped host block: 4 + FIX_SHARDS 32-bit words, rounded up */
 struct sqg_batch {
     unsigned long long seq = 0;
     int n = 0;
@@ -230,6 +233,7 @@ struct sqg_batch {
     long long n_tiles = 0, n_stiles = 0;
     long long* h_sigoff = nullptr;   // pinned, device-mapped: k_scan writes it directly
     long long* h_sigoff_dev = nullptr;   // its device-side address
+    // (the same allocation ends with SQG_HRES_LL words for k_fixup's report: error word, fix-up counts -- SigParams.host_res)
     long long n_bases_total = 0;         // bytes in d_bases
     std::vector<long long> h_base_off;   // per read: its segment 0 in d_bases
     std::vector<int32_t> s_ref_idx, s_ref_len, s_ref_pos, s_rlen;   // sqg_batch_sample: what gen_read returned
@@ -282,6 +286,92 @@ static double host_nrng(double m, double s, long long* xp) {   // src/rand.h:87-
     const double z = std::sqrt(-2.0 * std::log(u)) * std::cos(t);
     return (z * s) + m;
 }
+
+// The per-read scalar draws (`offset`, `median_before`: src/gensig.c:315-316) are host libm work -- they are printed values, so they
+// are made with the host's log / sqrt / cos -- and they depend on nothing but the worker's two streams: draw i of a worker is known
+// before its i-th read is.  With few workers (`-t 1`: the regime of the bench) a thread of the context therefore keeps up to CAP
+// draws per worker ready; staging takes what is there and draws the rest itself.  100 us of a 1000-read batch's 330 us of staging
+// (the reference's default -K), nothing a 16384-read batch notices.  A ring is valid only for the stream states it was started
+// from: whoever moves a worker's streams another way (sqg_skip_reads, a failed staging that puts them back) makes the next take() start over.
+struct DrawAhead {
+    static constexpr size_t CAP = 16384, CHUNK = 256;           // (CAP a power of two)
+    struct Ring {
+        std::vector<double> off, med;                             // draw p at index p & (CAP - 1)
+        std::vector<long long> offx, medx;                        // ... and the streams' raw states behind it
+        long long x_off_head = 0, x_med_head = 0, x_off_tail = 0, x_med_tail = 0;   // the states in front of draw `head` / `filled`
+        size_t head = 0, filled = 0;
+        unsigned long long epoch = 0;
+        bool active = false;
+    };
+    std::vector<Ring> rings;
+    std::mutex m;
+    std::condition_variable cv;
+    std::thread th;
+    bool stop = false, started = false;
+    double off_mean, off_std, med_mean, med_std;
+    DrawAhead(int nw, const sqg_profile_t& p) : rings((size_t)nw), off_mean(p.offset_mean), off_std(p.offset_std), med_mean(p.median_before_mean), med_std(p.median_before_std) {}
+    ~DrawAhead() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv.notify_all();
+        if (th.joinable()) th.join();
+    }
+    void producer() {
+        std::unique_lock<std::mutex> lk(m);
+        double o[CHUNK], d[CHUNK]; long long ox[CHUNK], dx[CHUNK];
+        for (;;) {
+            Ring* pick = nullptr;
+            for (auto& R : rings) if (R.active && R.filled - R.head + CHUNK <= CAP && (!pick || R.filled - R.head < pick->filled - pick->head)) pick = &R;
+            if (stop) return;
+            if (!pick) { cv.wait(lk); continue; }
+            const unsigned long long ep = pick->epoch;
+            long long xo = pick->x_off_tail, xm = pick->x_med_tail;
+            lk.unlock();
+            for (size_t i = 0; i < CHUNK; i++) { o[i] = host_nrng(off_mean, off_std, &xo); ox[i] = xo; d[i] = host_nrng(med_mean, med_std, &xm); dx[i] = xm; }
+            lk.lock();
+            if (pick->epoch != ep) continue;                      // (the worker's streams went elsewhere meanwhile)
+            for (size_t i = 0; i < CHUNK; i++) {
+                const size_t at = (pick->filled + i) & (CAP - 1);
+                pick->off[at] = o[i]; pick->med[at] = d[i]; pick->offx[at] = ox[i]; pick->medx[at] = dx[i];
+            }
+            pick->filled += CHUNK; pick->x_off_tail = xo; pick->x_med_tail = xm;
+        }
+    }
+    void restart(Ring& R, long long x_off, long long x_med) {    // (locked)
+        if (R.off.empty()) { R.off.resize(CAP); R.med.resize(CAP); R.offx.resize(CAP); R.medx.resize(CAP); }
+        R.head = R.filled = 0; R.x_off_head = R.x_off_tail = x_off; R.x_med_head = R.x_med_tail = x_med; R.epoch++; R.active = true;
+    }
+    // up to `want` draws of worker w whose streams stand at (x_off, x_med): values to off_out / med_out, the states behind them to *x_off / *x_med
+    size_t take(int w, size_t want, long long* x_off, long long* x_med, double* off_out, double* med_out) {
+        size_t n = 0;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (!started) { started = true; th = std::thread([this] { producer(); }); }
+            Ring& R = rings[(size_t)w];
+            if (!R.active || R.x_off_head != *x_off || R.x_med_head != *x_med) restart(R, *x_off, *x_med);
+            else {
+                n = std::min(want, R.filled - R.head);
+                for (size_t i = 0; i < n; i++) { const size_t at = (R.head + i) & (CAP - 1); off_out[i] = R.off[at]; med_out[i] = R.med[at]; }
+                if (n) {
+                    const size_t last = (R.head + n - 1) & (CAP - 1);
+                    *x_off = R.x_off_head = R.offx[last]; *x_med = R.x_med_head = R.medx[last];
+                    R.head += n;
+                }
+            }
+        }
+        cv.notify_one();
+        return n;
+    }
+    // the worker's streams stand at (x_off, x_med) now: what was made for other states is dropped
+    void rebase(int w, long long x_off, long long x_med) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            Ring& R = rings[(size_t)w];
+            if (R.active && R.x_off_head == x_off && R.x_med_head == x_med) return;
+            restart(R, x_off, x_med);
+        }
+        cv.notify_one();
+    }
+};
 
 static uint32_t canon(long long s) {
     s %= (long long)LCG_M;

@@ -36,8 +36,9 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->fix_stream) (void)hipStreamSynchronize(ctx->fix_stream);
+    delete ctx->draw_ahead; ctx->draw_ahead = nullptr;
     (void)hipFree(ctx->d_pcnt); (void)hipFree(ctx->d_slice); (void)hipFree(ctx->d_phist);
-    (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_scan_part); (void)hipFree(ctx->d_xcounts); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_samp_scratch); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err); (void)hipFree(ctx->d_mid_done); (void)hipFree(ctx->d_phc_q);
+    (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_scan_part); (void)hipFree(ctx->d_xcounts); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_samp_scratch); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err); (void)hipFree(ctx->d_mid_done); (void)hipFree(ctx->d_phc_q); if (ctx->h_samp) (void)hipHostFree(ctx->h_samp);
     for (auto& Q : ctx->cset) { (void)hipFree(Q.d_dwell); (void)hipFree(Q.d_tile_so); (void)hipFree(Q.d_seglen); }
     for (auto& S : ctx->slot) {
         (void)hipFree(S.d_sig); (void)hipFree(S.d_sigoff);

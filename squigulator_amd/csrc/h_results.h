@@ -18,7 +18,9 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
         b->n_samples = b->h_sigoff[b->n];
         for (int i = 0; i <= b->n; i++) b->sig_off[(size_t)i] = b->h_sigoff[i];
         unsigned int e = 0;
-        HIPCHK(c, hipMemcpy(&e, b->d_err, sizeof e, hipMemcpyDeviceToHost));   // the batch's own word: never cleared, never shared
+        const unsigned int* const hres = reinterpret_cast<const unsigned int*>(b->h_sigoff + (b->h_n - SQG_HRES_LL));   // k_fixup's report (mapped host memory)
+        if (b->fixup_launched) e = hres[0];
+        else HIPCHK(c, hipMemcpy(&e, b->d_err, sizeof e, hipMemcpyDeviceToHost));   // the batch's own word: never cleared, never shared
 #if defined(SQG_ABL_EV_NOSTORE) || defined(SQG_ABL_NOSTORE)       /* timing-only ablation builds: results are garbage by design */
         e = 0;
 #endif
@@ -40,8 +42,12 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
         c->timing.lean_ms = 0.f;
         if (b->lean_timed) HIPCHK(c, hipEventElapsedTime(&c->timing.lean_ms, b->ev[5], b->ev[6]));
         long long nfix = 0;
-        if (c->cfg.mode == SQG_MODE_CERTIFIED && !slot_is_mine(c, b)) nfix = -1;   // the slot's counters belong to a later batch by now: not known
-        if (c->cfg.mode == SQG_MODE_CERTIFIED && slot_is_mine(c, b)) {
+        if (c->cfg.mode == SQG_MODE_CERTIFIED && b->fixup_launched) {
+            nfix = hres[1];                                 // the global list + the lean kernel's lists, as k_fixup reported them
+            for (int i = 0; i < FIX_SHARDS; i++) nfix += hres[4 + i];
+        }
+        else if (c->cfg.mode == SQG_MODE_CERTIFIED && !slot_is_mine(c, b)) nfix = -1;   // the slot's counters belong to a later batch by now: not known
+        else if (c->cfg.mode == SQG_MODE_CERTIFIED) {
             unsigned int cnt[4 + FIX_SHARDS];                // the counters and the lists' statistics in one read-back
             const bool lists = S.d_fix_sh_count != nullptr && b->fixup_launched;   // (an empty batch launches no k_fixup: the words are an earlier batch's)
             HIPCHK(c, hipMemcpy(cnt, S.d_fix_count, (lists ? 4 + FIX_SHARDS : 4) * sizeof(unsigned int), hipMemcpyDeviceToHost));

@@ -365,7 +365,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     bool seglen_zeroed = false;
     if (n > 0 && b->n_chains > 0) {
         P.sig = S.d_sig; P.fix = S.d_fix; P.fix_count = S.d_fix_count;
-        P.fix_sh = S.d_fix_sh; P.fix_sh_cap = S.fix_sh_per; P.fix_sh_count = S.d_fix_sh_count; P.fix_sh_stat = S.d_fix_count + 4; P.fix_tag = (int)(++c->fix_tickets & 0x3fffffffull) + 1;   // (a tag per launch, also when a batch is run again after a failed run: stale entries of the first attempt must not match)
+        P.fix_sh = S.d_fix_sh; P.fix_sh_cap = S.fix_sh_per; P.fix_sh_count = S.d_fix_sh_count; P.fix_sh_stat = S.d_fix_count + 4; P.host_res = reinterpret_cast<unsigned int*>(b->h_sigoff_dev + (b->h_n - SQG_HRES_LL)); P.fix_tag = (int)(++c->fix_tickets & 0x3fffffffull) + 1;   // (a tag per launch, also when a batch is run again after a failed run: stale entries of the first attempt must not match)
         P.fix_cap = (unsigned int)std::min<size_t>(S.fix_cap, 0xffffffffu);
         if (b->run_idx < 8 && getenv("SQG_VERBOSE"))
             fprintf(stderr, "[sqg] batch %lld slot %d: sig %p part %p evrec %p part_state %p dwell %p bases %p seglen %p\n", (long long)b->run_idx, b->slot,

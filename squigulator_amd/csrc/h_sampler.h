@@ -163,9 +163,11 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
     const size_t na = (size_t)att_off.back();
     size_t top = 0;
     auto room = [&](size_t bytes) { const size_t o = top; top += (bytes + 255) & ~(size_t)255; return o; };
+    // (the host-built inputs -- chain lists, attempt offsets -- lie back to back: one upload from the call's pinned buffer)
     const size_t o_rec = room(std::max<size_t>(1, (size_t)n) * sizeof(SampleRec)), o_co = room(chain_off.size() * sizeof(int)),
                  o_cr = room(std::max<size_t>(1, chain_reads.size()) * sizeof(int)), o_cw = room(std::max<size_t>(1, chain_worker.size()) * sizeof(int)),
-                 o_try = room(na * sizeof(SampleRec)), o_ok = room(na), o_ao = room((att_off.size() + (size_t)n_chains) * sizeof(long long)),
+                 o_ao = room((att_off.size() + (size_t)n_chains) * sizeof(long long)), o_in_end = top,
+                 o_try = room(na * sizeof(SampleRec)), o_ok = room(na),
                  o_mc = room(std::max<size_t>(1, (size_t)n) * sizeof(int)), o_ms = room(std::max<size_t>(1, (size_t)n) * sizeof(uint32_t));
     if (top > c->samp_scratch_cap) {
         (void)hipStreamSynchronize(c->stage_stream);
@@ -187,23 +189,43 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
     const std::vector<uint32_t> snap_time = c->time_c;
     const std::vector<long long> snap_off = c->off_x, snap_med = c->med_x;
     const long long snap_full = c->full_next;
-    std::vector<uint32_t> snap_samp((size_t)c->nw * 3), snap_meth(c->d_meth_st ? (size_t)c->nw : 0);
-    if (hipMemcpy(snap_samp.data(), c->d_samp, snap_samp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { c->err = "sampler streams unreadable"; return SQG_EDEVICE; }
-    if (!snap_meth.empty() && hipMemcpy(snap_meth.data(), c->d_meth_st, snap_meth.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) { c->err = "sampler streams unreadable"; return SQG_EDEVICE; }
+    // (the sampler streams' snapshot and, below, the error word travel through pinned memory on the staging stream, in front of and behind
+    // the kernels: the call waits for the device ONCE -- three blocking copies were 60 us of a 1000-read batch's 330)
+    const size_t n_snap = (size_t)c->nw * 3, n_snap_m = c->d_meth_st ? (size_t)c->nw : 0;
+    const size_t in_bytes = o_in_end - o_co;                      // (256-byte granules, as on the device)
+    const size_t hw_head = ((n_snap + n_snap_m + 4) * sizeof(uint32_t) + 255) & ~(size_t)255;
+    const size_t hw_rec = hw_head + in_bytes, hw_used = hw_rec + ((std::max<size_t>(1, (size_t)n) * sizeof(SampleRec) + 255) & ~(size_t)255);
+    const size_t hw_all = (hw_used + (size_t)n_chains * sizeof(long long) + 255) / sizeof(uint32_t);
+    if (c->h_samp_cap < hw_all) {
+        (void)hipStreamSynchronize(c->stage_stream);
+        if (c->h_samp) (void)hipHostFree(c->h_samp);
+        c->h_samp = nullptr; c->h_samp_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_samp, (hw_all + hw_all / 4) * sizeof(uint32_t), hipHostMallocDefault));
+        c->h_samp_cap = hw_all + hw_all / 4;
+    }
+    uint8_t* const hb = reinterpret_cast<uint8_t*>(c->h_samp);
+    uint32_t* const snap_samp = c->h_samp; uint32_t* const snap_meth = c->h_samp + n_snap; uint32_t* const h_err = c->h_samp + n_snap + n_snap_m;
+    uint8_t* const h_in = hb + hw_head;
+    SampleRec* const h_rec = reinterpret_cast<SampleRec*>(hb + hw_rec);
+    long long* const h_used = reinterpret_cast<long long*>(hb + hw_used);
+    if (hipMemcpyAsync(snap_samp, c->d_samp, n_snap * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stage_stream) != hipSuccess) { c->err = "sampler streams unreadable"; return SQG_EDEVICE; }
+    if (n_snap_m && hipMemcpyAsync(snap_meth, c->d_meth_st, n_snap_m * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stage_stream) != hipSuccess) { c->err = "sampler streams unreadable"; return SQG_EDEVICE; }
     bool failed = true;                                           // cleared on the way out of a successful call
     auto cleanup = [&]() {
         if (!failed) return;
         c->time_c = snap_time; c->off_x = snap_off; c->med_x = snap_med; c->full_next = snap_full;
-        (void)hipStreamSynchronize(c->stage_stream);
-        (void)hipMemcpy(c->d_samp, snap_samp.data(), snap_samp.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (!snap_meth.empty()) (void)hipMemcpy(c->d_meth_st, snap_meth.data(), snap_meth.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        (void)hipStreamSynchronize(c->stage_stream);              // (the snapshot has landed by now)
+        (void)hipMemcpy(c->d_samp, snap_samp, n_snap * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (n_snap_m) (void)hipMemcpy(c->d_meth_st, snap_meth, n_snap_m * sizeof(uint32_t), hipMemcpyHostToDevice);
     };
 #define CHKS(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { c->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return e_ == hipErrorOutOfMemory ? SQG_ENOMEM : SQG_EDEVICE; } } while (0)
     if (n > 0) {
-        CHKS(hipMemcpyAsync(d_co, chain_off.data(), chain_off.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
-        CHKS(hipMemcpyAsync(d_cr, chain_reads.data(), chain_reads.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
-        CHKS(hipMemcpyAsync(d_cw, chain_worker.data(), chain_worker.size() * sizeof(int), hipMemcpyHostToDevice, c->stage_stream));
-        std::vector<long long> att_used;
+        memcpy(h_in + (o_co - o_co), chain_off.data(), chain_off.size() * sizeof(int));
+        memcpy(h_in + (o_cr - o_co), chain_reads.data(), chain_reads.size() * sizeof(int));
+        memcpy(h_in + (o_cw - o_co), chain_worker.data(), chain_worker.size() * sizeof(int));
+        memcpy(h_in + (o_ao - o_co), att_off.data(), att_off.size() * sizeof(long long));
+        CHKS(hipMemcpyAsync(sb + o_co, h_in, in_bytes, hipMemcpyHostToDevice, c->stage_stream));
+        bool have_used = false;
         if (c->genome.flags & SQG_SAMPLE_FULL) {
             // --full-contigs (src/sim.c:543-549): the reads are the contigs themselves, in order, as loaded ('N' stays 'N')
             if (c->full_next + n > c->genome.n_contigs) { c->err = "--full-contigs: more reads asked for than there are contigs left"; cleanup(); return SQG_EINVAL; }
@@ -218,14 +240,13 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
             CHKS(hipMemcpyAsync(d_rec, rec.data(), rec.size() * sizeof(SampleRec), hipMemcpyHostToDevice, c->stage_stream));
         } else if (concurrent) {
             long long* d_used = d_ao + att_off.size();
-            CHKS(hipMemcpyAsync(d_ao, att_off.data(), att_off.size() * sizeof(long long), hipMemcpyHostToDevice, c->stage_stream));
             hipLaunchKernelGGL(k_sample_try, dim3((unsigned)((max_a + 3) / 4), (unsigned)n_chains), dim3(256), 0, c->stage_stream, c->genome, c->d_samp,
                                d_cw, d_ao, d_try, d_ok);
             hipLaunchKernelGGL(k_sample_pick, dim3((unsigned)n_chains), dim3(256), 0, c->stage_stream, c->genome, c->d_samp, d_co, d_cr, d_cw,
                                d_ao, d_try, d_ok, d_rec, d_used, c->d_err);
             CHKS(hipGetLastError());
-            att_used.resize((size_t)n_chains);
-            CHKS(hipMemcpyAsync(att_used.data(), d_used, att_used.size() * sizeof(long long), hipMemcpyDeviceToHost, c->stage_stream));
+            have_used = true;
+            CHKS(hipMemcpyAsync(h_used, d_used, (size_t)n_chains * sizeof(long long), hipMemcpyDeviceToHost, c->stage_stream));
         } else {
             hipLaunchKernelGGL(k_sample, dim3((unsigned)n_chains), dim3(64), 0, c->stage_stream, c->genome, c->d_samp, d_co, d_cr, d_cw,
                                n_chains, d_rec, c->d_err);
@@ -236,18 +257,19 @@ static int sample_impl(sqg_ctx_t* c, int32_t n, const int32_t* worker, int32_t l
             hipLaunchKernelGGL(k_meth_scan, dim3((unsigned)n_chains), dim3(256), 0, c->stage_stream, d_co, d_cr, d_cw, d_mcnt, c->d_meth_st, d_mstate);
             CHKS(hipGetLastError());
         }
-        CHKS(hipMemcpyAsync(rec.data(), d_rec, rec.size() * sizeof(SampleRec), hipMemcpyDeviceToHost, c->stage_stream));
+        CHKS(hipMemcpyAsync(h_rec, d_rec, rec.size() * sizeof(SampleRec), hipMemcpyDeviceToHost, c->stage_stream));
+        CHKS(hipMemcpyAsync(h_err, c->d_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stage_stream));
         CHKS(hipStreamSynchronize(c->stage_stream));
-        if (!att_used.empty()) {
+        memcpy(rec.data(), h_rec, rec.size() * sizeof(SampleRec));
+        if (have_used) {
             double r = 1.0;
             for (int q = 0; q < n_chains; q++) {
                 const int m = chain_off[(size_t)q + 1] - chain_off[(size_t)q];
-                if (m >= 16) r = std::max(r, (double)att_used[(size_t)q] / (double)m);
+                if (m >= 16) r = std::max(r, (double)h_used[q] / (double)m);
             }
             c->samp_ratio = r;
         }
-        unsigned int e = 0;
-        CHKS(hipMemcpy(&e, c->d_err, sizeof e, hipMemcpyDeviceToHost));
+        const unsigned int e = *h_err;
         if (e & 16u) { CHKS(hipMemset(c->d_err, 0, sizeof e)); c->err = "read sampler: no acceptable read after 100000 attempts"; cleanup(); return SQG_EINVAL; }
     }
 #undef CHKS

@@ -344,6 +344,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     const bool ideal = (c->cfg.flags & SQG_IDEAL) != 0;
     std::vector<double> off_d, med_d;                              // by position in chain_reads
     std::vector<int> rd_worker;                                    // ... and the worker of the read at that position
+    std::vector<int> pre((size_t)n_wchains, 0);                   // draws of chain q that came from the context's draw-ahead thread (below)
     auto draw_range = [&](const int lo, const int hi) {
         int ci = lo;
         while (ci < hi) {
@@ -355,19 +356,41 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
                 off = (long long)lcg_mul(canon(off), j); med = (long long)lcg_mul(canon(med), j);
             }
             const int stop = std::min(hi, c_hi);
+            if (ci < c_lo + pre[(size_t)q]) {                       // (the chain's first draws came from the draw-ahead thread)
+                ci = std::min(stop, c_lo + pre[(size_t)q]);
+                if (ci >= stop) continue;
+                const uint32_t j = c->jump2((unsigned long long)(ci - c_lo));
+                off = (long long)lcg_mul(canon(snap_off[w]), j); med = (long long)lcg_mul(canon(snap_med[w]), j);
+            }
             for (; ci < stop; ci++) {
                 off_d[(size_t)ci] = host_nrng(p.offset_mean, p.offset_std, &off);                     // src/gensig.c:315
                 med_d[(size_t)ci] = host_nrng(p.median_before_mean, p.median_before_std, &med);       // src/gensig.c:316
             }
         }
     };
+    // few workers: what the context's draw-ahead thread has ready (h_common.h, DrawAhead) comes first -- a prefix of every worker chain
+    std::vector<long long> pre_off((size_t)n_wchains, 0), pre_med((size_t)n_wchains, 0);   // ... and the streams' states behind them
+    int n_pre = 0;
+    const bool ahead = !ideal && c->nw <= 4 && n > 0 && usable_cpus() >= 2 && !SQG_DEV_ENV("SQG_NO_DRAW_AHEAD");
+    if (ahead) {
+        if (!c->draw_ahead) c->draw_ahead = new DrawAhead(c->nw, p);
+        off_d.resize((size_t)n); med_d.resize((size_t)n);
+        for (int q = 0; q < n_wchains; q++) {
+            const int c_lo = wchain_off[(size_t)q], c_hi = wchain_off[(size_t)q + 1];
+            const size_t w = (size_t)rd[(size_t)chain_reads[(size_t)c_lo]].worker;
+            pre_off[(size_t)q] = c->off_x[w]; pre_med[(size_t)q] = c->med_x[w];
+            pre[(size_t)q] = (int)c->draw_ahead->take((int)w, (size_t)(c_hi - c_lo), &pre_off[(size_t)q], &pre_med[(size_t)q], off_d.data() + c_lo, med_d.data() + c_lo);
+            n_pre += pre[(size_t)q];
+        }
+    }
     // (measured, 16384 reads per batch: 1.30 ms on one thread, 1.10 with two, 0.93 with four, 0.88 with six -- the helpers sleep for
     // milliseconds between two batches and wake slowly).  sqg_set_stage_threads fixes the number (a host that runs one context per GPU
     // on a CPU quota shared by eight of them); automatic: four from 8192 reads per batch on, never more than the CPUs this process may use.
     const int dev_th = dev_env_int(SQG_DEV_ENV("SQG_STAGE_THREADS"), 0);       // (development build: A/B runs)
     const int forced_th = dev_th > 0 ? dev_th : c->stage_threads;
-    const int want_th = ideal ? 1 : forced_th > 0 ? forced_th : n >= 8192 ? std::min(4, usable_cpus()) : 1;
-    const int nth = std::max(1, std::min(want_th, std::max(n, 1)));
+    const int n_left = n - n_pre;                                  // draws still to be made here
+    const int want_th = ideal ? 1 : forced_th > 0 ? forced_th : n_left >= 8192 ? std::min(4, usable_cpus()) : 1;
+    const int nth = n_left > 0 ? std::max(1, std::min(want_th, std::max(n_left, 1))) : 1;
     c->stage_threads_last = nth;
     if (nth > 1) {
         off_d.resize((size_t)n); med_d.resize((size_t)n); rd_worker.resize((size_t)n);
@@ -382,12 +405,14 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     for (int q = 0; q < n_wchains; q++) {
         const size_t w = (size_t)rd[(size_t)chain_reads[(size_t)wchain_off[(size_t)q]]].worker;
         uint32_t tc = c->time_c[w];
-        for (int ci = wchain_off[(size_t)q]; ci < wchain_off[(size_t)q + 1]; ci++) {   // batch order within the worker
+        const int c_lo = wchain_off[(size_t)q], c_hi = wchain_off[(size_t)q + 1], c_pre = c_lo + pre[(size_t)q];
+        if (nth == 1 && pre[(size_t)q] > 0) { c->off_x[w] = pre_off[(size_t)q]; c->med_x[w] = pre_med[(size_t)q]; }   // (the streams behind the prefix: where the draws made here go on)
+        for (int ci = c_lo; ci < c_hi; ci++) {   // batch order within the worker
             const int i = chain_reads[(size_t)ci];
             ReadDesc& d = rd[(size_t)i];
             if (ideal) {                                          // src/gensig.c:311-313
                 d.offset = p.offset_mean; b->median[(size_t)i] = p.median_before_mean;
-            } else if (nth > 1) {
+            } else if (nth > 1 || ci < c_pre) {
                 d.offset = off_d[(size_t)ci]; b->median[(size_t)i] = med_d[(size_t)ci];
             } else {                                              // src/gensig.c:315-316
                 d.offset = host_nrng(p.offset_mean, p.offset_std, &c->off_x[w]);
@@ -402,9 +427,10 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         }
         c->time_c[w] = tc;
         if (nth > 1) {                                            // the streams behind the chain's reads
-            const uint32_t j = c->jump2((unsigned long long)(wchain_off[(size_t)q + 1] - wchain_off[(size_t)q]));
+            const uint32_t j = c->jump2((unsigned long long)(c_hi - c_lo));
             c->off_x[w] = (long long)lcg_mul(canon(c->off_x[w]), j); c->med_x[w] = (long long)lcg_mul(canon(c->med_x[w]), j);
         }
+        if (ahead) c->draw_ahead->rebase((int)w, c->off_x[w], c->med_x[w]);
     }
     st_mark("per-read draws");
     if (!c->use_dwell_stream) {                           // constant dwell: lengths are known now
@@ -450,7 +476,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         // a freed batch's block, pinned offsets and events are reused when they are large enough
         for (size_t pi = 0; pi < c->pool.size(); pi++) {
             sqg_ctx::Recycled& r = c->pool[pi];
-            if (r.block_bytes >= off && r.h_n >= (size_t)n + 1 && r.h_meta_bytes >= meta_bytes) {
+            if (r.block_bytes >= off && r.h_n >= (size_t)n + 1 + SQG_HRES_LL && r.h_meta_bytes >= meta_bytes) {
                 b->d_block = r.d_block; b->block_bytes = r.block_bytes; b->h_sigoff = r.h_sigoff; b->h_sigoff_dev = r.h_sigoff_dev; b->h_n = r.h_n;
                 for (int i = 0; i < 8; i++) b->ev[i] = r.ev[i];
                 b->h_meta = r.h_meta; b->h_meta_bytes = r.h_meta_bytes; b->ev_staged = r.ev_staged;
@@ -520,7 +546,7 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
     b->h_base_off.resize((size_t)n);
     for (int i = 0; i < n; i++) b->h_base_off[(size_t)i] = rd[(size_t)i].base_off;
     if (!b->h_sigoff) {
-        b->h_n = (size_t)n + 1 + (size_t)n / 8;
+        b->h_n = (size_t)n + 1 + (size_t)n / 8 + SQG_HRES_LL;
         CHKB(hipHostMalloc(&b->h_sigoff, b->h_n * sizeof(long long), hipHostMallocMapped));
         CHKB(hipHostGetDevicePointer((void**)&b->h_sigoff_dev, b->h_sigoff, 0));
         for (auto& e : b->ev) CHKB(hipEventCreate(&e));

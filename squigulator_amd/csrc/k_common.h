@@ -243,6 +243,8 @@ struct SigParams {
     unsigned int* fix_sh_count;  // one returning atomic per item with undecided samples, on one of FIX_SHARDS counters 128 B apart)
     unsigned int fix_sh_cap;     // entries per list (sized by the batch: >= FIX_SHARD_CAP_MIN, four times the fix-ups a batch of its size expects)
     unsigned int* fix_sh_stat;   // [FIX_SHARDS] entries k_fixup took from each list
+    unsigned int* host_res;      // device-visible pinned host memory of the batch: k_fixup leaves [0] the batch's error word, [1] the global list's
+                                 // count, [4 + s] the entries it took from list s -- sqg_batch_wait reads them without a copy of its own
     int fix_tag;                 // FixEntry.pad of this batch's entries (a list's count may include entries that went to the global list instead)
     uint2* evrec;                // per event {stream state at its first draw, k-mer rank}
     uint32_t* evrec32;           // bucketed hand-out, wavefront-per-link passes (k_part_events.h): INSTEAD of evrec, 4 B per event between the

@@ -713,9 +713,11 @@ __global__ __launch_bounds__(256) void k_fixup(const SigParams P) {
         for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
         if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
         __syncthreads();
-        if (threadIdx.x == 0) P.fix_sh_stat[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (threadIdx.x == 0) { const unsigned int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3]; P.fix_sh_stat[blockIdx.x] = tot; if (P.host_res) P.host_res[4 + blockIdx.x] = tot; }
     }
-    const unsigned int n = min(*P.fix_count, P.fix_cap);
+    const unsigned int n_all = *P.fix_count, n = min(n_all, P.fix_cap);
+    // (the batch's last kernel, behind everything that reports into the error word: the host finds both without a read-back)
+    if (P.host_res && blockIdx.x == 0 && threadIdx.x == 0) { P.host_res[0] = *P.err; P.host_res[1] = n_all; }
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) fixup_one(P, P.fix[i]);
     // the batch's last kernel: the per-read sample totals have been read by everything that needs them, and the slot's next batch
     // wants them zero (the pieces of a read add theirs up: k_part_events.h) -- saves that batch a fill kernel in front of its first pass

@@ -131,3 +131,33 @@ def test_a_batch_counted_ahead_and_then_freed_leaves_nothing_behind():
     for a, b in zip(*sigs):
         for x, y in zip(a, b):
             np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [1, 3])
+def test_draws_made_ahead_are_the_draws(T):
+    """few workers: a thread of the context makes the per-read `offset` / `median_before` draws (host libm) ahead of staging; staging
+    takes what is ready and draws the rest -- whatever the split, the doubles are the oracle's.  Small batches with pauses (the ring
+    runs ahead), one batch larger than the ring (prefix from the ring, the rest shared by the helper threads), sqg_skip_reads in
+    between (the streams move another way: the ring starts over)."""
+    import time
+    rng = np.random.default_rng(123)
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    k = profiles.default_kmer_size(fl)
+    mean, stdv = model.synthetic_model(k)
+    sizes = [300, 17, 1200, 300, 20000, 5, 900, 300]
+    batches = [_reads(rng, m, 20, 60) for m in sizes]
+    orac = orc.Oracle(prof, fl, k, mean, stdv, 11, num_workers=T)
+    want = [orac.run_batch_seqs(bt, want_ss=False) for bt in batches]
+    orac.close()
+    gen = api.SignalGenerator(prof, fl, k, mean, stdv, 11, num_workers=T, mode=api.MODE_CERTIFIED)
+    for bi, bt in enumerate(batches):
+        b = gen.submit(bt)
+        for i, w in enumerate(want[bi]):
+            assert b.offset[i] == w.offset and b.median_before[i] == w.median_before, (bi, i)
+        sig = b.signal()
+        for i in (0, len(bt) // 2, len(bt) - 1):
+            np.testing.assert_array_equal(sig[b.sig_off[i]:b.sig_off[i + 1]], want[bi][i].sig)
+        b.free()
+        time.sleep(0.03)                                            # the draw-ahead thread fills its ring
+    gen.close()

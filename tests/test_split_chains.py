@@ -337,7 +337,10 @@ def test_thousands_of_reads_per_worker(name, T, threads, monkeypatch):
     assert gen.set_stage_threads(int(threads) if threads else 0) == 0          # nothing staged yet
     for bi, bt in enumerate(batches):
         b = gen.submit(bt)
-        assert gen.set_stage_threads(int(threads) if threads else 0) == (int(threads) if threads else 1)   # (automatic: one below 8192 reads)
+        used = gen.set_stage_threads(int(threads) if threads else 0)
+        # (automatic: one below 8192 reads.  From the second batch on the context's draw-ahead thread may have made some of the draws
+        # already: fewer are left to share)
+        assert used == (int(threads) if threads else 1) if bi == 0 else 1 <= used <= (int(threads) if threads else 1)
         sig = b.signal()
         for i, w in enumerate(want[bi]):
             assert b.offset[i] == w.offset and b.median_before[i] == w.median_before, (bi, i)
