@@ -195,7 +195,14 @@ def pmc_step_traffic(workload_key):
     (profiles/traffic_latest.json); None when no profile of this workload and this build exists"""
     doc = _traffic_doc(workload_key)
     try:
-        return None if doc is None else float(sum(v["hbm_bytes_per_launch"] for k, v in doc["kernels"].items() if k.startswith(STEP_KERNELS)))
+        if doc is None:
+            return None
+        ks = doc["kernels"]
+        # with the next batch staged ahead (the timed region: everything is) a step's hand-out and the next step's counting pass are ONE
+        # launch (k_part_hand_count); the two kernels it replaces only run for the first batch and are not part of a steady-state step
+        fused = any(k.startswith("k_part_hand_count") for k in ks)
+        skip = ("k_part_hand_ord", "k_part_events<1, 0>", "k_part_events<2, 0>") if fused else ()
+        return float(sum(v["hbm_bytes_per_launch"] for k, v in ks.items() if k.startswith(STEP_KERNELS) and not k.startswith(skip)))
     except (KeyError, ValueError):
         return None
 
