@@ -232,16 +232,22 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 // precount: the batch staged behind this one, if its first event pass can ride along with this batch's hand-out
                 // (k_part_hand_count, k_part_events.h): same kind of batch, nothing in between, the plain launch sequence
                 sqg_batch* nb = nullptr;
-                if (phase == 0 && c->lds_ordered && wave_links && !b->one && dw != 0 && !c->range_mode && !c->staged_q.empty() && !SQG_DEV_ENV("SQG_NO_PRECOUNT")) {
+                if (phase == 0 && c->lds_ordered && wave_links && dw != 0 && !c->range_mode && !c->staged_q.empty() && !SQG_DEV_ENV("SQG_NO_PRECOUNT")) {
                     sqg_batch* cand = c->staged_q.front();
-                    if (cand->seq > b->seq && cand->staged && !cand->ran && !cand->begun && !cand->precounted && cand->part && cand->pieces && !cand->one &&
+                    if (cand->seq > b->seq && cand->staged && !cand->ran && !cand->begun && !cand->precounted && cand->part && cand->pieces && cand->one == b->one &&
                         cand->n > 0 && cand->n_chains > 0) nb = cand;
                 }
                 if (nb) {
                     const int ncs = (int)((b->run_idx + 1) % 3);
                     sqg_ctx::CountSet& NQ = c->cset[ncs];
                     if ((rc = grow_cset(c, NQ, nb))) return rc;
-                    if ((rc = ensure(c, (void**)&c->d_pcnt, &c->pcnt_cap, (size_t)2 * nb->n_chains * (size_t)n_part, sizeof(uint32_t)))) return rc;
+                    if (!nb->one && (rc = ensure(c, (void**)&c->d_pcnt, &c->pcnt_cap, (size_t)2 * nb->n_chains * (size_t)n_part, sizeof(uint32_t)))) return rc;
+                    if (nb->one) {
+                        // one partition (k <= 6): the pass writes part[] of the next batch's slot -- the other one, which the fix-ups of the batch
+                        // before this one (fix_stream) may still be reading
+                        if ((rc = ensure(c, (void**)&other.d_part, &other.part_cap, (size_t)nb->n_events + PART_SLACK, sizeof(uint32_t)))) return rc;
+                        HIPCHK(c, hipStreamWaitEvent(c->stream, other.done, 0));
+                    }
                     if (nb->ev_staged && hipEventQuery(nb->ev_staged) != hipSuccess) HIPCHK(c, hipStreamWaitEvent(c->stream, nb->ev_staged, 0));
                     if (nb->split_reads && NQ.seglen_dirty > 0) {
                         HIPCHK(c, hipMemsetAsync(NQ.d_seglen, 0, (size_t)2 * std::max<size_t>((size_t)nb->n, NQ.seglen_dirty) * sizeof(unsigned long long), c->stream));
@@ -251,6 +257,7 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                     SigParams Pn;
                     memset(&Pn, 0, sizeof Pn);
                     count_params(c, nb, NQ, n_part, Pn);
+                    if (nb->one) { Pn.one = 1; Pn.part = other.d_part; Pn.poff = nb->d_link_slot; }
                     const dim3 fg((unsigned)(dev_env_int(SQG_DEV_ENV("SQG_PHC_GRID"), 4) * c->num_cu)), ft(64 * (1 + PHC_COUNT_WAVES));   // (A/B: workgroups per CU)
                     // (development build, timing experiments: 1 -- the fused launch hands out only, the next batch's pass follows as a launch
                     // of its own; 2 -- the plain hand-out first, the fused launch counts only)
@@ -258,13 +265,16 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                     if (phc_abl == 2) hipLaunchKernelGGL(k_part_hand_ord, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, b->d_err, order_fault);
                     const uint32_t* const ns_ptr = phc_abl == 2 ? c->d_phc_q + 3 : pfirst + n_pairs;      // (word 3 of the queue block is always zero)
                     const int nl_fused = phc_abl == 1 ? 0 : nb->n_chains;
-#define PHCL(D_) hipLaunchKernelGGL((k_part_hand_count<D_>), fg, ft, 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, ns_ptr, c->d_phist, c->d_pow, \
+#define PHCL(D_, M_) hipLaunchKernelGGL((k_part_hand_count<D_, M_>), fg, ft, 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, ns_ptr, c->d_phist, c->d_pow, \
                                     b->d_err, order_fault, Pn, nl_fused, (uint32_t)nb->n_events, c->num_cu)
-                    if (dw == 1) PHCL(1); else PHCL(2);
+                    if (nb->one) { if (dw == 1) PHCL(1, PEV_ONE); else PHCL(2, PEV_ONE); }
+                    else { if (dw == 1) PHCL(1, PEV_COUNT); else PHCL(2, PEV_COUNT); }
 #undef PHCL
                     if (phc_abl == 1) {
                         const dim3 g1((unsigned)((nb->n_chains + PEV_WAVES - 1) / PEV_WAVES)), t1(64 * PEV_WAVES);
-                        if (dw == 1) hipLaunchKernelGGL((k_part_events<1, PEV_COUNT>), g1, t1, 0, c->stream, Pn, nb->n_chains, (uint32_t)nb->n_events);
+                        if (nb->one) { if (dw == 1) hipLaunchKernelGGL((k_part_events<1, PEV_ONE>), g1, t1, 0, c->stream, Pn, nb->n_chains, (uint32_t)nb->n_events);
+                                       else hipLaunchKernelGGL((k_part_events<2, PEV_ONE>), g1, t1, 0, c->stream, Pn, nb->n_chains, (uint32_t)nb->n_events); }
+                        else if (dw == 1) hipLaunchKernelGGL((k_part_events<1, PEV_COUNT>), g1, t1, 0, c->stream, Pn, nb->n_chains, (uint32_t)nb->n_events);
                         else hipLaunchKernelGGL((k_part_events<2, PEV_COUNT>), g1, t1, 0, c->stream, Pn, nb->n_chains, (uint32_t)nb->n_events);
                     }
                     nb->precounted = true; nb->cset = ncs; nb->cset_gen = ++NQ.gen;

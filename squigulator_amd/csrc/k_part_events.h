@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64 * (MODE == PEV_SCATTER ? PEV_WAVES_SCATTER : PEV
 #ifndef PHC_PRIO
 #define PHC_PRIO 0                       // A/B: the hand-out wavefront at a raised issue priority (s_setprio)
 #endif
-template <int DW>
+template <int DW, int MODE>
 __global__ __launch_bounds__(64 * (1 + PHC_COUNT_WAVES), 4) void k_part_hand_count(
         const uint32_t* __restrict__ part, uint32_t* __restrict__ state_out, const uint32_t* __restrict__ slice_lo, const uint32_t* __restrict__ slice_hi,
         const uint32_t* __restrict__ n_slices, const uint32_t* __restrict__ phist, const uint32_t* __restrict__ pw, unsigned int* __restrict__ err, const int fault,
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64 * (1 + PHC_COUNT_WAVES), 4) void k_part_hand_cou
         const int m = wid - (wid > hw ? 1 : 0);
         PevWave<false>& Wm = W[m];
         for (int li = (int)blockIdx.x * PHC_COUNT_WAVES + m; li < n_links_n; li += (int)gridDim.x * PHC_COUNT_WAVES)
-            pev_link<DW, PEV_COUNT>(Pn, T, Wm, li, dump_n, lane);
+            pev_link<DW, MODE>(Pn, T, Wm, li, dump_n, lane);                 // MODE: COUNT (k > 6), or ONE (k <= 6: the only event pass)
     }
 }
 

@@ -22,8 +22,9 @@ def _check(b, want, tag):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,T,lens", [("dna-r10-prom", 1, (300, 4000)), ("dna-r10-prom", 3, (200, 2500)), ("rna004-prom", 1, (300, 2500)),
-                                         ("dna-r10-prom", 1, (9000, 30000))],      # the last: reads cut into pieces of several links (totals added up)
-                         ids=["r10_t1", "r10_t3", "rna004_t1", "r10_long_reads"])
+                                         ("dna-r10-prom", 1, (9000, 30000)),       # reads cut into pieces of several links (totals added up)
+                                         ("dna-r9-prom", 1, (300, 4000)), ("dna-r9-prom", 3, (9000, 30000)), ("rna-r9-prom", 2, (300, 2500))],   # k <= 6: one partition, ONE event pass
+                         ids=["r10_t1", "r10_t3", "rna004_t1", "r10_long_reads", "r9_t1", "r9_t3_long_reads", "rna9_t2"])
 @pytest.mark.parametrize("mode", [api.MODE_CERTIFIED, api.MODE_EXACT], ids=["certified", "exact"])
 def test_batches_staged_ahead_equal_the_oracle(name, T, lens, mode):
     rng = np.random.default_rng(99)
