@@ -91,15 +91,31 @@ def test_random_few_worker_configuration_matches_oracle(seed, monkeypatch):
     orac = orc.Oracle(prof, flags, k, mean, stdv, s, num_workers=T)
     want = [orac.run_batch_seqs(bt) for bt in batches]
     orac.close()
+    def check(b, bi, mode, how):
+        sig, dw = b.signal(), b.dwell()
+        for i, w in enumerate(want[bi]):
+            np.testing.assert_array_equal(sig[b.sig_off[i]:b.sig_off[i + 1]], w.sig,
+                                          err_msg=f"seed {seed} mode {mode} {how} batch {bi} read {i} (k={k} T={T} flags={flags:#x} links={links} dwell={prof.dwell_mean}/{prof.dwell_std})")
+            np.testing.assert_array_equal(dw[b.ev_off[i]:b.ev_off[i + 1]], w.ss)
+            assert b.offset[i] == w.offset and b.median_before[i] == w.median_before
     for mode in (api.MODE_CERTIFIED, api.MODE_EXACT):
         gen = api.SignalGenerator(prof, flags, k, mean, stdv, s, num_workers=T, mode=mode)
         for bi, bt in enumerate(batches):
             b = gen.submit(bt)
-            sig, dw = b.signal(), b.dwell()
-            for i, w in enumerate(want[bi]):
-                np.testing.assert_array_equal(sig[b.sig_off[i]:b.sig_off[i + 1]], w.sig,
-                                              err_msg=f"seed {seed} mode {mode} batch {bi} read {i} (k={k} T={T} flags={flags:#x} links={links} dwell={prof.dwell_mean}/{prof.dwell_std})")
-                np.testing.assert_array_equal(dw[b.ev_off[i]:b.ev_off[i + 1]], w.ss)
-                assert b.offset[i] == w.offset and b.median_before[i] == w.median_before
+            check(b, bi, mode, "submit")
             b.free()
+        gen.close()
+        # the same job streamed: batch i+2 staged, batch i+1 queued, batch i consumed -- every run finds its successor staged, whose first
+        # event pass then rides along with this batch's hand-out (k_part_hand_count) wherever the kind of batch allows it
+        gen = api.SignalGenerator(prof, flags, k, mean, stdv, s, num_workers=T, mode=mode)
+        cur = gen.stage(batches[0]).run()
+        nxt = gen.stage(batches[1]) if len(batches) > 1 else None
+        for bi in range(len(batches)):
+            nn = gen.stage(batches[bi + 2]) if bi + 2 < len(batches) else None
+            if nxt is not None:
+                nxt.run()
+            cur.wait()
+            check(cur, bi, mode, "streamed")
+            cur.free()
+            cur, nxt = nxt, nn
         gen.close()
