@@ -90,9 +90,15 @@ def main():
     fixups = 0
     diffs = []
     sigbuf = None
+    # one batch staged ahead of the one being queued, as a streaming host does: every sqg_batch_run finds its successor staged, so that the
+    # successor's first event pass rides along with this batch's hand-out (k_part_hand_count) -- the path the bench times
     nxt = [g.sample(K).run() for g in gens]
+    ahead = [g.sample(K) for g in gens]
     while True:
-        cur, nxt = nxt, [g.sample(K).run() for g in gens]
+        cur, nxt = nxt, ahead
+        ahead = [g.sample(K) for g in gens]
+        for b in nxt:
+            b.run()
         ob = q.get()
         rd = ob.contents.reads
         for (mname, _), g, b in zip(modes, gens, cur):
@@ -144,6 +150,8 @@ def main():
         pass
     for b in nxt:
         b.wait(); b.free()
+    for b in ahead:
+        b.free()
     for g in gens:
         g.close()
     orac.close()
