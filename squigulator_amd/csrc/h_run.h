@@ -381,8 +381,8 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             fprintf(stderr, "[sqg] batch %lld slot %d: sig %p part %p evrec %p part_state %p dwell %p bases %p seglen %p\n", (long long)b->run_idx, b->slot,
                     (void*)S.d_sig, (void*)S.d_part, (void*)S.d_evrec, (void*)S.d_part_state, (void*)Q.d_dwell, (void*)b->d_bases, (void*)Q.d_seglen);
         if (b->run_idx < 8 && getenv("SQG_VERBOSE"))
-            fprintf(stderr, "[sqg] batch %lld: %d reads, %lld events, %d links in %d worker chains, %d pieces, %lld slices of %u events at most\n", (long long)b->run_idx, n, (long long)b->n_events,
-                    b->n_chains, b->n_wchains, b->n_pieces, (long long)b->max_slices, b->slice_len);
+            fprintf(stderr, "[sqg] batch %lld: %d reads, %lld events, %d links in %d worker chains, %d pieces, %lld slices of %u events at most%s\n", (long long)b->run_idx, n, (long long)b->n_events,
+                    b->n_chains, b->n_wchains, b->n_pieces, (long long)b->max_slices, b->slice_len, b->precounted ? "; first event pass: ran ahead, with the previous batch's hand-out" : "");
         const bool rna_prefix = (c->cfg.flags & SQG_RNA) && (c->cfg.flags & SQG_PREFIX);
         P.shift_len = rna_prefix ? (int)strlen(kAdaptorRna) * (int)p.dwell_mean : 0;
         {   // int16_t off = 30*dig/range (src/genread.c:82): double -> int16 as the CPU does it
