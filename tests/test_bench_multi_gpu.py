@@ -100,6 +100,16 @@ def test_genome_broadcast_from_rank0_and_numa_pin():
 
 
 @pytest.mark.gpu
+def test_order_free_flag_gives_the_same_bytes():
+    """bench.py --order-free (SQG_ORDER_FREE in cfg.flags: the kernels that do not rely on lane-ordered LDS atomics) -- the fallback whose cost
+    profiles/r04_summary.md quotes: same reads, same signals"""
+    args = ["--genome-mb", 24, "--workers-per-gpu", 1, "--batch-reads", 1024, "--digest", 4]
+    a = _bench("--gpus", 1, *args)
+    b = _bench("--gpus", 1, "--order-free", *args)
+    assert a["digest"] == b["digest"] and b["config"]["order_free"] is True and a["config"]["order_free"] is False
+
+
+@pytest.mark.gpu
 def test_gpus_flag_without_enough_devices_fails_loudly():
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
