@@ -2,12 +2,19 @@
 # the whole GPU suite under each fall-back / forced setting of the few-worker paths (tests that set the same variable themselves keep
 # their own value): tools/suite_variants.sh    (about 80 s per variant on one MI355X)
 cd "$(dirname "$0")/.."
-skip_ord="--deselect tests/test_split_chains.py::test_lds_atomics_are_served_in_lane_order"
+# (tests that check the DEFAULT choice of kernels, or a fault hook of the kernels a setting switches off, do not apply under that setting)
+skip_ord="--deselect tests/test_split_chains.py::test_lds_atomics_are_served_in_lane_order --deselect tests/test_split_chains.py::test_order_free_kernels_are_selectable_through_the_cfg --deselect tests/test_split_chains.py::test_every_batch_samples_the_lane_order_and_fails_loudly"
 skip_cmp="--deselect tests/test_split_chains.py::test_split_and_unsplit_runs_agree_at_size"
-run() { echo "== $1"; shift; env "$@" 2>&1 | tail -1; }
+# (a development knob in the environment makes the binding load libsqg_hip_dev.so: the tests about the release library's line / path are left out)
+skip_rel="--deselect tests/test_bench_multi_gpu.py::test_bench_line_carries_the_contract --deselect tests/test_precount.py::test_precount_is_taken_and_can_be_switched_off"
+run() { echo "== $1"; shift; env "$@" $skip_rel 2>&1 | tail -3; }
 run "order-free kernels"            SQG_PART_CLAIMS=1      python -m pytest tests -q -m gpu -x $skip_ord
-run "per-link rows (round 1)"       SQG_NO_PART=1          python -m pytest tests -q -m gpu -x
-run "workgroup-per-link passes"     SQG_PART_WG_EVENTS=1   python -m pytest tests -q -m gpu -x
+# (per-link rows, k > 6: a worker whose reads of one batch may draw >= 2^32 samples is refused at staging, SQG_EINVAL, where the bucketed hand-out
+# reports SQG_EOVERFLOW at the wait)
+run "per-link rows (round 1)"       SQG_NO_PART=1          python -m pytest tests -q -m gpu -x $skip_ord --deselect "tests/test_long_reads.py::test_a_read_of_uint32_max_samples_is_an_error_not_a_crash[dna-r10-prom]"
+run "workgroup-per-link passes"     SQG_PART_WG_EVENTS=1   python -m pytest tests -q -m gpu -x $skip_ord
 run "1024-event slices"             SQG_PART_SLICE=1024    python -m pytest tests -q -m gpu -x
 run "one piece per segment"         SQG_SPLIT_CHAINS=100000 python -m pytest tests -q -m gpu -x $skip_cmp
 run "three links"                   SQG_SPLIT_CHAINS=3     python -m pytest tests -q -m gpu -x $skip_cmp
+run "no precount"                   SQG_NO_PRECOUNT=1      python -m pytest tests -q -m gpu -x
+run "no draw-ahead thread"          SQG_NO_DRAW_AHEAD=1    python -m pytest tests -q -m gpu -x
