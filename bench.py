@@ -372,39 +372,54 @@ def cpu_reference(prof, flags, k, mean, stdv, fasta_path, rlen, seconds=10.0):
                       f"output); `t1`: one process alone; `to_blow5`: the same {cores} processes writing BLOW5 (zlib+svb-zd) through slow5lib"}
 
 
-def cpu_port(prof, flags, k, mean, stdv, reads, workers, nthreads):
-    """the oracle restatement (oracle/libsqg_oracle.so) on the same reads -> (per-read results, samples/s)"""
+def cpu_port(prof, flags, k, mean, stdv, batches, T, nthreads):
+    """the oracle restatement (oracle/libsqg_oracle.so) on the same batches of reads, one after the other (the streams carry over)
+    -> (per-batch per-read results, samples/s)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orc
-    T = int(max(workers)) + 1 if len(workers) else 1
     o = orc.Oracle(prof, flags, k, mean, stdv, 42, num_workers=T)
     t0 = time.perf_counter()
-    res = o.run_batch_seqs(reads, want_ss=False, nthreads=nthreads if T > 1 else 1)      # (the reference's static partition over T)
+    res = [o.run_batch_seqs(reads, want_ss=False, nthreads=nthreads if T > 1 else 1) for reads in batches]      # (the reference's static partition over T)
     dt = time.perf_counter() - t0
     o.close()
-    return res, sum(len(r.sig) for r in res) / dt
+    return res, sum(len(r.sig) for rb in res for r in rb) / dt
 
 
 def parity_check(prof, flags, k, mean, stdv, contigs, rlen, n_reads, one_worker, mode):
-    """the oracle as the checker: n_reads host-drawn reads of the workload through the oracle and through the C ABI in the
-    bench's regime (one worker: the chain is cut into links, bucketed hand-out for 9-mers; else one worker per read), every
-    int16 compared"""
+    """the oracle as the checker: n_reads host-drawn reads of the workload, in three batches, through the oracle and through the C ABI in
+    the bench's regime -- one worker: the chains are cut into links, bucketed hand-out for 9-mers; else one worker per read -- and in the
+    timed region's launch pattern: every batch is run with its successor already staged (whose first event pass then rides along with
+    this batch's hand-out, k_part_hand_count).  Every int16 compared."""
     rng = np.random.default_rng(1234)
     reads = sample_reads_host(contigs, n_reads, rlen, rng)
-    workers = np.zeros(n_reads, np.int32) if one_worker else np.arange(n_reads, dtype=np.int32)
-    res, rate = cpu_port(prof, flags & ~profiles.SQ_ORDER_FREE, k, mean, stdv, reads, workers, nthreads=min(os.cpu_count() or 1, 64))
-    gen = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=int(workers.max()) + 1, mode=mode)
-    b = gen.submit(reads, workers)
-    sig = b.signal()
-    bad = 0
-    for i, r in enumerate(res):
-        got = sig[b.sig_off[i]:b.sig_off[i + 1]]
-        if len(got) != len(r.sig) or not np.array_equal(got, r.sig):
-            bad += 1
-    ns = int(sum(len(r.sig) for r in res))
-    out = {"reads": n_reads, "samples": ns, "reads_differing": bad, "equal": bad == 0 and int(b.n_samples) == ns,
-           "regime": "-t 1" if one_worker else "T = K"}
-    b.free(); gen.close()
+    per = (n_reads + 2) // 3
+    batches = [reads[i:i + per] for i in range(0, n_reads, per)]
+    T = 1 if one_worker else max(len(bt) for bt in batches)
+    res, rate = cpu_port(prof, flags & ~profiles.SQ_ORDER_FREE, k, mean, stdv, batches, T, nthreads=min(os.cpu_count() or 1, 64))
+    gen = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=T, mode=mode)
+    bad = ns_gpu = 0
+
+    def compare(b, want):
+        nonlocal bad, ns_gpu
+        sig = b.signal()
+        ns_gpu += int(b.n_samples)
+        for i, r in enumerate(want):
+            got = sig[b.sig_off[i]:b.sig_off[i + 1]]
+            if len(got) != len(r.sig) or not np.array_equal(got, r.sig):
+                bad += 1
+        b.free()
+    staged = [gen.stage(batches[0], np.zeros(len(batches[0]), np.int32) if one_worker else None)]
+    for i in range(len(batches)):
+        if i + 1 < len(batches):
+            staged.append(gen.stage(batches[i + 1], np.zeros(len(batches[i + 1]), np.int32) if one_worker else None))
+        staged[i].run()
+        if i >= 1:
+            compare(staged[i - 1].wait(), res[i - 1])
+    compare(staged[-1].wait(), res[-1])
+    ns = int(sum(len(r.sig) for rb in res for r in rb))
+    out = {"reads": n_reads, "samples": ns, "reads_differing": bad, "equal": bad == 0 and ns_gpu == ns,
+           "regime": "-t 1" if one_worker else "T = K", "batches": len(batches), "staged_ahead": True}
+    gen.close()
     return out, rate
 
 
