@@ -697,6 +697,10 @@ def main():
         return gen.sample(K * world, None, lo=r_lo, hi=r_hi) if range_mode else gen.sample(K, workers)
 
     batches = [stage_one() for _ in range(min(nsteps, args.warmup + STAGE_AHEAD))]
+    # ... and the batch BEHIND the last timed one: staged, never run.  Every timed run then finds a successor whose first event pass it
+    # takes along (k_part_hand_count), as the first timed batch's pass was taken along by the last warm-up batch: the timed region holds
+    # exactly K of everything (without it the K-th counting pass would be missing from it)
+    tail = [stage_one()] if len(batches) == nsteps else []
 
     def sync_all():
         torch.cuda.synchronize()
@@ -749,6 +753,8 @@ def main():
             b.free()
             timed[i] = None
             nb = stage_one()
+            if to_stage == 1:
+                tail.append(stage_one())  # (the successor of the run's last batch, as above)
             run(nb)
             timed.append(nb)
             to_stage -= 1
@@ -794,9 +800,9 @@ def main():
     # the streaming leg: the same job with nothing staged ahead (the sampler's and the staging kernels share the GPU with the generator)
     pipe = None
     if args.pipeline_seconds > 0 and not args.digest:
-        for b in batches[:args.warmup] + [b for b in timed if b is not None]:
+        for b in batches[:args.warmup] + [b for b in timed if b is not None] + tail:
             b.free()
-        batches, timed = [], []
+        batches, timed, tail = [], [], []
         n_pipe = int(min(max(args.pipeline_seconds / max(dt_max / max(args.steps, 1), 1e-5), 8), 20000))
         sync_all()
         pipe = pipeline_leg(stage_one, run, n_pipe)
@@ -804,9 +810,9 @@ def main():
 
     e2e = None
     if args.e2e_seconds > 0 and world == 1 and not range_mode and not args.digest:
-        for b in batches[:args.warmup] + [b for b in timed if b is not None]:
+        for b in batches[:args.warmup] + [b for b in timed if b is not None] + tail:
             b.free()
-        batches, timed = [], []
+        batches, timed, tail = [], [], []
         Ke = min(args.e2e_batch_reads, K)
         we = workers[:Ke] if not W else np.minimum(w_lo + np.arange(Ke, dtype=np.int32) // max(Ke // W, 1), w_hi - 1).astype(np.int32)
         sync_all()
@@ -931,7 +937,7 @@ def main():
             out["cpu_baseline"] = ref or {"value": port_rate, "unit": "samples/s", "cores": 1 if one_worker else min(os.cpu_count() or 1, 64),
                                           "kind": "port", "sample": f"oracle restatement on the {n_chk} reads of parity_check"}
         print(json.dumps(out))
-    for b in batches[:args.warmup] + [b for b in timed if b is not None]:
+    for b in batches[:args.warmup] + [b for b in timed if b is not None] + tail:
         b.free()
     gen.close()
     if use_dist:
