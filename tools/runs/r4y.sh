@@ -1,5 +1,6 @@
-export BENCH_ARGS="--pipeline-seconds 0 --e2e-seconds 0 --steps 16"
-for rep in 1 2; do
-for e in "SQG_VERBOSE=0" "SQG_OVERLAP=1" "SQG_OVERLAP=1 SQG_LEAN_DYNLDS=2048" "SQG_OVERLAP=1 SQG_LEAN_DYNLDS=4096" "SQG_OVERLAP=1 SQG_LEAN_DYNLDS=9600" "SQG_LEAN_DYNLDS=4096"; do
-r=$(env $e timeout 300 python bench.py --lib $PWD/squigulator_amd/csrc/libsqg_hip_dev.so --no-cpu-baseline --no-store-probe $BENCH_ARGS 2>/dev/null | python tools/ab_line.py); echo "$e: $r"; done
-done
+#!/bin/bash
+# grouped sample loop: parity first, then the A/B of the two loops in one call
+cd "$(dirname "$0")/../.."
+mkdir -p gpurun_out/r4y
+timeout 1500 python -m pytest tests/test_hip_parity.py tests/test_fuzz_parity.py tests/test_config2_hg38.py -m gpu -q -x 2>&1 | tail -5
+bash tools/ab_step.sh 2>&1 | tee gpurun_out/r4y/ab.log
