@@ -454,7 +454,7 @@ def e2e_legs(gen, prof, flags, sample_batch, reads_per_batch, seconds):
     """The other half of work_per_single_read / output_db (src/sim.c:602-611,630-641): what a host that drains the results gets
     (SURVEY.md 8d / H5).  Three legs, one host thread each, batch i+1 sampled + staged + queued before batch i is consumed:
     `pinned_int16` -- sqg_fetch_signal into sqg_host_alloc memory (raw int16 over PCIe); `pinned_svb` -- sqg_batch_compress (svb-zd on
-    the device, the signal field of a BLOW5 record) + sqg_fetch_svb; `blow5` -- sqg_blow5_write_batch into /dev/shm (record framing +
+    the device, the signal field of a BLOW5 record), then batch i+1 queued, then sqg_fetch_svb; `blow5` -- sqg_blow5_write_batch into /dev/shm (record framing +
     zlib on the host's threads: the bytes the reference writes).  Never `value`: PCIe and zlib are 20x and 1500x below the kernels."""
     import torch
     probe = sample_batch().run().wait()
@@ -476,7 +476,7 @@ def e2e_legs(gen, prof, flags, sample_batch, reads_per_batch, seconds):
             if kind == "pinned_int16":
                 b.signal(out=pin16); nbytes += 2 * b.n_samples
             elif kind == "pinned_svb":
-                enc, _ = b.compress(fetch=True, out=pin8); nbytes += len(enc)
+                nbytes += len(b.fetch_svb(out=pin8))
             else:
                 w.write_batch(b, ids)
         try:
@@ -485,6 +485,8 @@ def e2e_legs(gen, prof, flags, sample_batch, reads_per_batch, seconds):
             t0 = time.perf_counter()
             while True:
                 last = nb >= 1 and time.perf_counter() - t0 >= seconds
+                if kind == "pinned_svb":                       # the encoder first (the context has ONE buffer of encodings: it cannot run ahead),
+                    cur.compress(fetch=False)                  # the next batch's kernels behind it -- they run while the bytes cross PCIe
                 nxt = None if last else sample_batch().run()
                 cur.wait()
                 drain(cur)

@@ -363,13 +363,22 @@ class Batch:
         r = CSvb()
         self.gen._chk(self.gen.L.sqg_batch_compress(self.gen.ctx, self.handle, C.byref(r)), "sqg_batch_compress")
         off = np.ctypeslib.as_array(r.svb_off, shape=(self.n_reads + 1,)).copy()
+        self._svb_bytes = int(r.n_bytes)
         if not fetch:
             return None, off
-        if out is not None and len(out) < r.n_bytes:
+        return self.fetch_svb(out), off
+
+    def fetch_svb(self, out: np.ndarray | None = None):
+        """the encodings compress(fetch=False) left on the device (sqg_fetch_svb): a host that queues its next batch between the two
+        calls has that batch's kernels running while these bytes cross PCIe"""
+        n = getattr(self, "_svb_bytes", None)
+        if n is None:
+            raise ValueError("fetch_svb needs a compress() of this batch first")
+        if out is not None and len(out) < n:
             raise ValueError("destination too small for the batch's encodings")
-        out = np.empty(r.n_bytes, np.uint8) if out is None else out[:r.n_bytes]
+        out = np.empty(n, np.uint8) if out is None else out[:n]
         self.gen._chk(self.gen.L.sqg_fetch_svb(self.gen.ctx, self.handle, out.ctypes.data), "sqg_fetch_svb")
-        return out, off
+        return out
 
     def free(self):
         if self.handle:
