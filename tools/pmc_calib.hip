@@ -10,6 +10,7 @@
 //                   slots bucketed by a random 6-bit partition exactly as part[] is laid out (runs of a (link, partition) are
 //                   consecutive slots: a 256-event item touches 64 partitions x ~4 consecutive words)
 //   cal_gather_xcd  the same with the workgroup -> item map that keeps consecutive items on one XCD (blockIdx % 8 = XCD)
+//   cal_rgather8    8 B per lane from a 2-MiB table at random places, 16 per lane (k_samples_lean's pore-table look-up)
 //   cal_write2      int16 per lane, lanes contiguous (128 B per wave store) (the signal stores of k_samples_lean)
 //   cal_write4      4 B per lane, lanes contiguous                     (k_part_hand_ord: state[])
 //   cal_write16     16 B per lane                                      (k_store_probe)
@@ -58,6 +59,15 @@ __global__ __launch_bounds__(256) void cal_gather(const uint4* __restrict__ slot
     const uint4 s = slots[(size_t)g * 64 + lane];
     uint32_t acc = s.x ^ s.y ^ s.z ^ s.w;
     if (MODE == 1) acc ^= state[s.x] ^ state[s.y] ^ state[s.z] ^ state[s.w];
+    if (acc == 0x12345u) sink[0] = acc;
+}
+// 8 B per lane from a 2-MiB table at random places (k_samples_lean's pore-table look-up: the table lives in L2), 16 look-ups per lane
+__global__ __launch_bounds__(256) void cal_rgather8(const uint2* __restrict__ tab, const unsigned n_items, uint32_t* __restrict__ sink) {
+    const unsigned g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= n_items) return;
+    uint32_t h = (g * 64 + (threadIdx.x & 63)) * 2654435761u, acc = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { h = h * 1664525u + 1013904223u; const uint2 v = tab[h >> 14]; acc ^= v.x + v.y; }
     if (acc == 0x12345u) sink[0] = acc;
 }
 __global__ __launch_bounds__(256) void cal_write2(uint16_t* __restrict__ a, size_t n, uint32_t v) {
@@ -110,6 +120,7 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL((cal_gather<0, false>), dim3(ggrid), dim3(256), 0, 0, (const uint4*)d_slot, d_state, n_items, d_sink);
         hipLaunchKernelGGL((cal_gather<1, false>), dim3(ggrid), dim3(256), 0, 0, (const uint4*)d_slot, d_state, n_items, d_sink);
         hipLaunchKernelGGL((cal_gather<1, true>), dim3(ggrid), dim3(256), 0, 0, (const uint4*)d_slot, d_state, n_items, d_sink);
+        hipLaunchKernelGGL(cal_rgather8, dim3(ggrid / 16), dim3(256), 0, 0, (const uint2*)d_state, n_items / 16, d_sink);   // n_ev / 4 look-ups
         hipLaunchKernelGGL(cal_write2, dim3(grid), dim3(256), 0, 0, (uint16_t*)d_out, bytes / 2, (uint32_t)r);
         hipLaunchKernelGGL(cal_write4, dim3(grid), dim3(256), 0, 0, d_out, bytes / 4, (uint32_t)r);
         hipLaunchKernelGGL(cal_write16, dim3(grid), dim3(256), 0, 0, (uint4*)d_out, bytes / 16, (uint32_t)r);
@@ -129,6 +140,7 @@ int main(int argc, char** argv) {
     timed("cal_slots", [&] { hipLaunchKernelGGL((cal_gather<0, false>), dim3(ggrid), dim3(256), 0, 0, (const uint4*)d_slot, d_state, n_items, d_sink); }, (double)bytes);
     timed("cal_gather", [&] { hipLaunchKernelGGL((cal_gather<1, false>), dim3(ggrid), dim3(256), 0, 0, (const uint4*)d_slot, d_state, n_items, d_sink); }, 2.0 * bytes);
     timed("cal_gather_xcd", [&] { hipLaunchKernelGGL((cal_gather<1, true>), dim3(ggrid), dim3(256), 0, 0, (const uint4*)d_slot, d_state, n_items, d_sink); }, 2.0 * bytes);
+    timed("cal_rgather8", [&] { hipLaunchKernelGGL(cal_rgather8, dim3(ggrid / 16), dim3(256), 0, 0, (const uint2*)d_state, n_items / 16, d_sink); }, (double)(n_ev / 4) * 8);
     timed("cal_write2", [&] { hipLaunchKernelGGL(cal_write2, dim3(grid), dim3(256), 0, 0, (uint16_t*)d_out, bytes / 2, 1u); }, (double)bytes);
     timed("cal_write4", [&] { hipLaunchKernelGGL(cal_write4, dim3(grid), dim3(256), 0, 0, d_out, bytes / 4, 1u); }, (double)bytes);
     timed("cal_write16", [&] { hipLaunchKernelGGL(cal_write16, dim3(grid), dim3(256), 0, 0, (uint4*)d_out, bytes / 16, 1u); }, (double)bytes);
