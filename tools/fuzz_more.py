@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""tests/test_fuzz_parity.py's two randomised parity tests over seeds the suite does not hold: python tools/fuzz_more.py [first] [count]
+(a one-off sweep for latent bugs: every case is the HIP path, both arithmetic modes, submitted and streamed, against the oracle)."""
+import os
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_fuzz_parity as F  # noqa: E402
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    bad = []
+    t0 = time.time()
+    for seed in range(first, first + count):
+        for fn in (F.test_random_configuration_matches_oracle, F.test_random_few_worker_configuration_matches_oracle):
+            with pytest.MonkeyPatch.context() as mp:
+                try:
+                    fn.__wrapped__(seed, mp) if hasattr(fn, "__wrapped__") else fn(seed, mp)
+                except Exception as e:  # noqa: BLE001
+                    bad.append((fn.__name__, seed, str(e)[:600]))
+                    print("FAIL", fn.__name__, seed, str(e)[:600], flush=True)
+    print(f"{2 * count} cases (seeds {first}..{first + count - 1}), {len(bad)} failures, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
