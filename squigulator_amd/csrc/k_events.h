@@ -198,11 +198,12 @@ __global__ __launch_bounds__(1024) void k_link_prefix(const SigParams P, const i
     unsigned long long sum = 0;
     if (live) for (int l = la; l < lb; l++) sum += lr[(size_t)l * P.num_kmer];
     sums[g][lane] = sum;
+    const uint32_t base = live ? P.rows[wj] : 0u;                  // read by every group BEFORE the barrier: group 0 rewrites it behind it (read behind the barrier, a
+                                                                   // group that fell behind -- another context's kernels on the same CU -- saw the advanced row: round 4)
     __syncthreads();
     unsigned long long excl = 0, total = 0;
     for (int w = 0; w < 16; w++) { const unsigned long long x = sums[w][lane]; if (w < g) excl += x; total += x; }
     if (!live) return;
-    const uint32_t base = P.rows[wj];
     if (before) excl += before[wj];
     uint32_t st = row_after<DIRECT>(P.pw, base, excl);
     for (int l = la; l < lb; l++) {
