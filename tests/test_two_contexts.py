@@ -71,6 +71,16 @@ def test_contexts_on_threads_equal_one_context(name, T, G, K):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("rep", range(3))
+def test_contexts_on_threads_with_per_link_rows(rep, monkeypatch):
+    """the same with the per-link rows of the 5^8 / 5^9 tables and of many workers with few reads (forced here: SQG_NO_PART, development
+    library): k_link_prefix's groups read the worker's row that its first group rewrites -- with a second context's kernels on the same
+    CUs a group that read it late saw the advanced row (5 failures in 8 runs before the read moved in front of the barrier)"""
+    monkeypatch.setenv("SQG_NO_PART", "1")
+    test_contexts_on_threads_equal_one_context("dna-r10-prom", 2, 2, 300)
+
+
+@pytest.mark.gpu
 def test_sharded_contexts_match_the_oracle():
     """the same against the oracle's single-process run (-t 4), two contexts, sequentially driven"""
     rng = np.random.default_rng(5)
