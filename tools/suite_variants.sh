@@ -1,6 +1,6 @@
 #!/bin/bash
 # the whole GPU suite under each fall-back / forced setting of the few-worker paths (tests that set the same variable themselves keep
-# their own value): tools/suite_variants.sh    (about 80 s per variant on one MI355X)
+# their own value): tools/suite_variants.sh    (about 220 s per variant on one MI355X: 30 GPU-minutes in all)
 cd "$(dirname "$0")/.."
 # (tests that check the DEFAULT choice of kernels, or a fault hook of the kernels a setting switches off, do not apply under that setting)
 skip_ord="--deselect tests/test_split_chains.py::test_lds_atomics_are_served_in_lane_order --deselect tests/test_split_chains.py::test_order_free_kernels_are_selectable_through_the_cfg --deselect tests/test_split_chains.py::test_every_batch_samples_the_lane_order_and_fails_loudly"
