@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SQG_ABI_VERSION 1
+#define SQG_ABI_VERSION 2
 
 /* option bits -- identical values to opt_t.flag, src/sq.h:32-42 */
 #define SQG_RNA         0x001u
@@ -136,6 +136,8 @@ typedef struct {
     float total_ms;             /* first launch to last completion                           */
     int64_t fallback_samples;   /* CERTIFIED mode: samples recomputed on the FP64 path; -1: not known any more (the batch was
                                  * waited for after two later batches had been run: the counters live with the output slabs) */
+    int32_t carried_first_pass; /* 1: this batch's launch sequence (events_ms) also held the first event pass of the batch behind it */
+    int32_t first_pass_ran_ahead; /* 1: this batch's own first event pass ran inside its predecessor's sequence (not in events_ms)  */
 } sqg_timing_t;
 
 int  sqg_create(const sqg_cfg_t *cfg, sqg_ctx_t **out);
@@ -161,7 +163,12 @@ int  sqg_batch_stage(sqg_ctx_t *ctx, int32_t n_reads, const char *seqs,
  * If the NEXT batch is already staged when this one is run (few workers, k > 6: the bucketed hand-out), its first event pass --
  * the dwell draws of src/gensig.c:254-257, which need nothing but the staged reads -- is launched inside this batch's sequence,
  * sharing the GPU with this batch's stream hand-out (one is bound by the VALU, the other by memory).  A host that wants it stages
- * batch i+1 before it runs batch i; nothing else changes: results, order, and what stays valid for how long. */
+ * batch i+1 before it runs batch i; results, order, and what stays valid for how long do not change.  Two things do, and a host may
+ * notice them: (1) sqg_batch_free of a batch that was staged, whose first pass ran ahead this way, and that is freed WITHOUT having been
+ * run waits for the context's stream (the pass may still be reading the batch's memory); (2) sqg_get_timing attributes that pass to
+ * the batch whose launch sequence carried it: events_ms of batch i holds batch i+1's first pass, and batch i+1's own events_ms does
+ * not (sqg_timing_t.carried_first_pass / .first_pass_ran_ahead say which batches that applies to).  The pass is best effort: if a
+ * buffer it needs cannot be had, the batch behind simply counts for itself. */
 int  sqg_batch_run(sqg_ctx_t *ctx, sqg_batch_t *b);
 /* Block until the batch has finished; fills *res. */
 int  sqg_batch_wait(sqg_ctx_t *ctx, sqg_batch_t *b, sqg_result_t *res);

@@ -30,7 +30,7 @@ struct sqg_ctx {
     orc_core_t* core = nullptr;
     orc_ref_t* ref = nullptr;           // resident genome (sqg_genome_load)
     unsigned long long next_stage = 0, next_run = 0;
-    sqg_timing_t timing = {0, 0, 0, 0, 0, 0};
+    sqg_timing_t timing = {0, 0, 0, 0, 0, 0, 0, 0};
     std::string err;
 };
 

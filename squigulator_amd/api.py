@@ -13,7 +13,7 @@ import numpy as np
 from . import build as _build
 from . import profiles as P
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MODE_EXACT = 0
 MODE_CERTIFIED = 1
 
@@ -53,7 +53,8 @@ class CResult(C.Structure):
 
 class CTiming(C.Structure):
     _fields_ = [("dwell_ms", C.c_float), ("events_ms", C.c_float), ("samples_ms", C.c_float),
-                ("lean_ms", C.c_float), ("total_ms", C.c_float), ("fallback_samples", C.c_int64)]
+                ("lean_ms", C.c_float), ("total_ms", C.c_float), ("fallback_samples", C.c_int64),
+                ("carried_first_pass", C.c_int32), ("first_pass_ran_ahead", C.c_int32)]
 
 
 class CSvb(C.Structure):
@@ -87,7 +88,8 @@ EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_d
 DEV_KNOBS = ("SQG_SEPARATE_DWELL", "SQG_EVENTS_WIDE_MAX", "SQG_MID_SPLIT", "SQG_SCAN_G4", "SQG_TEST_ORDER_FAULT", "SQG_LEAN_GRID",
              "SQG_LEAN_DYNLDS", "SQG_FIX_INLINE", "SQG_ABL_NOFIX", "SQG_SAMPLER_SERIAL", "SQG_OVERLAP", "SQG_PART_CLAIMS",
              "SQG_TEST_DELTA_X", "SQG_LEAN_EPL", "SQG_TEST_ROW_TURNS", "SQG_PART_WG_EVENTS", "SQG_SPLIT_CHAINS", "SQG_NO_PART",
-             "SQG_PART_SLICE", "SQG_TEST_NO_LEAN", "SQG_STAGE_THREADS", "SQG_NO_PRECOUNT", "SQG_PHC_ABL", "SQG_PHC_GRID", "SQG_NO_DRAW_AHEAD")
+             "SQG_PART_SLICE", "SQG_TEST_NO_LEAN", "SQG_STAGE_THREADS", "SQG_NO_PRECOUNT", "SQG_PHC_ABL", "SQG_PHC_GRID", "SQG_NO_DRAW_AHEAD",
+             "SQG_CU_SPLIT")
 
 _libs = {}                  # absolute path -> loaded library
 LOADED_PATH = None          # the library the last load_library() call opened (bench.py prints it with its hash)
@@ -539,7 +541,8 @@ class SignalGenerator:
         t = CTiming()
         self._chk(self.L.sqg_get_timing(self.ctx, C.byref(t)), "sqg_get_timing")
         return {"dwell_ms": t.dwell_ms, "events_ms": t.events_ms, "samples_ms": t.samples_ms,
-                "lean_ms": t.lean_ms, "total_ms": t.total_ms, "fallback_samples": t.fallback_samples}
+                "lean_ms": t.lean_ms, "total_ms": t.total_ms, "fallback_samples": t.fallback_samples,
+                "carried_first_pass": bool(t.carried_first_pass), "first_pass_ran_ahead": bool(t.first_pass_ran_ahead)}
 
     def probe_store_bandwidth(self, nbytes=1 << 30, iters=10) -> float:
         ms = C.c_float()

@@ -136,14 +136,16 @@ struct sqg_ctx {
         unsigned long long gen = 0;   // bumped whenever a batch starts writing the set
     } cset[3];
     int num_cu = 256;                              // compute units of the device
-    unsigned int* d_phc_q = nullptr;               // k_part_hand_count: {next slice, next link, wavefronts that have left} (the last one zeroes them)
+    unsigned int* d_zero = nullptr;                // one word that is always zero ("no slices": k_part_hand_count as a counting-only launch, development builds)
     std::deque<sqg_batch*> staged_q;               // staged, not yet run, in staging order (the batch behind the one being run: precount)
     hipStream_t stream2 = nullptr;                 // the sample kernels (k_samples_lean, generic); == stream unless SQG_OVERLAP=1
     hipStream_t fix_stream = nullptr;              // the FP64 fix-ups of batch i (two small kernels) run next to k_events of batch i+1
     unsigned long long* d_scan_part = nullptr; size_t scan_part_cap = 0;   // k_scan: {ticket, total} per workgroup
     uint32_t* d_link_rows = nullptr; size_t link_rows_cap = 0;   // split chains: one row per link of the running batch
     // k > 6, split chains (k_part.h), buffers of the running batch
-    uint32_t* d_pcnt = nullptr; size_t pcnt_cap = 0;             // [n_links][n_part]
+    uint32_t* d_pcnt[2] = {nullptr, nullptr}; size_t pcnt_cap[2] = {0, 0};   // [n_part][n_links] counts, then offsets; one per run-index parity: the first
+                                                                 // pass of batch i+1 (precount) fills its own while batch i's is still in use, and
+                                                                 // either can be made larger before a batch's first launch without losing the other
     uint32_t* d_slice = nullptr; size_t slice_cap = 0;           // {slice_lo, slice_hi}[max_slices], pfirst[n_pairs + 1], pstart, ptotal [n_pairs] (k_part.h)
     uint32_t* d_phist = nullptr; size_t phist_cap = 0;           // [max_slices][PART_SUB]
     double row_bound = 0;                          // k > 6: upper bound of any sample count held in d_rows
@@ -164,7 +166,7 @@ struct sqg_ctx {
     int stage_threads_last = 0;                    // ... and how many the last staging call used
     int phase_timing_every = 1;                    // sqg_set_phase_timing: the batches whose run index is a multiple carry the phase events (0: none)
     std::set<unsigned long long> abandoned;        // staged batches that were freed without having been run
-    sqg_timing_t timing = {0, 0, 0, 0, 0, 0};
+    sqg_timing_t timing = {0, 0, 0, 0, 0, 0, 0, 0};
     bool use_dwell_stream = true, use_kmer_streams = true;
     float delta_x = 0.f;                   // certified mode: swept |x_fast - x_exact| bound incl. margin
     float delta_x_measured = 0.f;
@@ -255,6 +257,8 @@ struct sqg_batch {
     int cset = 0;                        // ... and which of the three sets of first-pass outputs (run index % 3)
     unsigned long long cset_gen = 0;     // generation of that set when this batch took it
     bool precounted = false;             // its first event pass was run inside the launch sequence of the batch before it (into cset)
+    int pre_slot = -1;                   // ... which, with one partition, wrote part[] of this slot
+    bool carried_precount = false;       // this batch's launch sequence carried its successor's first event pass (k_part_hand_count)
     unsigned long long run_idx = 0;      // how many batches had been run before this one
     bool ran = false, waited = false, lean_timed = false, dwell_timed = false, fixup_launched = false;
     bool staged = false;                 // staging completed: the batch holds a place in the run order

@@ -37,8 +37,8 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->fix_stream) (void)hipStreamSynchronize(ctx->fix_stream);
     delete ctx->draw_ahead; ctx->draw_ahead = nullptr;
-    (void)hipFree(ctx->d_pcnt); (void)hipFree(ctx->d_slice); (void)hipFree(ctx->d_phist);
-    (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_scan_part); (void)hipFree(ctx->d_xcounts); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_samp_scratch); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err); (void)hipFree(ctx->d_mid_done); (void)hipFree(ctx->d_phc_q); if (ctx->h_samp) (void)hipHostFree(ctx->h_samp);
+    (void)hipFree(ctx->d_pcnt[0]); (void)hipFree(ctx->d_pcnt[1]); (void)hipFree(ctx->d_slice); (void)hipFree(ctx->d_phist);
+    (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_scan_part); (void)hipFree(ctx->d_xcounts); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_samp_scratch); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err); (void)hipFree(ctx->d_mid_done); (void)hipFree(ctx->d_zero); if (ctx->h_samp) (void)hipHostFree(ctx->h_samp);
     for (auto& Q : ctx->cset) { (void)hipFree(Q.d_dwell); (void)hipFree(Q.d_tile_so); (void)hipFree(Q.d_seglen); }
     for (auto& S : ctx->slot) {
         (void)hipFree(S.d_sig); (void)hipFree(S.d_sigoff);
@@ -59,6 +59,28 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     if (ctx->fix_stream) (void)hipStreamDestroy(ctx->fix_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+// ---- (development build) CU-masked streams -------------------------------------------------------------------------------
+// What a bit of a stream's CU mask stands for (measured: tools/cumask_probe.hip, profiles/r05_cumask.md): bit i is CU slot i / 8 of XCC
+// i % 8 (MI355X, 8 XCCs of 32 CUs); an XCC whose bits are ALL clear runs on all of its CUs, so every XCC gets the same slots.
+static int cu_split_streams(sqg_ctx* c, int n_ev, const bool same) {
+    const int ncu = c->num_cu, words = (ncu + 31) / 32, nx = 8, per = ncu / nx;
+    if (ncu % nx || n_ev < (same ? 0 : 1) || n_ev >= per) return SQG_EINVAL;
+    std::vector<uint32_t> m_ev((size_t)words, 0u), m_smp((size_t)words, 0u);
+    for (int i = 0; i < ncu; i++) ((i / nx) < n_ev ? m_ev : m_smp)[(size_t)i >> 5] |= 1u << (i & 31);
+    const int n_e = n_ev * nx, n_s = ncu - n_e;
+    fprintf(stderr, "[sqg] CU split: %d CUs for the event side, %d for the sample kernels%s\n", n_e, n_s, same ? " (one stream on the latter)" : "");
+    hipStream_t old = c->stream;
+    hipStream_t s_ev = nullptr, s_smp = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s_smp, (uint32_t)words, m_smp.data()) != hipSuccess) return SQG_EDEVICE;
+    if (same) { c->stream = s_smp; c->stream2 = s_smp; c->num_cu = n_s; }
+    else {
+        if (hipExtStreamCreateWithCUMask(&s_ev, (uint32_t)words, m_ev.data()) != hipSuccess) return SQG_EDEVICE;
+        c->stream = s_ev; c->stream2 = s_smp; c->num_cu = n_e;       // (num_cu: what the persistent event-side grids are sized by)
+    }
+    if (old) { (void)hipStreamSynchronize(old); (void)hipStreamDestroy(old); }
+    return SQG_OK;
 }
 
 extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
@@ -130,14 +152,21 @@ extern "C" int sqg_create(const sqg_cfg_t* cfg, sqg_ctx_t** out) {
     CHK(hipMalloc(&c->d_mid_done, sizeof(unsigned int)));
     CHK(hipMemset(c->d_mid_done, 0, sizeof(unsigned int)));
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && ncu > 0) c->num_cu = ncu; }
-    CHK(hipMalloc(&c->d_phc_q, 4 * sizeof(unsigned int)));
-    CHK(hipMemset(c->d_phc_q, 0, 4 * sizeof(unsigned int)));
+    CHK(hipMalloc(&c->d_zero, sizeof(unsigned int)));
+    CHK(hipMemset(c->d_zero, 0, sizeof(unsigned int)));
     CHK(hipMemset(c->d_err, 0, sizeof(unsigned int)));
     CHK(hipStreamCreateWithFlags(&c->stage_stream, hipStreamNonBlocking));
     // SQG_OVERLAP=1: the sample kernels get their own stream, so that the event kernels of the next batch run next to
     // them.  Both are VALU-bound: measured +2 % with earlier kernels, -2..4 % with the current ones, and it stretches every
     // kernel's duration -- the default keeps one stream and clean per-kernel timings.  Batches are double-buffered either way.
-    if (SQG_DEV_ENV("SQG_OVERLAP")) CHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    if (const char* split = SQG_DEV_ENV("SQG_CU_SPLIT")) {
+        // (development build, experiment) CU partitioning: the event side on `n` CUs of every XCD, the sample kernels on the others, each
+        // through a stream with a CU mask of its own -- two queues that cannot take each other's CUs.  SQG_CU_SPLIT="n" or "n,same"
+        // (same: ONE stream on the 32 - n CUs per XCD: how a kernel scales with the CUs it gets).
+        int rc2 = cu_split_streams(c, atoi(split), strstr(split, "same") != nullptr);
+        if (rc2 != SQG_OK) return fail(rc2);
+    }
+    else if (SQG_DEV_ENV("SQG_OVERLAP")) CHK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     else c->stream2 = c->stream;
     {   // lowest priority: the fix-ups fill the gaps of the next batch's k_events, they must not take its slots
         int prio_lo = 0, prio_hi = 0;

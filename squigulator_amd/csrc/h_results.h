@@ -27,8 +27,9 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
         b->waited = true;
         if (e) {
             c->err = "device reported: " + std::string((e & 1) ? "dwell>65535 " : "") + ((e & 2) ? "read>=UINT32_MAX samples " : "") + ((e & 4) ? "internal length mismatch " : "") + ((e & 8) ? "FP64 fix-up list overflow " : "") + ((e & 32) ? "one k-mer stream asked for >= 2^32 samples by one batch " : "") +
-                     ((e & 64) ? "LDS atomics were not served in lane order (the batch's sample of the stream hand-out; create the context with SQG_ORDER_FREE)" : "");
-            b->wait_rc = (e & (12 | 64)) ? SQG_EDEVICE : SQG_EOVERFLOW;
+                     ((e & 64) ? "LDS atomics were not served in lane order (the batch's sample of the stream hand-out; create the context with SQG_ORDER_FREE) " : "") +
+                     ((e & 0x80000000u) ? "the batch's last kernel left no report" : "");
+            b->wait_rc = (e & (12 | 64 | 0x80000000u)) ? SQG_EDEVICE : SQG_EOVERFLOW;
             return b->wait_rc;
         }
         float d = 0, s = 0, t = 0, ee = 0;
@@ -55,6 +56,7 @@ extern "C" int sqg_batch_wait(sqg_ctx_t* c, sqg_batch_t* b, sqg_result_t* res) {
             if (lists) for (int i = 0; i < FIX_SHARDS; i++) nfix += cnt[4 + i];   // ... + the lean kernel's lists (a word per list, written by k_fixup)
         }
         c->timing.dwell_ms = d; c->timing.samples_ms = s; c->timing.total_ms = t; c->timing.fallback_samples = nfix;
+        c->timing.carried_first_pass = b->carried_precount ? 1 : 0; c->timing.first_pass_ran_ahead = b->precounted ? 1 : 0;
     } else if (b->wait_rc) {
         c->err = "this batch failed on the device (see the first sqg_batch_wait)";
         return b->wait_rc;

@@ -5,7 +5,7 @@
 // (sqg_batch_run_end), `before` / `after` being what the other ranges of the batch draw from each stream
 // what the first event pass of a batch (pev_link<DW, COUNT>) reads and writes: filled the same way for the batch being run and for the
 // batch behind it, whose pass may ride along with this batch's hand-out (precount below)
-static void count_params(sqg_ctx* c, const sqg_batch* b, sqg_ctx::CountSet& Q, const int n_part, SigParams& P) {
+static void count_params(sqg_ctx* c, const sqg_batch* b, sqg_ctx::CountSet& Q, const int n_part, uint32_t* d_pcnt, SigParams& P) {
     const sqg_profile_t& p = c->cfg.profile;
     P.reads = b->d_reads; P.chain_off = b->d_chain_off; P.chain_reads = b->d_chain_reads; P.chain_order = b->d_chain_order; P.bases = b->d_bases;
     P.dwell = c->use_dwell_stream ? Q.d_dwell : nullptr; P.dwell_out = Q.d_dwell; P.seglen_out = Q.d_seglen; P.seglen = Q.d_seglen; P.tile_so = Q.d_tile_so;
@@ -14,7 +14,7 @@ static void count_params(sqg_ctx* c, const sqg_batch* b, sqg_ctx::CountSet& Q, c
     P.dwell_unbounded = c->dwell_hi > 65535.0 ? 1 : 0;
     P.dwell_pack = c->dwell_hi < 1024.0 ? 1 : 0;
     P.pieces = b->d_pieces; P.piece_total = b->d_piece_total;
-    P.pcnt = c->d_pcnt; P.n_part = n_part; P.n_links = b->n_chains;
+    P.pcnt = d_pcnt; P.n_part = n_part; P.n_links = b->n_chains;
 }
 
 static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* before, const uint32_t* after) {
@@ -30,7 +30,11 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     if (phase != 2) {
         b->run_idx = c->runs;
         for (auto it = c->staged_q.begin(); it != c->staged_q.end(); ++it) if (*it == b) { c->staged_q.erase(it); break; }
-        if (b->precounted && b->cset != (int)(b->run_idx % 3)) b->precounted = false;     // (cannot happen: the batch behind the one that ran is this one)
+        b->fixup_launched = false;                                // (a batch that is run again after a failed run: the first attempt's report is not this one's)
+        // a first pass that ran ahead is only taken if it wrote what this run reads: the set of this run index, still in the generation the
+        // pass took it in, and -- one partition: the pass writes part[] itself -- the slot this batch runs in.  (The run order guarantees all
+        // three; a batch that fails them is simply counted again.)
+        if (b->precounted && (b->cset != (int)(b->run_idx % 3) || c->cset[b->cset].gen != b->cset_gen || (b->one && b->pre_slot != (int)(b->run_idx & 1)))) b->precounted = false;
         if (!b->precounted) { b->cset = (int)(b->run_idx % 3); b->cset_gen = ++c->cset[b->cset].gen; }   // from here on the set's buffers belong to this batch
     }
     b->slot = (int)(b->run_idx & 1);
@@ -49,6 +53,26 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
         if ((rc = grow_cset(c, Q, b))) return rc;
     }
     const bool other_fresh = b->other_fresh;
+    // precount (below): the batch staged behind this one, if its first event pass can ride along with this batch's hand-out.  What the
+    // pass writes is made large enough HERE, before this batch's first launch (a reallocation synchronises the streams and must not
+    // happen between the kernels that advance the rows and the hand-out); it is an optimisation: should a buffer not be had, the plain
+    // hand-out runs and the batch behind counts for itself.
+    sqg_batch* pre_nb = nullptr;
+    if (phase == 0 && n > 0 && b->n_chains > 0 && b->part && b->pieces && c->lds_ordered && c->use_dwell_stream && !SQG_DEV_ENV("SQG_SEPARATE_DWELL") &&
+        !c->range_mode && !c->staged_q.empty() && !SQG_DEV_ENV("SQG_NO_PRECOUNT")) {
+        sqg_batch* cand = c->staged_q.front();
+        if (cand->seq > b->seq && cand->staged && !cand->ran && !cand->begun && !cand->precounted && cand->part && cand->pieces && cand->one == b->one &&
+            cand->n > 0 && cand->n_chains > 0) {
+            const int n_part0 = (c->num_kmer + PART_SUB - 1) >> PART_SUB_BITS;
+            sqg_ctx::CountSet& NQ = c->cset[(b->run_idx + 1) % 3];
+            bool ok = grow_cset(c, NQ, cand) == SQG_OK;
+            const int nx = (int)((b->run_idx + 1) & 1);          // (the counts go to the buffer of the NEXT run index: this batch's own -- which a pass that ran ahead may have filled already -- stays)
+            if (ok && !cand->one) ok = ensure(c, (void**)&c->d_pcnt[nx], &c->pcnt_cap[nx], (size_t)2 * cand->n_chains * (size_t)n_part0, sizeof(uint32_t)) == SQG_OK;
+            if (ok && cand->one) ok = ensure(c, (void**)&other.d_part, &other.part_cap, (size_t)cand->n_events + PART_SLACK, sizeof(uint32_t)) == SQG_OK;
+            if (ok) pre_nb = cand;
+            else c->err.clear();
+        }
+    }
 
     // Dwell draws are made inside k_events (SQG_SEPARATE_DWELL=1 keeps the stand-alone k_dwell for A/B runs).
     const bool separate_dwell = SQG_DEV_ENV("SQG_SEPARATE_DWELL") != nullptr;
@@ -74,19 +98,20 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     const int kmer_pad = n_part * PART_SUB;
     const size_t n_pairs = (size_t)b->n_wchains * (size_t)n_part;   // (worker chain, partition)
     if (phase != 2 && b->part) {
-        if ((rc = ensure(c, (void**)&c->d_pcnt, &c->pcnt_cap, (size_t)2 * b->n_chains * (size_t)n_part, sizeof(uint32_t)))) return rc;   // counts, offsets
+        if ((rc = ensure(c, (void**)&c->d_pcnt[b->run_idx & 1], &c->pcnt_cap[b->run_idx & 1], (size_t)2 * b->n_chains * (size_t)n_part, sizeof(uint32_t)))) return rc;   // counts, offsets (no-op for a batch whose first pass ran ahead: the pass' launch sized it)
         if ((rc = ensure(c, (void**)&c->d_slice, &c->slice_cap, (size_t)2 * (size_t)b->max_slices + (size_t)3 * n_pairs + 1, sizeof(uint32_t)))) return rc;
         if ((rc = ensure(c, (void**)&c->d_phist, &c->phist_cap, (size_t)b->max_slices * (size_t)PART_SUB, sizeof(uint32_t)))) return rc;
     }
     const size_t n_rows = (size_t)c->nw * (size_t)c->num_kmer;
     if (phase == 1 && (rc = ensure(c, (void**)&c->d_xcounts, &c->xcounts_cap, n_rows, sizeof(uint32_t)))) return rc;
+    uint32_t* const d_pcnt = c->d_pcnt[b->run_idx & 1];
     SigParams P;
     memset(&P, 0, sizeof P);
     P.link_rows = (b->split && !b->part) ? c->d_link_rows : nullptr;
-    P.part = S.d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = c->d_pcnt; P.poff = b->one ? b->d_link_slot : c->d_pcnt ? c->d_pcnt + (size_t)b->n_chains * n_part : nullptr; P.n_part = n_part; P.n_links = b->n_chains;
+    P.part = S.d_part; P.part_state = b->part ? S.d_part_state : nullptr; P.pcnt = d_pcnt; P.poff = b->one ? b->d_link_slot : d_pcnt ? d_pcnt + (size_t)b->n_chains * n_part : nullptr; P.n_part = n_part; P.n_links = b->n_chains;
     P.link_q = b->d_link_q; P.pieces = b->d_pieces; P.piece_total = b->d_piece_total;
     P.one = b->one ? 1 : 0;
-    count_params(c, b, Q, n_part, P);
+    count_params(c, b, Q, n_part, d_pcnt, P);
     P.sig_off = S.d_sigoff; P.model = c->d_model; P.pw = c->d_pow; P.rows = c->d_rows;
     P.seed_base = canon((long long)c->cfg.seed + (long long)c->wlo * ((long long)c->num_kmer + 10)); P.seed_step = canon((long long)c->num_kmer + 10);
     P.dig = p.digitisation; P.range = p.range; P.kd = p.digitisation / p.range;
@@ -190,15 +215,15 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                     if ((rc = dbg_sync(c, "k_part_events<one>/k_part_slices"))) return rc;
                 } else {
                     if (mid_split) {
-                        hipLaunchKernelGGL(k_part_offsets, dim3((unsigned)n_part, (unsigned)b->n_wchains), dim3(1024), 0, c->stream, c->d_pcnt,
-                                           c->d_pcnt + (size_t)b->n_chains * n_part, n_part, b->n_chains, b->d_wlink_off, ptotal);
+                        hipLaunchKernelGGL(k_part_offsets, dim3((unsigned)n_part, (unsigned)b->n_wchains), dim3(1024), 0, c->stream, d_pcnt,
+                                           d_pcnt + (size_t)b->n_chains * n_part, n_part, b->n_chains, b->d_wlink_off, ptotal);
                         hipLaunchKernelGGL(k_part_slices, dim3(1), dim3(1024), 0, c->stream, pstart, ptotal, (int)n_pairs, b->slice_len, pfirst, nullptr, nullptr);
                         hipLaunchKernelGGL(k_part_slice_bounds, dim3((pgrid + 255) / 256), dim3(256), 0, c->stream, pstart, ptotal, (int)n_pairs, b->slice_len, pfirst, slice_lo, slice_hi);
                     } else {
                         // offsets per (partition, worker chain), the tile offsets of split reads, the slices and their bounds: one launch
                         const int n_off = (int)n_pairs, n_pc = b->split_reads ? b->n_pieces : 0;
-                        hipLaunchKernelGGL(k_part_mid, dim3((unsigned)(n_off + (n_pc + 15) / 16)), dim3(1024), 0, c->stream, P, c->d_pcnt,
-                                           c->d_pcnt + (size_t)b->n_chains * n_part, n_part, b->n_chains, b->d_wlink_off, ptotal, pstart, (int)n_pairs, b->slice_len,
+                        hipLaunchKernelGGL(k_part_mid, dim3((unsigned)(n_off + (n_pc + 15) / 16)), dim3(1024), 0, c->stream, P, d_pcnt,
+                                           d_pcnt + (size_t)b->n_chains * n_part, n_part, b->n_chains, b->d_wlink_off, ptotal, pstart, (int)n_pairs, b->slice_len,
                                            pfirst, slice_lo, slice_hi, n_off, n_pc, c->d_mid_done);
                     }
                     HIPCHK(c, hipGetLastError());
@@ -231,23 +256,13 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                 const int order_fault = SQG_DEV_ENV("SQG_TEST_ORDER_FAULT") ? 1 : 0;         // (tests: the per-batch order check has to fire)
                 // precount: the batch staged behind this one, if its first event pass can ride along with this batch's hand-out
                 // (k_part_hand_count, k_part_events.h): same kind of batch, nothing in between, the plain launch sequence
-                sqg_batch* nb = nullptr;
-                if (phase == 0 && c->lds_ordered && wave_links && dw != 0 && !c->range_mode && !c->staged_q.empty() && !SQG_DEV_ENV("SQG_NO_PRECOUNT")) {
-                    sqg_batch* cand = c->staged_q.front();
-                    if (cand->seq > b->seq && cand->staged && !cand->ran && !cand->begun && !cand->precounted && cand->part && cand->pieces && cand->one == b->one &&
-                        cand->n > 0 && cand->n_chains > 0) nb = cand;
-                }
+                sqg_batch* nb = (pre_nb && wave_links && dw != 0) ? pre_nb : nullptr;       // (chosen, and its buffers made, before this batch's first launch)
                 if (nb) {
                     const int ncs = (int)((b->run_idx + 1) % 3);
                     sqg_ctx::CountSet& NQ = c->cset[ncs];
-                    if ((rc = grow_cset(c, NQ, nb))) return rc;
-                    if (!nb->one && (rc = ensure(c, (void**)&c->d_pcnt, &c->pcnt_cap, (size_t)2 * nb->n_chains * (size_t)n_part, sizeof(uint32_t)))) return rc;
-                    if (nb->one) {
-                        // one partition (k <= 6): the pass writes part[] of the next batch's slot -- the other one, which the fix-ups of the batch
-                        // before this one (fix_stream) may still be reading
-                        if ((rc = ensure(c, (void**)&other.d_part, &other.part_cap, (size_t)nb->n_events + PART_SLACK, sizeof(uint32_t)))) return rc;
-                        HIPCHK(c, hipStreamWaitEvent(c->stream, other.done, 0));
-                    }
+                    // (one partition, k <= 6: the pass writes part[] of the next batch's slot -- the other one, which the fix-ups of the batch
+                    // before this one (fix_stream) may still be reading)
+                    if (nb->one) HIPCHK(c, hipStreamWaitEvent(c->stream, other.done, 0));
                     if (nb->ev_staged && hipEventQuery(nb->ev_staged) != hipSuccess) HIPCHK(c, hipStreamWaitEvent(c->stream, nb->ev_staged, 0));
                     if (nb->split_reads && NQ.seglen_dirty > 0) {
                         HIPCHK(c, hipMemsetAsync(NQ.d_seglen, 0, (size_t)2 * std::max<size_t>((size_t)nb->n, NQ.seglen_dirty) * sizeof(unsigned long long), c->stream));
@@ -256,14 +271,14 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                     if (nb->split_reads) NQ.seglen_dirty = (size_t)nb->n;
                     SigParams Pn;
                     memset(&Pn, 0, sizeof Pn);
-                    count_params(c, nb, NQ, n_part, Pn);
+                    count_params(c, nb, NQ, n_part, c->d_pcnt[(b->run_idx + 1) & 1], Pn);
                     if (nb->one) { Pn.one = 1; Pn.part = other.d_part; Pn.poff = nb->d_link_slot; }
                     const dim3 fg((unsigned)(dev_env_int(SQG_DEV_ENV("SQG_PHC_GRID"), 4) * c->num_cu)), ft(64 * (1 + PHC_COUNT_WAVES));   // (A/B: workgroups per CU)
                     // (development build, timing experiments: 1 -- the fused launch hands out only, the next batch's pass follows as a launch
                     // of its own; 2 -- the plain hand-out first, the fused launch counts only)
                     const int phc_abl = dev_env_int(SQG_DEV_ENV("SQG_PHC_ABL"), 0);
                     if (phc_abl == 2) hipLaunchKernelGGL(k_part_hand_ord, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, b->d_err, order_fault);
-                    const uint32_t* const ns_ptr = phc_abl == 2 ? c->d_phc_q + 3 : pfirst + n_pairs;      // (word 3 of the queue block is always zero)
+                    const uint32_t* const ns_ptr = phc_abl == 2 ? c->d_zero : pfirst + n_pairs;
                     const int nl_fused = phc_abl == 1 ? 0 : nb->n_chains;
 #define PHCL(D_, M_) hipLaunchKernelGGL((k_part_hand_count<D_, M_>), fg, ft, 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, ns_ptr, c->d_phist, c->d_pow, \
                                     b->d_err, order_fault, Pn, nl_fused, (uint32_t)nb->n_events, c->num_cu)
@@ -277,7 +292,8 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                         else if (dw == 1) hipLaunchKernelGGL((k_part_events<1, PEV_COUNT>), g1, t1, 0, c->stream, Pn, nb->n_chains, (uint32_t)nb->n_events);
                         else hipLaunchKernelGGL((k_part_events<2, PEV_COUNT>), g1, t1, 0, c->stream, Pn, nb->n_chains, (uint32_t)nb->n_events);
                     }
-                    nb->precounted = true; nb->cset = ncs; nb->cset_gen = ++NQ.gen;
+                    nb->precounted = true; nb->cset = ncs; nb->cset_gen = ++NQ.gen; nb->pre_slot = b->slot ^ 1;
+                    b->carried_precount = true;                       // (sqg_get_timing: this batch's event side holds the successor's first pass)
                 }
                 else if (c->lds_ordered) hipLaunchKernelGGL(k_part_hand_ord, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, b->d_err, order_fault);
                 else if (c->dwell_hi >= (double)PART_JT) hipLaunchKernelGGL(k_part_hand<true>, dim3(pgrid), dim3(64), 0, c->stream, S.d_part, S.d_part_state, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist, c->d_pow, (uint32_t)b->n_events);

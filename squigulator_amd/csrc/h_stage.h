@@ -552,6 +552,12 @@ static int stage_common(sqg_ctx_t* c, int32_t n, const char* seqs, const int64_t
         for (auto& e : b->ev) CHKB(hipEventCreate(&e));
         CHKB(hipEventCreateWithFlags(&b->ev_staged, hipEventDisableTiming));
     }
+    {   // k_fixup's report (error word, fix-up counts: the last SQG_HRES_LL words of the mapped block) starts out as "nothing reported":
+        // a recycled block holds an earlier batch's words, and sqg_batch_wait reads them whenever this batch's k_fixup was launched
+        unsigned int* const hres = reinterpret_cast<unsigned int*>(b->h_sigoff + (b->h_n - SQG_HRES_LL));
+        hres[0] = 0x80000000u;                              // (bit 31: "k_fixup has not written its report": an error, should a wait ever see it)
+        for (int i = 1; i < 4 + FIX_SHARDS; i++) hres[i] = 0u;
+    }
     CHKB(hipEventRecord(b->ev_staged, c->stage_stream));   // sqg_batch_run waits for it on its own stream
     st_mark("mallocs+enqueue");
     // the read bytes of sqg_batch_stage come from the caller's (pageable) buffer through a stack-owned copy: wait for that

@@ -80,22 +80,35 @@ def _few_case(seed):
     return prof, flags, k, T, int(rng.integers(1, 1 << 30)), batches, links
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(36))
-def test_random_few_worker_configuration_matches_oracle(seed, monkeypatch):
+# The fall-back paths of the few-worker regime -- what a device that fails the LDS-order check, a 5^8 / 5^9 table, a batch that is not
+# staged ahead ... run -- take the same randomised cases as the default path (fewer of them): "order-free" through cfg.flags (the
+# release library's own switch, include/sqg.h SQG_ORDER_FREE), the others through the development library's knobs.
+VARIANTS = {
+    "default": {},
+    "order-free": {"cfg": profiles.SQ_ORDER_FREE},                 # k_part_hand (claims), k_events<..., PART>; k <= 6: per-link rows
+    "per-link-rows": {"env": {"SQG_NO_PART": "1"}},                # k_events<HIST> + k_link_prefix (round 1's path)
+    "no-precount": {"env": {"SQG_NO_PRECOUNT": "1"}},              # the first event pass always as a launch of its own
+    "wg-per-link": {"env": {"SQG_PART_WG_EVENTS": "1"}},           # k_events<..., PART> with the ordered hand-out
+}
+
+
+def _few_worker_case(seed, monkeypatch, variant="default"):
     prof, flags, k, T, s, batches, links = _few_case(seed)
     monkeypatch.setenv("SQG_SPLIT_CHAINS", links)
-    if seed % 9 == 8:
+    if variant == "default" and seed % 9 == 8:
         monkeypatch.setenv("SQG_PART_CLAIMS", "1")       # the order-free kernels
+    for name, val in VARIANTS[variant].get("env", {}).items():
+        monkeypatch.setenv(name, val)
+    flags |= VARIANTS[variant].get("cfg", 0)
     mean, stdv = model.synthetic_model(k, salt=seed)
-    orac = orc.Oracle(prof, flags, k, mean, stdv, s, num_workers=T)
+    orac = orc.Oracle(prof, flags & ~profiles.SQ_ORDER_FREE, k, mean, stdv, s, num_workers=T)
     want = [orac.run_batch_seqs(bt) for bt in batches]
     orac.close()
     def check(b, bi, mode, how):
         sig, dw = b.signal(), b.dwell()
         for i, w in enumerate(want[bi]):
             np.testing.assert_array_equal(sig[b.sig_off[i]:b.sig_off[i + 1]], w.sig,
-                                          err_msg=f"seed {seed} mode {mode} {how} batch {bi} read {i} (k={k} T={T} flags={flags:#x} links={links} dwell={prof.dwell_mean}/{prof.dwell_std})")
+                                          err_msg=f"seed {seed} {variant} mode {mode} {how} batch {bi} read {i} (k={k} T={T} flags={flags:#x} links={links} dwell={prof.dwell_mean}/{prof.dwell_std})")
             np.testing.assert_array_equal(dw[b.ev_off[i]:b.ev_off[i + 1]], w.ss)
             assert b.offset[i] == w.offset and b.median_before[i] == w.median_before
     for mode in (api.MODE_CERTIFIED, api.MODE_EXACT):
@@ -119,3 +132,17 @@ def test_random_few_worker_configuration_matches_oracle(seed, monkeypatch):
             cur.free()
             cur, nxt = nxt, nn
         gen.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(36))
+def test_random_few_worker_configuration_matches_oracle(seed, monkeypatch):
+    _few_worker_case(seed, monkeypatch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(36, 48))
+@pytest.mark.parametrize("variant", [v for v in VARIANTS if v != "default"])
+def test_few_worker_fallback_paths_match_oracle(variant, seed, monkeypatch):
+    """(seeds of their own: twelve more random cases per fall-back, every k of the bucketed hand-out and of its one-partition case)"""
+    _few_worker_case(seed, monkeypatch, variant)

@@ -18,9 +18,10 @@ def _reads(rng, n, lo=300, hi=2500):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,T,G,K", [("dna-r9-prom", 4, 2, 400), ("dna-r10-prom", 2, 2, 300), ("dna-r10-prom", 6, 3, 96), ("rna004-prom", 2, 2, 200)])
-def test_contexts_on_threads_equal_one_context(name, T, G, K):
+def test_contexts_on_threads_equal_one_context(name, T, G, K, extra_flags=0):
     rng = np.random.default_rng(31)
     prof, fl = profiles.get_profile(name)
+    fl |= extra_flags
     k = profiles.default_kmer_size(fl)
     mean, stdv = model.synthetic_model(k)
     batches = [_reads(rng, K) for _ in range(3)]
@@ -78,6 +79,18 @@ def test_contexts_on_threads_with_per_link_rows(rep, monkeypatch):
     CUs a group that read it late saw the advanced row (5 failures in 8 runs before the read moved in front of the barrier)"""
     monkeypatch.setenv("SQG_NO_PART", "1")
     test_contexts_on_threads_equal_one_context("dna-r10-prom", 2, 2, 300)
+
+
+# the fall-back paths under the same load -- two contexts' kernels sharing the CUs is what found the per-link rows' race -- (see
+# tests/test_fuzz_parity.py VARIANTS)
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,T,G,K", [("dna-r10-prom", 2, 2, 300), ("dna-r9-prom", 4, 2, 400)])
+@pytest.mark.parametrize("variant", ["order-free", "per-link-rows", "no-precount", "wg-per-link"])
+def test_contexts_on_threads_on_the_fallback_paths(variant, name, T, G, K, monkeypatch):
+    env = {"per-link-rows": {"SQG_NO_PART": "1"}, "no-precount": {"SQG_NO_PRECOUNT": "1"}, "wg-per-link": {"SQG_PART_WG_EVENTS": "1"}}.get(variant, {})
+    for kname, val in env.items():
+        monkeypatch.setenv(kname, val)
+    test_contexts_on_threads_equal_one_context(name, T, G, K, extra_flags=profiles.SQ_ORDER_FREE if variant == "order-free" else 0)
 
 
 @pytest.mark.gpu

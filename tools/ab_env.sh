@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of (library, environment) pairs in one call: tools/ab_env.sh "<lib> VAR=val ..." "<lib> ..." ; three rounds
-for rep in 1 2 3; do
+for rep in $(seq 1 ${REPS:-3}); do
 for spec in "$@"; do
   words=($spec); lib=${words[0]}; envs=("${words[@]:1}")
   r=$(env "${envs[@]}" timeout 300 python bench.py --lib $PWD/$lib --no-cpu-baseline --no-store-probe $BENCH_ARGS 2>/dev/null | python tools/ab_line.py)
