@@ -219,6 +219,43 @@ def pmc_traffic(workload_key):
         return None
 
 
+def pmc_resources(workload_key, kernel_ms, samples_per_launch, store_peak_GBps):
+    """What the dominant kernel occupies besides HBM bytes, from the hash-matched PMC passes (tools/prof_pmc.sh ->
+    profiles/traffic_latest.json: SQ_ACTIVE_INST_VALU, SQ_INSTS_VALU, GRBM_GUI_ACTIVE, TCP_TCC_READ/WRITE_REQ, FETCH/WRITE_SIZE per launch)
+    priced with THIS run's kernel time: `valu_busy` = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs (quad-cycles
+    -> cycles); `l2_req_frac` = the kernel's TCP -> L2 requests per cycle over what `cal_rgather8` (tools/pmc_calib.hip: random 8-B
+    look-ups in an L2-resident table) sustains; `store_frac` = written bytes per second over the box's int16 streaming-store rate;
+    `hbm_frac` = all HBM bytes per second over 8 TB/s.  `bound` names the largest.  None without a matching profile."""
+    doc = _traffic_doc(workload_key)
+    try:
+        if doc is None or not kernel_ms:
+            return None
+        kk = doc["kernels"]["k_samples_lean"]
+        if "SQ_ACTIVE_INST_VALU" not in kk:
+            return None
+        cyc = kk["GRBM_GUI_ACTIVE"] / 8.0
+        out = {"source": "profiles/traffic_latest.json (PMC passes of the same sources and workload), priced with this run's kernel_ms",
+               "valu_busy": kk["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc,
+               "valu_inst_per_sample": kk["SQ_INSTS_VALU"] * 64.0 / samples_per_launch if samples_per_launch else None,
+               "kernel_cycles_pmc": cyc, "kernel_clock_GHz_pmc": cyc / (kk.get("kernel_us", 0) * 1e3) if kk.get("kernel_us") else None}
+        req = kk.get("TCP_TCC_READ_REQ_sum", 0.0) + kk.get("TCP_TCC_WRITE_REQ_sum", 0.0)
+        cal = (doc.get("calib") or {}).get("rgather8_l2_req_per_cycle")
+        out["l2_req_per_sample"] = req / samples_per_launch if samples_per_launch else None
+        out["l2_req_per_cycle"] = req / cyc
+        out["l2_req_frac"] = (req / cyc / cal) if cal else None
+        out["l2_req_calibrated_peak_per_cycle"] = cal
+        wbytes = kk["WRITE_SIZE_KiB"] * 1024.0
+        out["store_GBps"] = wbytes / (kernel_ms * 1e-3) / 1e9
+        out["store_frac"] = (out["store_GBps"] / store_peak_GBps) if store_peak_GBps else None
+        out["hbm_frac"] = kk["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / HBM_PEAK_BYTES_PER_S
+        cands = {"valu": out["valu_busy"], "l2_requests": out["l2_req_frac"], "stores": out["store_frac"], "hbm": out["hbm_frac"]}
+        cands = {k: v for k, v in cands.items() if v is not None}
+        out["bound"] = max(cands, key=cands.get)
+        return out
+    except (KeyError, ValueError, ZeroDivisionError, TypeError):
+        return None
+
+
 def host_info():
     """(CPU model, physical cores, hardware threads)"""
     name, phys = "unknown", set()
@@ -545,6 +582,14 @@ def main():
                     help="wall time (at least two batches) of each end-to-end leg -- raw int16 into pinned host memory, svb-zd into pinned "
                          "host memory, BLOW5 into /dev/shm (`e2e` in the line; N = 1 only); 0 skips them")
     ap.add_argument("--e2e-batch-reads", type=int, default=2048, help="reads per batch of the end-to-end legs")
+    ap.add_argument("--small-batch-seconds", type=float, default=1.0,
+                    help="wall time of each small-batch streaming leg (`small_batch` in the line; N = 1, worker-sharded runs of the genome "
+                         "workloads only): the reference's default batch size, `-t 1 -K 1000` and `-t 8 -K 1000` (src/sim.c:208-209), "
+                         "nothing staged ahead; 0 skips them")
+    ap.add_argument("--every-batch-launches", type=int, default=24,
+                    help="batches of an extra leg behind the timed region in which EVERY batch carries the phase events: kernel_ms over >= 20 "
+                         "launches (`kernel_ms_every_batch`; the events cost ~1 %% of a step, so the timed region carries them on every "
+                         "--timing-every'th batch only); 0 skips it")
     ap.add_argument("--workers-per-gpu", type=int, default=None,
                     help="W > 0: the job has T = N*W virtual workers, W per GPU (sharded by worker, no data-path collective), and every "
                          "batch of N*K reads is split over them as the reference's static partition does (src/thread.c:80-99): "
@@ -679,9 +724,11 @@ def main():
         torch.cuda.synchronize()
         gen.load_genome_device(seq.data_ptr(), lens, args.rlen, sm)
         genome_bases = int(sum(lens))
+        genome_dev = (seq, lens) if (args.small_batch_seconds > 0 and world == 1 and not args.digest) else None   # (the -t 8 leg's context loads it again)
         del seq
         torch.cuda.empty_cache()
     else:
+        genome_dev = None
         host_contigs = load_contigs(SEQUINS) if args.workload == "sequin-rna004" else load_contigs(GENOME)
         gen.load_genome(host_contigs, args.rlen, sm)
         genome_bases = sum(len(c) for c in host_contigs)
@@ -799,12 +846,78 @@ def main():
         dt_max = dt
     tot_samples, tot_reads = float(tot[0]), float(tot[1])
 
-    # the streaming leg: the same job with nothing staged ahead (the sampler's and the staging kernels share the GPU with the generator)
-    pipe = None
-    if args.pipeline_seconds > 0 and not args.digest:
+    def free_all():
+        nonlocal batches, timed, tail
         for b in batches[:args.warmup] + [b for b in timed if b is not None] + tail:
             b.free()
         batches, timed, tail = [], [], []
+
+    # every batch with the phase events: kernel_ms over >= 20 launches (the timed region above carries them on every n-th batch only)
+    every = None
+    if args.every_batch_launches > 0 and not args.digest and not range_mode:
+        free_all()
+        gen.set_phase_timing(1)
+        nb_e = args.every_batch_launches
+        sync_all()
+        eb = [stage_one() for _ in range(nb_e + 1)]                 # (+ the successor of the last one: every run carries a first pass)
+        l_ms, e_ms = [], []
+        te0 = time.perf_counter()
+        for b in eb[:nb_e]:
+            run(b)
+        for b in eb[:nb_e]:
+            b.wait()
+            tm = gen.timing()
+            if tm["total_ms"] > 0:
+                l_ms.append(tm["lean_ms"] if tm["lean_ms"] > 0 else tm["samples_ms"]); e_ms.append(tm["events_ms"])
+        sync_all()
+        te = time.perf_counter() - te0
+        for b in eb:
+            b.free()
+        gen.set_phase_timing(timing_every)
+        if l_ms:
+            every = {"launches": len(l_ms), "k_samples_lean": float(np.mean(l_ms)), "k_samples_lean_min": float(np.min(l_ms)),
+                     "k_samples_lean_max": float(np.max(l_ms)), "event side (k_events, k_part_*)": float(np.mean(e_ms)),
+                     "ms_per_step": te / nb_e * 1e3,
+                     "what": "a leg of its own behind the timed region: every batch carries the phase events (barrier packets: ~1 % of a step)"}
+
+    # the reference's default batch size, streaming (src/sim.c:208-209: -t 8 -K 1000): nothing staged ahead
+    small = None
+    if args.small_batch_seconds > 0 and world == 1 and not range_mode and not args.digest and W == 1:
+        free_all()
+        small = {"reads_per_batch": 1000, "what": "streaming (one host thread: sample + stage batch i+2, queue batch i+1, wait for and free batch i), "
+                 "the reference's default -K 1000 (src/sim.c:208-209); -t 8: the static partition of a batch over eight virtual workers"}
+        for t_small in (1, 8):
+            g2 = gen
+            if t_small != T:
+                if genome_dev is None:
+                    continue
+                g2 = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=t_small, device=local_rank, mode=amode)
+                g2.load_genome_device(genome_dev[0].data_ptr(), genome_dev[1], args.rlen, sm)
+            g2.set_phase_timing(0)
+            g2.set_stage_threads(0)                                # (automatic: a 1000-read batch's draws are not worth waking helpers for)
+            wk = (np.arange(1000, dtype=np.int32) // (1000 // t_small)).clip(0, t_small - 1).astype(np.int32)
+            st1 = lambda g2=g2, wk=wk: g2.sample(1000, wk)
+            warm = st1().run(); warm.wait(); ns0 = warm.n_samples; warm.free()
+            sync_all()
+            # (size the leg from a short trial: ~0.35 ms per batch)
+            trial = pipeline_leg(st1, lambda b: b.run(), 64)
+            n_small = int(min(max(args.small_batch_seconds / max(trial[2] / 65, 1e-6), 64), 40000))
+            sync_all()
+            r = pipeline_leg(st1, lambda b: b.run(), n_small)
+            sync_all()
+            small[f"-t {t_small} -K 1000"] = {"value": r[0] / r[2], "unit": "samples/s", "reads_per_s": r[1] / r[2], "seconds": r[2], "batches": n_small + 1,
+                                             "ms_per_batch": r[2] / (n_small + 1) * 1e3, "host_stage_ms_per_batch": r[3] * 1e3}
+            if g2 is not gen:
+                g2.close()
+        gen.set_phase_timing(timing_every)
+        gen.set_stage_threads(stage_threads)
+    genome_dev = None
+    torch.cuda.empty_cache()
+
+    # the streaming leg: the same job with nothing staged ahead (the sampler's and the staging kernels share the GPU with the generator)
+    pipe = None
+    if args.pipeline_seconds > 0 and not args.digest:
+        free_all()
         n_pipe = int(min(max(args.pipeline_seconds / max(dt_max / max(args.steps, 1), 1e-5), 8), 20000))
         sync_all()
         pipe = pipeline_leg(stage_one, run, n_pipe)
@@ -812,9 +925,7 @@ def main():
 
     e2e = None
     if args.e2e_seconds > 0 and world == 1 and not range_mode and not args.digest:
-        for b in batches[:args.warmup] + [b for b in timed if b is not None] + tail:
-            b.free()
-        batches, timed, tail = [], [], []
+        free_all()
         Ke = min(args.e2e_batch_reads, K)
         we = workers[:Ke] if not W else np.minimum(w_lo + np.arange(Ke, dtype=np.int32) // max(Ke // W, 1), w_hi - 1).astype(np.int32)
         sync_all()
@@ -889,6 +1000,8 @@ def main():
                 "what": "nothing staged ahead but one batch: one host thread per GPU samples (device-side gen_read) + stages batch i+2, queues batch i+1, "
                         "waits for batch i and frees it; two batches in flight, one staged, results left in HBM"},
             "e2e": e2e,
+            "small_batch": small,
+            "kernel_ms_every_batch": every,
             "reads_per_s": tot_reads / dt_max,
             # samples the fp32 path left to FP64, over the batches whose counters were still theirs when they were waited for
             "fp64_fixup_frac": (fallback / fallback_of if fallback_of else None) if args.mode == "certified" else None,
@@ -917,6 +1030,9 @@ def main():
             out["roofline"]["step_traffic_frac"] = st / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S
         if not args.no_store_probe:
             out["roofline"]["measured_store_peak_GBps"] = gen.probe_store_bandwidth(1 << 30, 10) / 1e9
+        # what the kernel occupies besides HBM bytes (the profile's counters priced with this run's time); `bound` in `resources` names
+        # the largest share -- roofline.bound stays "hbm": that is the roofline this line's frac is quoted against
+        out["roofline"]["resources"] = pmc_resources(wkey, k_ms, samples / steps, out["roofline"].get("measured_store_peak_GBps"))
         if digests:
             out["digest"] = digests
         if args.no_cpu_baseline or world > 1:

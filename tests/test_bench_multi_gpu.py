@@ -162,6 +162,36 @@ def test_bench_line_carries_the_contract():
     assert e["blow5"]["value"] < e["pinned_svb"]["value"] < d["value"]
     if c["kind"] == "reference":
         assert c["to_blow5"] > 0
+    # round 5: kernel_ms over >= 20 launches (a leg in which every batch carries the phase events), the reference's default batch size
+    # streaming with one and with eight virtual workers (src/sim.c:208-209), and what the kernel occupies besides HBM bytes (null unless
+    # profiles/traffic_latest.json was measured on this workload and these sources: this small run has no such profile)
+    ev = d["kernel_ms_every_batch"]
+    assert ev["launches"] >= 20 and ev["k_samples_lean"] > 0 and ev["k_samples_lean_min"] <= ev["k_samples_lean"] <= ev["k_samples_lean_max"]
+    sb = d["small_batch"]
+    for leg in ("-t 1 -K 1000", "-t 8 -K 1000"):
+        assert sb[leg]["unit"] == "samples/s" and sb[leg]["value"] > 0 and sb[leg]["seconds"] >= 0.9 and sb[leg]["batches"] >= 65, (leg, sb[leg])
+    assert "resources" in r and (r["resources"] is None or r["resources"]["bound"] in ("valu", "l2_requests", "stores", "hbm"))
+
+
+def test_resources_are_priced_from_the_profile_of_the_same_sources(tmp_path, monkeypatch):
+    """roofline.resources: the PMC counters of profiles/traffic_latest.json (hash-matched) priced with the run's own kernel time"""
+    sys.path.insert(0, ROOT)
+    import bench
+    from squigulator_amd import build
+    kk = {"hbm_bytes_per_launch": 6.9e9, "WRITE_SIZE_KiB": 4.2e6, "FETCH_SIZE_KiB": 1.2e6, "SQ_ACTIVE_INST_VALU": 1.2e9, "SQ_INSTS_VALU": 9.6e8,
+          "GRBM_GUI_ACTIVE": 4.0e7, "TCP_TCC_READ_REQ_sum": 1.9e8, "TCP_TCC_WRITE_REQ_sum": 1.0e8, "kernel_us": 2400.0}
+    doc = {"workload_key": "w", "source_hash": build.source_hash(), "kernels": {"k_samples_lean": kk}, "calib": {"rgather8_l2_req_per_cycle": 100.0}}
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "traffic_latest.json").write_text(json.dumps(doc))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    res = bench.pmc_resources("w", 2.4, 2.13e9, 5000.0)
+    assert res["valu_busy"] == pytest.approx(1.2e9 * 4 / 1024 / 5.0e6) and res["valu_inst_per_sample"] == pytest.approx(9.6e8 * 64 / 2.13e9)
+    assert res["l2_req_frac"] == pytest.approx(2.9e8 / 5.0e6 / 100.0) and res["store_frac"] == pytest.approx(4.2e6 * 1024 / 2.4e-3 / 1e9 / 5000.0)
+    assert res["hbm_frac"] == pytest.approx(6.9e9 / 2.4e-3 / 8e12) and res["bound"] == "valu"
+    assert bench.pmc_resources("other workload", 2.4, 2.13e9, 5000.0) is None
+    doc["source_hash"] = "0" * 16
+    (tmp_path / "profiles" / "traffic_latest.json").write_text(json.dumps(doc))
+    assert bench.pmc_resources("w", 2.4, 2.13e9, 5000.0) is None
 
 
 @pytest.mark.gpu

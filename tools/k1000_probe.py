@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a 1000-read batch's host time goes in the streaming pattern (stage i+2, run i+1, wait i, free i): per-call wall times.
-usage: python tools/k1000_probe.py [reads_per_batch] [batches] [genome_mb]"""
+usage: python tools/k1000_probe.py [reads_per_batch] [batches] [genome_mb] [workers]"""
 import os
 import sys
 import time
@@ -17,14 +17,15 @@ from squigulator_amd import api, model, profiles  # noqa: E402
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 NB = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 MB = float(sys.argv[3]) if len(sys.argv) > 3 else 256.0
+T = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 prof, fl = profiles.get_profile("dna-r10-prom")
 mean, stdv = model.synthetic_model(9)
 dev = torch.device("cuda", 0)
 seq, lens = bench.synthetic_genome_device(MB, dev)
-gen = api.SignalGenerator(prof, fl, 9, mean, stdv, 42, num_workers=1, mode=api.MODE_CERTIFIED)
+gen = api.SignalGenerator(prof, fl, 9, mean, stdv, 42, num_workers=T, mode=api.MODE_CERTIFIED)
 gen.load_genome_device(seq.data_ptr(), lens, 10000, api.SAMPLE_DNA)
 gen.set_phase_timing(0)
-workers = np.zeros(K, np.int32)
+workers = (np.arange(K, dtype=np.int32) // max(K // T, 1)).clip(0, T - 1).astype(np.int32)
 t = {"sample": 0.0, "run": 0.0, "wait": 0.0, "free": 0.0}
 ns = 0
 t0 = time.perf_counter()
@@ -41,4 +42,4 @@ for it in range(NB + 20):
     t["sample"] += b - a; t["run"] += c - b; t["wait"] += d - c; t["free"] += e - d
     cur, nxt = nxt, nn
 tot = time.perf_counter() - t0
-print(f"{K} reads per batch: {tot / NB * 1e3:.3f} ms per batch, {ns / tot:.3e} samples/s; per call (ms): " + ", ".join(f"{k} {v / NB * 1e3:.3f}" for k, v in t.items()))
+print(f"{K} reads per batch, -t {T}: {tot / NB * 1e3:.3f} ms per batch, {ns / tot:.3e} samples/s; per call (ms): " + ", ".join(f"{k} {v / NB * 1e3:.3f}" for k, v in t.items()))

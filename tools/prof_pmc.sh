@@ -5,7 +5,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/${1:-prof}
 shift || true
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-store-probe --pipeline-seconds 0 --e2e-seconds 0 $*"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-store-probe --pipeline-seconds 0 --e2e-seconds 0 --small-batch-seconds 0 --every-batch-launches 0 $*"
 # the stats pass runs the bench exactly as the driver does (defaults; CPU legs included): its kernel averages are the ones
 # the bench line's roofline.kernel_ms has to agree with
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python $GRAFT_REPO_ROOT/bench.py $* > $OUT/trace.log 2>&1
@@ -15,9 +15,15 @@ timeout 900 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_
 ls -R $OUT | head -30
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in their own passes (TCC slots); the WRITE pass also runs the
 # bench's store probe (k_store_probe writes a known 1 GiB per launch) to calibrate WRITE_SIZE units
-BENCH2="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --pipeline-seconds 0 --e2e-seconds 0 $*"
+BENCH2="python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --pipeline-seconds 0 --e2e-seconds 0 --small-batch-seconds 0 --every-batch-launches 0 $*"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o pmc4 -- $BENCH2 > $OUT/pmc4.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT -o pmc5 -- $BENCH2 > $OUT/pmc5.log 2>&1
+# the L2 request path of the step's kernels (two TCP counters per pass: more aborts rocprofv3), and the same counters on
+# tools/pmc_calib.hip's random 8-B look-ups in an L2-resident table (cal_rgather8): the request rate the chip sustains
+timeout 900 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum --kernel-trace --output-format csv -d $OUT -o pmc6 -- $BENCH > $OUT/pmc6.log 2>&1
+if [ -x $GRAFT_REPO_ROOT/tools/bin/pmc_calib ]; then
+  timeout 300 rocprofv3 --pmc TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -o cal1 -- $GRAFT_REPO_ROOT/tools/bin/pmc_calib 2 > $OUT/cal1.log 2>&1
+fi
 # condense on the box (the raw traces of a default run -- timed steps + the streaming leg -- exceed what gpurun brings back):
 # $OUT/summary/<name>_{summary.md,kernel_stats.csv,traffic.json,bench_under_rocprof.json}; the big CSVs are dropped
 NAME=$(basename $OUT)

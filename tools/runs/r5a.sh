@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r5a; mkdir -p $OUT
 D=squigulator_amd/csrc/libsqg_hip_dev.so
-export BENCH_ARGS="--pipeline-seconds 0 --e2e-seconds 0"
+export BENCH_ARGS="--pipeline-seconds 0 --e2e-seconds 0 --small-batch-seconds 0 --every-batch-launches 0"
 export REPS=2
 timeout 300 python bench.py --lib $PWD/$D --no-cpu-baseline --no-store-probe --steps 6 --warmup 2 $BENCH_ARGS > $OUT/first.log 2>&1
 grep -q '^{"metric"' $OUT/first.log || { echo "the plain bench run failed:"; tail -20 $OUT/first.log; exit 1; }
