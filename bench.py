@@ -487,12 +487,13 @@ def pipeline_leg(stage_one, run, n_batches):
     return samples, reads, dt, t_stage / max(n_batches, 1)
 
 
-def e2e_legs(gen, prof, flags, sample_batch, reads_per_batch, seconds):
+def e2e_legs(gen, prof, flags, sample_batch, reads_per_batch, seconds, kinds=("pinned_int16", "pinned_svb", "blow5", "blow5_fast")):
     """The other half of work_per_single_read / output_db (src/sim.c:602-611,630-641): what a host that drains the results gets
     (SURVEY.md 8d / H5).  Three legs, one host thread each, batch i+1 sampled + staged + queued before batch i is consumed:
     `pinned_int16` -- sqg_fetch_signal into sqg_host_alloc memory (raw int16 over PCIe); `pinned_svb` -- sqg_batch_compress (svb-zd on
     the device, the signal field of a BLOW5 record), then batch i+1 queued, then sqg_fetch_svb; `blow5` -- sqg_blow5_write_batch into /dev/shm (record framing +
-    zlib on the host's threads: the bytes the reference writes).  Never `value`: PCIe and zlib are 20x and 1500x below the kernels."""
+    zlib on the host's threads: the bytes the reference writes); `blow5_fast` -- the same call on a writer opened with SQG_BLOW5_STORED (records
+    framed on the device in stored-block zlib streams: a valid BLOW5 file with the reference's records, not its bytes).  Never `value`: PCIe and zlib are 20x and 1500x below the kernels."""
     import torch
     probe = sample_batch().run().wait()
     cap = int(probe.n_samples * 1.4) + 65536
@@ -503,9 +504,11 @@ def e2e_legs(gen, prof, flags, sample_batch, reads_per_batch, seconds):
     shm = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
     out = {"reads_per_batch": reads_per_batch,
            "what": "one host thread: sample + stage + queue batch i+1, wait for batch i, drain it; samples/s of the drained batches"}
-    for kind in ("pinned_int16", "pinned_svb", "blow5"):
+    for kind in kinds:
         path = os.path.join(shm, f"sqg_bench_e2e_{os.getpid()}.blow5")
-        w = api.Blow5Writer(path, prof, flags, threads=0) if kind == "blow5" else None
+        # blow5: the reference's bytes (deflate on the host's threads); blow5_fast: SQG_BLOW5_STORED -- the same records in stored-block
+        # zlib streams, framed on the device, one PCIe copy and one pwrite() behind the next batch (include/sqg.h)
+        w = api.Blow5Writer(path, prof, flags, threads=0, stored=(kind == "blow5_fast")) if kind.startswith("blow5") else None
         samples = nb = nbytes = 0
 
         def drain(b):
@@ -522,7 +525,7 @@ def e2e_legs(gen, prof, flags, sample_batch, reads_per_batch, seconds):
             t0 = time.perf_counter()
             while True:
                 last = nb >= 1 and time.perf_counter() - t0 >= seconds
-                if kind == "pinned_svb":                       # the encoder first (the context has ONE buffer of encodings: it cannot run ahead),
+                if kind in ("pinned_svb", "blow5_fast"):       # the encoder first (the context has ONE buffer of encodings: it cannot run ahead),
                     cur.compress(fetch=False)                  # the next batch's kernels behind it -- they run while the bytes cross PCIe
                 nxt = None if last else sample_batch().run()
                 cur.wait()
@@ -542,7 +545,8 @@ def e2e_legs(gen, prof, flags, sample_batch, reads_per_batch, seconds):
                 os.unlink(path)
             except OSError:
                 pass
-        out[kind] = {"value": samples / dt, "unit": "samples/s", "seconds": dt, "batches": nb, "bytes_per_sample": nbytes / max(samples, 1)}
+        out[kind] = {"value": samples / dt, "unit": "samples/s", "seconds": dt, "batches": nb, "bytes_per_sample": nbytes / max(samples, 1),
+                     "reads_per_batch": reads_per_batch, "GBps": nbytes / dt / 1e9}
     return out
 
 
@@ -582,6 +586,7 @@ def main():
                     help="wall time (at least two batches) of each end-to-end leg -- raw int16 into pinned host memory, svb-zd into pinned "
                          "host memory, BLOW5 into /dev/shm (`e2e` in the line; N = 1 only); 0 skips them")
     ap.add_argument("--e2e-batch-reads", type=int, default=2048, help="reads per batch of the end-to-end legs")
+    ap.add_argument("--e2e-fast-batch-reads", type=int, default=8192, help="reads per batch of the stored-block BLOW5 leg (`e2e.blow5_fast`)")
     ap.add_argument("--small-batch-seconds", type=float, default=1.0,
                     help="wall time of each small-batch streaming leg (`small_batch` in the line; N = 1, worker-sharded runs of the genome "
                          "workloads only): the reference's default batch size, `-t 1 -K 1000` and `-t 8 -K 1000` (src/sim.c:208-209), "
@@ -929,7 +934,13 @@ def main():
         Ke = min(args.e2e_batch_reads, K)
         we = workers[:Ke] if not W else np.minimum(w_lo + np.arange(Ke, dtype=np.int32) // max(Ke // W, 1), w_hi - 1).astype(np.int32)
         sync_all()
-        e2e = e2e_legs(gen, prof, flags, lambda: gen.sample(Ke, we), Ke, args.e2e_seconds)
+        e2e = e2e_legs(gen, prof, flags, lambda: gen.sample(Ke, we), Ke, args.e2e_seconds, kinds=("pinned_int16", "pinned_svb", "blow5"))
+        sync_all()
+        # the stored-block writer at a batch size of its own (the zlib leg above needs seconds per batch: hence its small ones): the file
+        # system is what bounds it (tools/io_probe.cpp: 6.9 GB/s into ONE file of a tmpfs on the pool's boxes), so per-batch overheads count
+        Kf = min(args.e2e_fast_batch_reads, K)
+        wf = workers[:Kf] if not W else np.minimum(w_lo + np.arange(Kf, dtype=np.int32) // max(Kf // W, 1), w_hi - 1).astype(np.int32)
+        e2e.update({k2: v for k2, v in e2e_legs(gen, prof, flags, lambda: gen.sample(Kf, wf), Kf, args.e2e_seconds, kinds=("blow5_fast",)).items() if k2 == "blow5_fast"})
         sync_all()
 
     ptot = torch.tensor(list(pipe[:3]) if pipe else [0.0, 0.0, 1.0], dtype=torch.float64, device="cuda" if on_gpu else "cpu")

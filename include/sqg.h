@@ -221,8 +221,23 @@ int  sqg_fetch_svb(sqg_ctx_t *ctx, sqg_batch_t *b, uint8_t *dst /* n_bytes */);
  * stream per record, as slow5lib's) run on `threads` host threads (<= 0: up to 16).  read_number and start_time continue
  * over the calls in read order (src/sim.c:602).  Pure host code: usable without a GPU when the encodings come from elsewhere. */
 typedef struct sqg_blow5 sqg_blow5_t;
-int  sqg_blow5_open(const char *path, const sqg_profile_t *profile, uint32_t flags /* SQG_RNA | SQG_R10 | SQG_ONT */,
+/* flags of sqg_blow5_open only -- the record compression MODE.  Default (bit clear): one deflate stream per record with slow5lib's
+ * parameters, on the host's threads: the file is `cmp`-identical to the reference's (28 MB/s per thread is what bounds it).
+ * SQG_BLOW5_STORED: the same records, each in a zlib stream of STORED blocks (RFC 1951 BTYPE 00: 78 01 | {final, LEN, ~LEN, <= 65535
+ * bytes}* | Adler-32) -- a valid BLOW5 file that slow5lib (any inflate) reads back to the same records, field for field and sample for
+ * sample, in other bytes (1.3 per sample instead of 0.97); sqg_blow5_write_batch then takes the records framed on the device
+ * (sqg_batch_blow5_records) and the host's part is one PCIe copy and one pwrite(), made behind the caller while the next batch is fetched.  (A deflate block with the fixed Huffman
+ * code would be larger, not smaller: svb-zd bytes are nearly uniform, and that code spends 8-9 bits on a literal.) */
+#define SQG_BLOW5_STORED 0x10000u
+int  sqg_blow5_open(const char *path, const sqg_profile_t *profile, uint32_t flags /* SQG_RNA | SQG_R10 | SQG_ONT | SQG_BLOW5_STORED */,
                     int32_t threads, sqg_blow5_t **out);
+/* The batch's records as SQG_BLOW5_STORED writes them, framed on the device around its svb-zd encodings (compressing the batch first
+ * if need be) and copied to pinned host memory of the context: *records (valid until the next-but-one call on this context), *n_bytes, and --
+ * rec_off may be NULL -- [n_reads+1] offsets of the records in it.  read_number0 / start_time0: records and samples written before
+ * this batch (src/sim.c:602).  Read ids of at most 4096 bytes. */
+int  sqg_batch_blow5_records(sqg_ctx_t *ctx, sqg_batch_t *b, const sqg_profile_t *profile, uint32_t flags, const char *read_ids,
+                             const int64_t *id_off, int64_t read_number0, uint64_t start_time0,
+                             const uint8_t **records, int64_t *n_bytes, const int64_t **rec_off);
 /*   read_ids/id_off [n+1]: the reads' ids, concatenated (src/sim.c:564-570); offset, median_before [n]; sig_off [n+1]: samples
  *   per read as differences (sqg_result_t.sig_off); svb/svb_off [n+1]: the encodings (sqg_fetch_svb / sqg_svb_t.svb_off) */
 int  sqg_blow5_write(sqg_blow5_t *w, int32_t n, const char *read_ids, const int64_t *id_off, const double *offset,

@@ -307,3 +307,25 @@ extern "C" void sqg_host_free(void* p) { free(p); }
 
 /* the BLOW5 writer: the product's own host code */
 #include "../squigulator_amd/csrc/h_blow5.h"
+
+/* the records of the writer's stored-block mode: the same host framing (blow5_record_stored), batch-wide */
+extern "C" int sqg_batch_blow5_records(sqg_ctx_t* c, sqg_batch_t* b, const sqg_profile_t* profile, uint32_t flags, const char* read_ids,
+                                       const int64_t* id_off, int64_t read_number0, uint64_t start_time0,
+                                       const uint8_t** records, int64_t* n_bytes, const int64_t** rec_off) {
+    if (!c || !b || !b->ran || !profile || !records || !n_bytes || (b->n > 0 && (!read_ids || !id_off))) return SQG_EINVAL;
+    if (b->svb_off.empty()) { sqg_svb_t sv; const int rc = sqg_batch_compress(c, b, &sv); if (rc) return rc; }
+    sqg_blow5 w; w.profile = *profile; w.flags = flags;
+    static thread_local std::vector<uint8_t> out, raw;
+    static thread_local std::vector<int64_t> ro;
+    out.clear(); ro.assign((size_t)b->n + 1, 0);
+    for (int i = 0; i < b->n; i++) {
+        if (id_off[i + 1] - id_off[i] > 4096) { c->err = "sqg_batch_blow5_records: read id longer than 4096 bytes"; return SQG_EINVAL; }
+        blow5_record_stored(raw, out, &w, read_ids + id_off[i], (size_t)(id_off[i + 1] - id_off[i]), b->offset[(size_t)i], b->median[(size_t)i],
+                            b->svb.data() + b->svb_off[(size_t)i], (uint64_t)(b->svb_off[(size_t)i + 1] - b->svb_off[(size_t)i]),
+                            (int32_t)(read_number0 + i), start_time0 + (uint64_t)b->sig_off[(size_t)i]);
+        ro[(size_t)i + 1] = (int64_t)out.size();
+    }
+    *records = out.data(); *n_bytes = (int64_t)out.size();
+    if (rec_off) *rec_off = ro.data();
+    return SQG_OK;
+}

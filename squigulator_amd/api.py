@@ -73,6 +73,7 @@ class CSample(C.Structure):
 
 
 SAMPLE_DNA, SAMPLE_RNA, SAMPLE_CDNA, SAMPLE_TRUNC, SAMPLE_FULL = 0, 1, 2, 4, 8
+BLOW5_STORED = 0x10000          # include/sqg.h SQG_BLOW5_STORED (flags of sqg_blow5_open)
 
 EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_device_count",
            "sqg_batch_stage", "sqg_batch_run", "sqg_batch_wait", "sqg_fetch_signal", "sqg_fetch_dwell",
@@ -80,7 +81,7 @@ EXPORTS = ("sqg_create", "sqg_destroy", "sqg_last_error", "sqg_strerror", "sqg_d
            "sqg_batch_compress", "sqg_fetch_svb", "sqg_genome_load", "sqg_batch_sample", "sqg_fetch_reads",
            "sqg_host_alloc", "sqg_host_free", "sqg_set_range_mode", "sqg_skip_reads", "sqg_batch_sample_range",
            "sqg_batch_run_begin", "sqg_batch_run_end", "sqg_genome_load_device",
-           "sqg_blow5_open", "sqg_blow5_write", "sqg_blow5_write_batch", "sqg_blow5_close", "sqg_blow5_last_error",
+           "sqg_blow5_open", "sqg_blow5_write", "sqg_blow5_write_batch", "sqg_blow5_close", "sqg_blow5_last_error", "sqg_batch_blow5_records",
            "sqg_genome_set_meth", "sqg_build_info", "sqg_set_stage_threads")
 
 # Environment knobs only the development build of the library reads (csrc/h_common.h: SQG_DEV_ENV; tools/README.md).  The release
@@ -191,6 +192,9 @@ def load_library(path: str | None = None):
                                   C.POINTER(i64), vp, C.POINTER(i64)]
     L.sqg_blow5_write_batch.restype = C.c_int
     L.sqg_blow5_write_batch.argtypes = [vp, vp, vp, C.c_char_p, C.POINTER(i64)]
+    L.sqg_batch_blow5_records.restype = C.c_int
+    L.sqg_batch_blow5_records.argtypes = [vp, vp, C.POINTER(CProfile), C.c_uint32, C.c_char_p, C.POINTER(i64), i64, C.c_uint64,
+                                          C.POINTER(C.c_void_p), C.POINTER(i64), C.POINTER(C.POINTER(i64))]
     L.sqg_blow5_close.restype = C.c_int
     L.sqg_blow5_close.argtypes = [vp, C.POINTER(i64)]
     L.sqg_blow5_last_error.restype = C.c_char_p
@@ -256,11 +260,13 @@ class Blow5Writer:
     """The library's native BLOW5 writer (sqg_blow5_*): header, record framing and zlib on host threads; the signal field is
     the svb-zd encoding made on the device.  Pure host code: write() works without a GPU."""
 
-    def __init__(self, path: str, profile: P.Profile, flags: int, threads: int = 0, lib_path: str | None = None):
+    def __init__(self, path: str, profile: P.Profile, flags: int, threads: int = 0, lib_path: str | None = None, stored: bool = False):
+        """stored: SQG_BLOW5_STORED -- the records in zlib streams of stored blocks, framed on the device by write_batch (include/sqg.h)"""
         self.L = load_library(lib_path)
         self.h = C.c_void_p()
         cp = CProfile(*profile.as_tuple())
-        rc = self.L.sqg_blow5_open(os.fsencode(path), C.byref(cp), flags & (P.SQ_RNA | P.SQ_R10 | P.SQ_ONT), threads, C.byref(self.h))
+        rc = self.L.sqg_blow5_open(os.fsencode(path), C.byref(cp), (flags & (P.SQ_RNA | P.SQ_R10 | P.SQ_ONT)) | (BLOW5_STORED if stored else 0),
+                                   threads, C.byref(self.h))
         if rc != 0:
             raise SqgError(rc, "sqg_blow5_open", path)
 
@@ -381,6 +387,18 @@ class Batch:
         out = np.empty(n, np.uint8) if out is None else out[:n]
         self.gen._chk(self.gen.L.sqg_fetch_svb(self.gen.ctx, self.handle, out.ctypes.data), "sqg_fetch_svb")
         return out
+
+    def blow5_records(self, profile, flags: int, read_ids, read_number0: int = 0, start_time0: int = 0):
+        """the batch's BLOW5 records in stored-block zlib streams, framed on the device (sqg_batch_blow5_records) -> (bytes copy, offsets)"""
+        blob = b"".join(read_ids)
+        ioff = np.zeros(len(read_ids) + 1, np.int64)
+        ioff[1:] = np.cumsum([len(r) for r in read_ids])
+        cp = CProfile(*profile.as_tuple())
+        recs, nb, ro = C.c_void_p(), C.c_int64(), C.POINTER(C.c_int64)()
+        self.gen._chk(self.gen.L.sqg_batch_blow5_records(self.gen.ctx, self.handle, C.byref(cp), flags, blob, ioff.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                       read_number0, start_time0, C.byref(recs), C.byref(nb), C.byref(ro)), "sqg_batch_blow5_records")
+        data = C.string_at(recs, nb.value) if nb.value else b""
+        return data, np.array([ro[i] for i in range(len(read_ids) + 1)], np.int64)
 
     def free(self):
         if self.handle:

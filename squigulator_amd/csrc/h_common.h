@@ -193,6 +193,12 @@ struct sqg_ctx {
     uint8_t* d_svb = nullptr; size_t svb_cap = 0;               // svb-zd encodings of the last compressed batch
     long long* d_svb_size = nullptr; size_t svb_size_cap = 0;   // per read
     long long* d_svb_off = nullptr; size_t svb_off_cap = 0;
+    uint8_t* d_b5meta = nullptr; size_t b5meta_cap = 0;        // sqg_batch_blow5_records: ids, offsets, per-read doubles (uploaded per call)
+    uint8_t* d_b5out = nullptr; size_t b5out_cap = 0;          // ... the framed records on the device
+    uint8_t* h_b5out[2] = {nullptr, nullptr}; size_t h_b5out_cap[2] = {0, 0};   // ... and in pinned host memory (what the call returns), two of
+    int b5_flip = 0;                                           //     them used alternately: a result stays valid over the NEXT call (a writer copies it out behind that call)
+    uint8_t* h_b5meta = nullptr; size_t h_b5meta_cap = 0;      // ... pinned staging of the upload
+    std::vector<int64_t> b5_rec_off;
     std::string err;
 };
 

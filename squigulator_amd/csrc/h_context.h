@@ -49,6 +49,7 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
         if (S.sampled) (void)hipEventDestroy(S.sampled);
     }
     (void)hipFree(ctx->d_svb); (void)hipFree(ctx->d_svb_size); (void)hipFree(ctx->d_svb_off);
+    (void)hipFree(ctx->d_b5meta); (void)hipFree(ctx->d_b5out); for (auto* q : ctx->h_b5out) if (q) (void)hipHostFree(q); if (ctx->h_b5meta) (void)hipHostFree(ctx->h_b5meta);
     (void)hipFree(ctx->d_genome); (void)hipFree(ctx->d_contig_off); (void)hipFree(ctx->d_cum); (void)hipFree(ctx->d_nprefix);
     (void)hipFree(ctx->d_trans_csum); (void)hipFree(ctx->d_trans_idx); (void)hipFree(ctx->d_samp);
     (void)hipFree(ctx->d_meth); (void)hipFree(ctx->d_meth_has); (void)hipFree(ctx->d_meth_st);

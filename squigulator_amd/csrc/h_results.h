@@ -166,6 +166,73 @@ extern "C" int sqg_fetch_svb(sqg_ctx_t* c, sqg_batch_t* b, uint8_t* dst) {
     return SQG_OK;
 }
 
+// The batch's BLOW5 records -- slow5_rec_to_mem's layout (slow5lib/src/slow5.c:3928-4072) around the device's svb-zd bytes, each in a zlib
+// stream of stored blocks (k_blow5.h) -- framed on the device and copied to pinned host memory of the context: what a writer appends to
+// the file as it is.  Compresses the batch first unless its encodings are still the context's.
+extern "C" int sqg_batch_blow5_records(sqg_ctx_t* c, sqg_batch_t* b, const sqg_profile_t* profile, uint32_t flags, const char* read_ids,
+                                       const int64_t* id_off, int64_t read_number0, uint64_t start_time0,
+                                       const uint8_t** records, int64_t* n_bytes, const int64_t** rec_off) {
+    if (!c || !b || !b->ran || !profile || !records || !n_bytes || (b->n > 0 && (!read_ids || !id_off))) return SQG_EINVAL;
+    if (b->run_idx + 2 < c->runs || !slot_is_mine(c, b)) return SQG_ESEQUENCE;
+    int rc;
+    if (b->n_svb < 0 || b->compress_seq != c->compress_seq) { sqg_svb_t sv; if ((rc = sqg_batch_compress(c, b, &sv))) return rc; }
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const int n = b->n;
+    const bool ont = (flags & SQG_ONT) != 0;
+    std::vector<int64_t>& ro = c->b5_rec_off;
+    ro.assign((size_t)n + 1, 0);
+    for (int i = 0; i < n; i++) {
+        const int64_t idl = id_off[i + 1] - id_off[i];
+        if (idl < 0 || idl > B5_ID_MAX) { c->err = "sqg_batch_blow5_records: read id longer than 4096 bytes (use the host-zlib writer)"; return SQG_EINVAL; }
+        const unsigned long long R = (unsigned long long)(2 + idl + 4 + 32 + 8) + (unsigned long long)(b->h_svboff[i + 1] - b->h_svboff[i]) + (unsigned long long)(30 + (ont ? 1 : 0));
+        ro[(size_t)i + 1] = ro[(size_t)i] + (int64_t)b5_stored_size(R);
+    }
+    const size_t total = (size_t)ro[(size_t)n];
+    *records = nullptr; *n_bytes = (int64_t)total;
+    if (rec_off) *rec_off = ro.data();
+    if (n == 0) return SQG_OK;
+    // one upload: id offsets | record offsets | offsets | medians | id bytes
+    const size_t id_bytes = (size_t)(id_off[n] - id_off[0]);
+    const size_t o_io = 0, o_ro = o_io + ((size_t)n + 1) * 8, o_of = o_ro + ((size_t)n + 1) * 8, o_md = o_of + (size_t)n * 8, o_id = o_md + (size_t)n * 8, meta = o_id + id_bytes + 16;
+    if ((rc = ensure(c, (void**)&c->d_b5meta, &c->b5meta_cap, meta, 1))) return rc;
+    if ((rc = ensure(c, (void**)&c->d_b5out, &c->b5out_cap, total + 64, 1))) return rc;
+    if (c->h_b5meta_cap < meta) {
+        if (c->h_b5meta) (void)hipHostFree(c->h_b5meta);
+        c->h_b5meta = nullptr; c->h_b5meta_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_b5meta, meta + meta / 2, hipHostMallocDefault));
+        c->h_b5meta_cap = meta + meta / 2;
+    }
+    const int fl = c->b5_flip ^= 1;
+    if (c->h_b5out_cap[fl] < total) {
+        if (c->h_b5out[fl]) (void)hipHostFree(c->h_b5out[fl]);
+        c->h_b5out[fl] = nullptr; c->h_b5out_cap[fl] = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_b5out[fl], total + total / 4, hipHostMallocDefault));
+        c->h_b5out_cap[fl] = total + total / 4;
+    }
+    {
+        long long* io = reinterpret_cast<long long*>(c->h_b5meta + o_io);
+        for (int i = 0; i <= n; i++) io[i] = (long long)(id_off[i] - id_off[0]);
+        memcpy(c->h_b5meta + o_ro, ro.data(), ((size_t)n + 1) * 8);
+        memcpy(c->h_b5meta + o_of, b->offset.data(), (size_t)n * 8);
+        memcpy(c->h_b5meta + o_md, b->median.data(), (size_t)n * 8);
+        memcpy(c->h_b5meta + o_id, read_ids + id_off[0], id_bytes);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_b5meta, c->h_b5meta, meta, hipMemcpyHostToDevice, c->stream2));
+    Blow5Params P;
+    P.svb = c->d_svb; P.svb_off = c->d_svb_off; P.sig_off = c->slot[b->slot].d_sigoff;
+    P.id_off = reinterpret_cast<const long long*>(c->d_b5meta + o_io); P.rec_off = reinterpret_cast<const long long*>(c->d_b5meta + o_ro);
+    P.offset = reinterpret_cast<const double*>(c->d_b5meta + o_of); P.median = reinterpret_cast<const double*>(c->d_b5meta + o_md);
+    P.ids = c->d_b5meta + o_id; P.out = c->d_b5out;
+    P.digitisation = profile->digitisation; P.range = profile->range; P.sample_rate = profile->sample_rate;
+    P.read_number0 = read_number0; P.start_time0 = start_time0; P.ont = ont ? 1 : 0; P.n = n;
+    hipLaunchKernelGGL(k_blow5_frame, dim3((unsigned)n), dim3(256), 0, c->stream2, P);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_b5out[fl], c->d_b5out, total, hipMemcpyDeviceToHost, c->stream2));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    *records = c->h_b5out[fl];
+    return SQG_OK;
+}
+
 extern "C" void* sqg_host_alloc(size_t bytes) {
     void* p = nullptr;
     if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;

@@ -1,5 +1,5 @@
 // sqg_kernels.h -- gfx950 device code of the per-read signal path (included by sqg_hip.hip); the kernels live in
-// k_common.h, k_events.h, k_part.h, k_part_events.h, k_samples.h, k_sampler.h and k_svb.h.
+// k_common.h, k_events.h, k_part.h, k_part_events.h, k_samples.h, k_sampler.h, k_svb.h and k_blow5.h.
 //
 //   k_init_rows   per-(worker,k-mer) stream seeds                       (src/sim.c:238-257)
 //   k_dwell       per-event dwell draw from the worker's time stream   (src/gensig.c:254-257)
@@ -13,6 +13,7 @@
 //   k_items       one descriptor per work item of the lean sample kernel
 //   k_sample, k_copy_reads   gen_read on the device-resident genome        (src/genread.c:125-370)
 //   k_svb_*       slow5lib's svb-zd signal compression                    (slow5lib/src/slow5_press.c:1055-1087)
+//   k_blow5_frame BLOW5 records (slow5_rec_to_mem's layout) in stored-block zlib streams (slow5lib/src/slow5.c:3928-4072)
 //
 // Arithmetic modes.  EXACT: every draw goes through the FP64 restatement of nrng()
 // (src/rand.h:87-94).  CERTIFIED: a draw is first evaluated with fp32 hardware transcendentals;
@@ -33,3 +34,4 @@
 #include "k_samples.h"
 #include "k_sampler.h"
 #include "k_svb.h"
+#include "k_blow5.h"

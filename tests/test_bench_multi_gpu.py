@@ -160,6 +160,9 @@ def test_bench_line_carries_the_contract():
     assert e["pinned_int16"]["bytes_per_sample"] == 2.0 and 0.5 < e["pinned_svb"]["bytes_per_sample"] < 2.0
     assert 0.4 < e["blow5"]["bytes_per_sample"] < e["pinned_svb"]["bytes_per_sample"]      # (zlib over the svb-zd bytes)
     assert e["blow5"]["value"] < e["pinned_svb"]["value"] < d["value"]
+    # round 5: the stored-block writer (SQG_BLOW5_STORED): the svb-zd bytes + ~130 B of framing per record, far faster than zlib
+    assert e["blow5_fast"]["unit"] == "samples/s" and e["blow5_fast"]["batches"] >= 2 and e["blow5_fast"]["value"] > 3 * e["blow5"]["value"]
+    assert e["pinned_svb"]["bytes_per_sample"] < e["blow5_fast"]["bytes_per_sample"] < e["pinned_svb"]["bytes_per_sample"] * 1.01 + 0.01
     if c["kind"] == "reference":
         assert c["to_blow5"] > 0
     # round 5: kernel_ms over >= 20 launches (a leg in which every batch carries the phase events), the reference's default batch size

@@ -15,7 +15,10 @@ import orc
 from blow5_cases import BLOW5_CASES
 from squigulator_amd import api, model, options, profiles
 
+import subprocess
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "blow5")
+DUMP = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_blow5_dump")   # the reference's slow5lib as a reader
 INPUTS = os.path.join(os.path.dirname(__file__), "golden", "inputs")
 
 
@@ -141,4 +144,167 @@ def test_full_size_batch_round_trip(tmp_path):
         one, ch = struct.unpack_from("<Qc", r, q); q += 9
         med, rn, mux, st = struct.unpack_from("<diBQ", r, q)
         assert (one, ch, med, rn, mux, st) == (1, b"0", b.median_before[i], i, 0, int(b.sig_off[i]))
+    b.free(); gen.close()
+
+
+# ---- SQG_BLOW5_STORED: the same records in zlib streams of stored blocks (include/sqg.h) ------------------------------------------
+def ref_dump(path, how="full"):
+    """the file as the REFERENCE's own slow5lib reads it (oracle/_ref/ref_blow5_dump: header attributes, every field of every record,
+    every sample): None where the reader was not built (no /root/reference at build time)"""
+    if not os.path.exists(DUMP):
+        return None
+    return subprocess.run([DUMP, path] + (["hash"] if how == "hash" else []), capture_output=True, text=True, check=True).stdout
+
+
+def _stored_records_are_valid(buf):
+    """every record's stream is 78 01 + stored blocks + Adler-32, nothing else: sizes as include/sqg.h states them"""
+    hs = struct.unpack_from("<I", buf, 64)[0]
+    p = 68 + hs
+    while buf[p:] != b"5WOLB":
+        (n,) = struct.unpack_from("<Q", buf, p)
+        z = buf[p + 8:p + 8 + n]
+        assert z[:2] == b"\x78\x01"
+        q, raw = 2, b""
+        while True:
+            final, ln, nln = z[q], *struct.unpack_from("<HH", z, q + 1)
+            assert final in (0, 1) and ln == (~nln & 0xffff) and (final == 1 or ln == 65535)
+            raw += z[q + 5:q + 5 + ln]
+            q += 5 + ln
+            if final:
+                break
+        assert q + 4 == n and struct.unpack_from(">I", z, q)[0] == zlib.adler32(raw)
+        p += 8 + n
+
+
+@pytest.mark.parametrize("cid", [c[0] for c in BLOW5_CASES])
+def test_stored_mode_holds_the_reference_records(cid, tmp_path):
+    """host framing (sqg_blow5_write with SQG_BLOW5_STORED): same header, same uncompressed records as the reference's file, and the
+    reference's own slow5lib reads both files to the same text, field for field and sample for sample"""
+    o, ids, offset, median, so, sig = _case(cid)
+    gold = os.path.join(GOLD, cid + ".blow5")
+    encs = [orc.svb_zd(sig[so[i]:so[i + 1]]) for i in range(len(ids))]
+    path = str(tmp_path / "s.blow5")
+    w = api.Blow5Writer(path, o.profile, o.flags, threads=3, stored=True)
+    done = 0
+    while done < len(ids):
+        nb = min(o.batch, len(ids) - done)
+        e = encs[done:done + nb]
+        eo = np.concatenate(([0], np.cumsum([len(x) for x in e]))).astype(np.int64)
+        w.write(ids[done:done + nb], offset[done:done + nb], median[done:done + nb], so[done:done + nb + 1] - so[done], np.concatenate(e), eo)
+        done += nb
+    n = w.close()
+    got = open(path, "rb").read()
+    assert n == len(got)
+    hdr_g, rec_g = parse_blow5(got)
+    hdr_w, rec_w = parse_blow5(open(gold, "rb").read())
+    assert hdr_g == hdr_w and rec_g == rec_w
+    _stored_records_are_valid(got)
+    d = ref_dump(path)
+    if d is not None:
+        assert d == ref_dump(gold) and d.strip().endswith("records\t%d" % len(ids))
+
+
+def test_stored_mode_long_records(tmp_path):
+    """records of several stored blocks (> 65535 bytes), of exactly one full block, and ids of every length: sizes and checksums"""
+    prof, fl = profiles.get_profile("dna-r9-prom")
+    rng = np.random.default_rng(3)
+    lens = [1, 30000, 65535 - 107, 65535 - 106, 65535 - 105, 200000, 131070 - 106]
+    sig = [rng.integers(300, 900, m).astype(np.int16) for m in lens]
+    encs = [orc.svb_zd(x) for x in sig]
+    ids = [b"r%d" % i + b"x" * (i * 7) for i in range(len(lens))]
+    so = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    eo = np.concatenate(([0], np.cumsum([len(x) for x in encs]))).astype(np.int64)
+    path = str(tmp_path / "l.blow5")
+    w = api.Blow5Writer(path, prof, fl, threads=2, stored=True)
+    w.write(ids, rng.normal(10, 3, len(lens)), rng.normal(200, 20, len(lens)), so, np.concatenate(encs), eo)
+    w.close()
+    buf = open(path, "rb").read()
+    _stored_records_are_valid(buf)
+    _, recs = parse_blow5(buf)
+    for i, r in enumerate(recs):
+        q = 2 + len(ids[i]) + 4 + 32
+        (nb,) = struct.unpack_from("<Q", r, q)
+        dec, used = orc.svb_zd_decode(np.frombuffer(r, np.uint8, nb, q + 8))
+        np.testing.assert_array_equal(dec, sig[i])
+    d = ref_dump(path, "hash")
+    assert d is None or d.strip().endswith("records\t%d" % len(lens))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cid", ["r9_t1", "r10_t1", "rna004_prefix", "r9_two_batches", "r9_ont"])
+def test_device_framed_records_equal_the_host_framing_and_the_reference_records(cid, tmp_path):
+    """the product path in stored mode: fixture reads -> kernels -> svb-zd -> records framed on the device (k_blow5_frame) -> file.  The
+    bytes are those of the host framing of the same records (sqg_blow5_write with the flag), the uncompressed records the reference
+    file's, and the reference's slow5lib reads both files to the same text"""
+    o, ids, offset, median, so, sig = _case(cid)
+    import bench
+    contigs = bench.load_contigs(os.path.join(INPUTS, o.ref))
+    k = o.kmer_size_default
+    mean, stdv = model.synthetic_model(k)
+    gen = api.SignalGenerator(o.profile, o.flags, k, mean, stdv, o.seed, num_workers=o.threads, mode=api.MODE_CERTIFIED)
+    gen.load_genome(contigs, o.rlen, api.SAMPLE_RNA if (o.flags & profiles.SQ_RNA) else api.SAMPLE_DNA)
+    p_dev, p_host = str(tmp_path / "dev.blow5"), str(tmp_path / "host.blow5")
+    w = api.Blow5Writer(p_dev, o.profile, o.flags, threads=2, stored=True)
+    wh = api.Blow5Writer(p_host, o.profile, o.flags, threads=1, stored=True)
+    done = 0
+    while done < len(ids):
+        nb = min(o.batch, len(ids) - done)
+        b = gen.sample(nb).run().wait()
+        w.write_batch(b, ids[done:done + nb])
+        enc, eo = b.compress()
+        wh.write(ids[done:done + nb], b.offset, b.median_before, b.sig_off, enc, eo)
+        b.free()
+        done += nb
+    w.close(); wh.close()
+    gen.close()
+    got = open(p_dev, "rb").read()
+    assert got == open(p_host, "rb").read()
+    gold = os.path.join(GOLD, cid + ".blow5")
+    assert parse_blow5(got) == parse_blow5(open(gold, "rb").read())
+    _stored_records_are_valid(got)
+    d = ref_dump(p_dev)
+    assert d is None or d == ref_dump(gold)
+
+
+@pytest.mark.gpu
+def test_device_framing_of_a_bench_sized_batch(tmp_path):
+    """2048 reads of 10 kb (records of 2-4 stored blocks): the device's records against the host framing, byte for byte, and read back
+    by the reference's slow5lib (hashes of the signals against the batch's own)"""
+    import bench
+    prof, fl = profiles.get_profile("dna-r10-prom")
+    mean, stdv = model.synthetic_model(9)
+    gen = api.SignalGenerator(prof, fl, 9, mean, stdv, 42, num_workers=1, mode=api.MODE_CERTIFIED)
+    gen.load_genome(bench.synthetic_genome_host(8.0), 10000, api.SAMPLE_DNA)
+    b = gen.sample(2048).run().wait()
+    ids = [b"S1_%d!c!0!1!+" % (i + 1) for i in range(b.n_reads)]
+    recs, ro = b.blow5_records(prof, fl, ids, read_number0=5, start_time0=12345)
+    enc, eo = b.compress()
+    ph = str(tmp_path / "h.blow5")
+    wh = api.Blow5Writer(ph, prof, fl, threads=4, stored=True)
+    wh.write(ids, b.offset, b.median_before, b.sig_off, enc, eo)
+    wh.close()
+    host = open(ph, "rb").read()
+    hs = struct.unpack_from("<I", host, 64)[0]
+    body = host[68 + hs:-5]
+    assert len(recs) == ro[-1] == len(body)
+    # (the host file starts its numbering at 0: patch nothing, compare a file written by write_batch instead)
+    pd = str(tmp_path / "d.blow5")
+    w = api.Blow5Writer(pd, prof, fl, threads=4, stored=True)
+    w.write_batch(b, ids)
+    n = w.close()
+    dev = open(pd, "rb").read()
+    assert n == len(dev) and dev == host
+    _stored_records_are_valid(dev[:68 + hs] + dev[68 + hs:68 + hs + int(ro[3])] + b"5WOLB")       # (the first three records, parsed in Python)
+    d = ref_dump(pd, "hash")
+    if d is not None:
+        sig = b.signal()
+        lines = [ln for ln in d.splitlines() if ln.startswith("S1_")]
+        assert len(lines) == b.n_reads
+        for i in (0, 1, 777, b.n_reads - 1):
+            h = 1469598103934665603
+            for v in sig[b.sig_off[i]:b.sig_off[i + 1]].astype(np.uint16).tolist():
+                h = ((h ^ (v & 0xff)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+                h = ((h ^ (v >> 8)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+            f = lines[i].split("\t")
+            assert f[-1] == "fnv1a:%016x" % h and int(f[6]) == b.sig_off[i + 1] - b.sig_off[i] and int(f[9]) == i
     b.free(); gen.close()
