@@ -123,6 +123,30 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     P.evrec = S.d_evrec;
     // bucketed hand-out with the wavefront-per-link passes: 4 B per event between the scatter pass and the sample kernels (k_part_events.h)
     if (b->part && b->pieces && !b->one) { P.evrec32 = reinterpret_cast<uint32_t*>(S.d_evrec); P.lbase = S.d_lbase; P.tile_link = S.d_tile_link; } P.tile_read = b->d_tile_read; P.stile_read = b->d_stile_read;
+    // what k_items needs of P (the rest of the sample kernels' parameters follows further down): k_items may run inside k_part_hist
+    {
+        const bool rna_prefix0 = (c->cfg.flags & SQG_RNA) && (c->cfg.flags & SQG_PREFIX);
+        P.shift_len = rna_prefix0 ? (int)strlen(kAdaptorRna) * (int)p.dwell_mean : 0;
+        P.slow_count = S.d_fix_count + 1; P.items = S.d_items; P.lean_epl = c->lean_epl;
+        P.slow_tiles = (certified && c->use_kmer_streams) ? S.d_slow : nullptr;
+    }
+    // (round 5) bucketed hand-out, one launch sequence (no range sharding): the scan of the reads' totals runs as extra workgroups of
+    // k_part_mid and the lean kernel's work items are prepared by extra workgroups of k_part_hist -- two launches and their gaps less per
+    // batch (35 us of a 3.7-ms step).  SQG_NO_FOLD=1 (development build) keeps the two kernels for A/B runs.
+    const bool fold = phase == 0 && n > 0 && b->n_chains > 0 && b->part && !b->one && b->pieces && certified && c->use_kmer_streams &&
+                      (c->lean_epl < 4 || SQG_LEAN_ITEMS4) && !SQG_DEV_ENV("SQG_MID_SPLIT") && !SQG_DEV_ENV("SQG_NO_FOLD");
+    const unsigned scan_wgs = n > 0 ? (unsigned)((n + SCAN_WG - 1) / SCAN_WG) : 0u;
+    ScanArgs SA;
+    memset(&SA, 0, sizeof SA);
+    if (n > 0 && phase != 1) {
+        // the scan also writes the offsets through the batch's pinned host mapping (no copy between kernels)
+        const size_t cap0 = c->scan_part_cap;
+        if ((rc = ensure(c, (void**)&c->d_scan_part, &c->scan_part_cap, (size_t)2 * scan_wgs, sizeof(unsigned long long)))) return rc;
+        if (c->scan_part_cap != cap0)                         // tickets start at 1: a fresh array must not hold one by accident
+            HIPCHK(c, hipMemsetAsync(c->d_scan_part, 0, c->scan_part_cap * sizeof(unsigned long long), c->stream));
+        SA.seglen = Q.d_seglen; SA.n_reads = n; SA.sig_off = S.d_sigoff; SA.host_off = b->h_sigoff_dev; SA.err = b->d_err; SA.counters = S.d_fix_count;
+        SA.part = c->d_scan_part; SA.ticket = ++c->scan_tickets; SA.shard_counters = S.d_fix_sh_count;   // (a ticket per launch, also after a failed run)
+    }
     constexpr int NT = SQG_EVENT_THREADS, NT_WIDE = 1024;
     // few chains (the reference's default -K 1000 with one worker per read): a chain is a sequence of segments, each with
     // its barriers and LDS round trips, and there are not enough chains to hide them -- 1024 threads per chain walk it in a
@@ -222,15 +246,20 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
                     } else {
                         // offsets per (partition, worker chain), the tile offsets of split reads, the slices and their bounds: one launch
                         const int n_off = (int)n_pairs, n_pc = b->split_reads ? b->n_pieces : 0;
-                        hipLaunchKernelGGL(k_part_mid, dim3((unsigned)(n_off + (n_pc + 15) / 16)), dim3(1024), 0, c->stream, P, d_pcnt,
+                        const int n_sc = fold ? (int)scan_wgs : 0;
+                        hipLaunchKernelGGL(k_part_mid, dim3((unsigned)(n_off + (n_pc + 15) / 16 + n_sc)), dim3(1024), 0, c->stream, P, d_pcnt,
                                            d_pcnt + (size_t)b->n_chains * n_part, n_part, b->n_chains, b->d_wlink_off, ptotal, pstart, (int)n_pairs, b->slice_len,
-                                           pfirst, slice_lo, slice_hi, n_off, n_pc, c->d_mid_done);
+                                           pfirst, slice_lo, slice_hi, n_off, n_pc, c->d_mid_done, SA, n_sc);
                     }
                     HIPCHK(c, hipGetLastError());
                     if ((rc = dbg_sync(c, "k_events<count>/k_part_offsets"))) return rc;
                     launch_part_events(0, false);                 // every event to its slot (the dwell is in memory now)
                 }
-                hipLaunchKernelGGL(k_part_hist, dim3(pgrid), dim3(256), 0, c->stream, S.d_part, slice_lo, slice_hi, pfirst + n_pairs, c->d_phist);
+                {
+                    const int n_st = fold ? (int)b->n_stiles : 0;
+                    hipLaunchKernelGGL(k_part_hist, dim3(pgrid + (unsigned)((n_st + 255) / 256)), dim3(256), 0, c->stream, S.d_part, slice_lo, slice_hi, pfirst + n_pairs,
+                                       c->d_phist, P, n_st, pgrid);
+                }
                 HIPCHK(c, hipGetLastError());
                 if ((rc = dbg_sync(c, "k_events<scatter>/k_part_hist"))) return rc;
                 if (phase == 1) {                                 // range sharding: what this range draws per stream, for the exchange
@@ -341,18 +370,11 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
     }
     if (!untimed) HIPCHK(c, hipEventRecord(b->ev[3], c->stream));
     if (n > 0) {
-        // the scan also writes the offsets through the batch's pinned host mapping (no copy between kernels)
-        const unsigned scan_wgs = (unsigned)((n + SCAN_WG - 1) / SCAN_WG);
-        {
-            const size_t cap0 = c->scan_part_cap;
-            if ((rc = ensure(c, (void**)&c->d_scan_part, &c->scan_part_cap, (size_t)2 * scan_wgs, sizeof(unsigned long long)))) return rc;
-            if (c->scan_part_cap != cap0)                         // tickets start at 1: a fresh array must not hold one by accident
-                HIPCHK(c, hipMemsetAsync(c->d_scan_part, 0, c->scan_part_cap * sizeof(unsigned long long), c->stream));
+        if (!fold) {                                              // (else: the scan ran inside k_part_mid)
+            hipLaunchKernelGGL(k_scan, dim3(scan_wgs), dim3(SCAN_WG), 0, c->stream, SA);
+            HIPCHK(c, hipGetLastError());
+            if ((rc = dbg_sync(c, "k_scan"))) return rc;
         }
-        hipLaunchKernelGGL(k_scan, dim3(scan_wgs), dim3(SCAN_WG), 0, c->stream, Q.d_seglen, n, S.d_sigoff, b->h_sigoff_dev,
-                           b->d_err, S.d_fix_count, c->d_scan_part, ++c->scan_tickets, S.d_fix_sh_count);   // (a ticket per launch, also after a failed run)
-        HIPCHK(c, hipGetLastError());
-        if ((rc = dbg_sync(c, "k_scan"))) return rc;
     } else HIPCHK(c, hipMemsetAsync(S.d_fix_count, 0, 4 * sizeof(unsigned int), c->stream));
     // Output size is data-dependent.  A hard bound exists (|z| <= sqrt(2 ln(2^31-1)) = 6.5556 for any
     // draw), so the slab is sized by it and the launches continue without a host round trip; only
@@ -417,7 +439,8 @@ static int run_impl(sqg_ctx* c, sqg_batch* b, const int phase, const uint32_t* b
             if (lean_grid_cap > 0) lgrid = std::min(lgrid, (unsigned)lean_grid_cap);
             // work items of 256 events (4 per lane) look their descriptor up themselves, on the scalar unit; with shorter
             // items (profiles with long dwells) the look-up chain per item is worth a kernel of its own
-            if (c->lean_epl < 4 || SQG_LEAN_ITEMS4) hipLaunchKernelGGL(k_items, dim3((unsigned)((n_stiles + 255) / 256)), dim3(256), 0, c->stream, P, n_stiles, n, nullptr);
+            if (fold) {}                                          // (the work items were prepared inside k_part_hist)
+            else if (c->lean_epl < 4 || SQG_LEAN_ITEMS4) hipLaunchKernelGGL(k_items, dim3((unsigned)((n_stiles + 255) / 256)), dim3(256), 0, c->stream, P, n_stiles);
             else P.items = nullptr;
             if (c->stream2 != c->stream) {
                 HIPCHK(c, hipEventRecord(b->ev[7], c->stream));              // event side done: the sample kernels may start ...

@@ -118,17 +118,26 @@ __global__ __launch_bounds__(256) void k_dwell(const ReadDesc* __restrict__ read
 // cleared.  sig_off goes to HBM for the kernels and, when host_off is given, through the pinned host mapping straight
 // to the host (no D2H copy between kernels): visible once the stream has been synchronised.
 #define SCAN_WG 1024
-__global__ __launch_bounds__(SCAN_WG) void k_scan(const unsigned long long* __restrict__ seglen, int n_reads,
-                                                  long long* __restrict__ sig_off, long long* __restrict__ host_off,
-                                                  unsigned int* __restrict__ err, unsigned int* __restrict__ counters,
-                                                  unsigned long long* __restrict__ part, unsigned long long ticket,
-                                                  unsigned int* __restrict__ shard_counters) {
+struct ScanArgs {                                        // (k_scan's arguments: the scan also runs as extra workgroups of k_part_mid)
+    const unsigned long long* seglen; int n_reads;
+    long long* sig_off; long long* host_off;
+    unsigned int* err; unsigned int* counters;
+    unsigned long long* part; unsigned long long ticket;
+    unsigned int* shard_counters;
+};
+// workgroup g of ng (SCAN_WG threads; the workgroups before g were dispatched earlier)
+__device__ static inline void scan_body(const ScanArgs& A, const int g, const int ng) {
+    const unsigned long long* __restrict__ seglen = A.seglen; const int n_reads = A.n_reads;
+    long long* __restrict__ sig_off = A.sig_off; long long* __restrict__ host_off = A.host_off;
+    unsigned int* __restrict__ err = A.err; unsigned int* __restrict__ counters = A.counters;
+    unsigned long long* __restrict__ part = A.part; const unsigned long long ticket = A.ticket;
+    unsigned int* __restrict__ shard_counters = A.shard_counters;
     __shared__ long long wsum[SCAN_WG / 64];
     __shared__ long long before_sh;
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, g = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (g == 0 && tid < 4) counters[tid] = 0;            // fix-up list / slow-tile list counters of this batch
     if (shard_counters)                                  // ... and the FIX_SHARDS list counters of the lean kernel
-        for (int i = g * SCAN_WG + tid; i < FIX_SHARDS; i += gridDim.x * SCAN_WG) shard_counters[i * FIX_SHARD_STRIDE] = 0;
+        for (int i = g * SCAN_WG + tid; i < FIX_SHARDS; i += ng * SCAN_WG) shard_counters[i * FIX_SHARD_STRIDE] = 0;
     const int i = g * SCAN_WG + tid;
     long long v = 0;
     if (i < n_reads) {
@@ -162,6 +171,7 @@ __global__ __launch_bounds__(SCAN_WG) void k_scan(const unsigned long long* __re
     if (i < n_reads) { sig_off[i] = run; if (host_off) host_off[i] = run; }
     if (i == n_reads - 1) { sig_off[n_reads] = run + v; if (host_off) host_off[n_reads] = run + v; }
 }
+__global__ __launch_bounds__(SCAN_WG) void k_scan(const ScanArgs A) { scan_body(A, (int)blockIdx.x, (int)gridDim.x); }
 
 // ---- split chains --------------------------------------------------------------------------
 // With few workers and many reads (the reference's `-t 1`, or `-t 8 -K 1000`) a worker's chain of reads is cut into

@@ -157,11 +157,16 @@ __global__ __launch_bounds__(256) void k_part_slice_bounds(const uint32_t* __res
 #ifndef PART_HIST_V4
 #define PART_HIST_V4 1
 #endif
+// Workgroups from `first_items` on (round 5) prepare the lean sample kernel's work items instead (items_body, k_samples.h: they need the
+// scan's offsets and the scatter pass' tile links, both complete before this launch, and nothing of this kernel): k_items as a launch of
+// its own was 15 us of work behind a launch gap.
+__device__ static inline void items_body(const SigParams& P, const int block, const int n_stiles);
 __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* __restrict__ part, const uint32_t* __restrict__ slice_lo,
                                                    const uint32_t* __restrict__ slice_hi, const uint32_t* __restrict__ n_slices,
-                                                   uint32_t* __restrict__ phist) {
+                                                   uint32_t* __restrict__ phist, const SigParams P, const int n_stiles, const unsigned first_items) {
     __shared__ uint32_t row[PART_SUB + PART_HIST_PAD];
     const int tid = threadIdx.x;
+    if (blockIdx.x >= first_items) { items_body(P, (int)(blockIdx.x - first_items), n_stiles); return; }
     if (blockIdx.x >= *n_slices) return;
     for (int i = tid; i < PART_SUB; i += 256) row[i] = 0u;
     __syncthreads();

@@ -469,9 +469,17 @@ __global__ __launch_bounds__(64) void k_part_tile_bases(const SigParams P) { par
 // release / acquire: the others' totals are then visible to it -- goes on to k_part_slices and the slices' bounds.
 __global__ __launch_bounds__(1024) void k_part_mid(const SigParams P, const uint32_t* __restrict__ pcnt, uint32_t* __restrict__ poff, const int n_part, const int n_links,
                                                    const int* __restrict__ wlink_off, uint32_t* ptotal, uint32_t* pstart, const int n_pairs, const uint32_t slice_len,
-                                                   uint32_t* pfirst, uint32_t* slice_lo, uint32_t* slice_hi, const int n_off, const int n_pieces, unsigned int* done) {
+                                                   uint32_t* pfirst, uint32_t* slice_lo, uint32_t* slice_hi, const int n_off, const int n_pieces, unsigned int* done,
+                                                   const ScanArgs SA, const int n_scan) {
     __shared__ int last;
     const int g = blockIdx.x;
+    const int n_pcb = (n_pieces + 15) / 16;
+    if (g >= n_off + n_pcb) {
+        // (round 5) the scan of the reads' sample totals (k_scan: 8 us behind a launch gap): its inputs are the first event pass', it needs
+        // nothing of this kernel; its workgroups come last in the grid, in order (a scan workgroup waits for the ones before it only)
+        if (g - n_off - n_pcb < n_scan) scan_body(SA, g - n_off - n_pcb, n_scan);
+        return;
+    }
     if (g >= n_off) {
         const int pi = (g - n_off) * 16 + (int)(threadIdx.x >> 6);
         if (pi < n_pieces) part_tile_bases_body(P, pi, threadIdx.x & 63);

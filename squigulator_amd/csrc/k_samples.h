@@ -66,9 +66,9 @@ __device__ static inline void push_fix_one(const SigParams& P, long long at, uin
 // kernel does this itself on the scalar unit).  Collapses the dependent look-ups of the lean kernel's set-up
 // (tile -> read -> tile_so / sig_off / seglen) into one record per item and decides which items the lean
 // kernel takes; the others are queued (as 64-event tiles) for k_samples<MODE, GENERIC>.
-__global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_stiles, const int n_reads, long long* __restrict__ host_off) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (host_off && g <= n_reads) host_off[g] = P.sig_off[g];          // (the scan writes the host's copy of the offsets itself)
+// (also run as extra workgroups of k_part_hist: block = index among the items' workgroups)
+__device__ static inline void items_body(const SigParams& P, const int block, const int n_stiles) {
+    const int g = block * 256 + threadIdx.x;
     if (g >= n_stiles) return;
     const int r = P.stile_read[g];
     const ReadDesc rd = P.reads[r];
@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_st
     d.slot_first = P.one ? rd.slot0 + lt * LEAN_EV : P.evrec32 ? (rd.slot0 >= 0 ? rd.slot0 : P.tile_link[rd.tile_off + lt * LEAN_EPL]) : 0;
     P.items[g] = d;
 }
+__global__ __launch_bounds__(256) void k_items(const SigParams P, const int n_stiles) { items_body(P, (int)blockIdx.x, n_stiles); }
 
 // load through the constant address space: for a wave-uniform address this is a scalar load (the arrays read this way
 // were written by earlier kernels of the stream)
