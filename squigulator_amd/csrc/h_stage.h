@@ -63,7 +63,11 @@ static int grow_slot(sqg_ctx* c, sqg_ctx::Slot& Z, const sqg_batch* b, bool with
         if ((rc2 = ensure(c, (void**)&Z.d_lbase, &Z.lbase_cap, (size_t)b->n_chains * PART_MAX, sizeof(uint32_t)))) return rc2;
         if ((rc2 = ensure(c, (void**)&Z.d_tile_link, &Z.tile_link_cap, (size_t)b->n_tiles + 64, sizeof(int)))) return rc2;
     }
+#if defined(SQG_ABL_HANDOVER)
+    if (b->part && (rc2 = ensure(c, (void**)&Z.d_part_state, &Z.part_state_cap, (size_t)4 * ((size_t)b->n_events + PART_SLACK), sizeof(uint32_t)))) return rc2;
+#else
     if (b->part && (rc2 = ensure(c, (void**)&Z.d_part_state, &Z.part_state_cap, (size_t)b->n_events + PART_SLACK, sizeof(uint32_t)))) return rc2;
+#endif
     if ((rc2 = ensure(c, (void**)&Z.d_slow, &Z.slow_cap, (size_t)b->n_tiles + 64, sizeof(int)))) return rc2;
     if (certified && c->use_kmer_streams) {
         if ((rc2 = ensure(c, (void**)&Z.d_items, &Z.items_cap, (size_t)b->n_stiles + 64, sizeof(ItemDesc)))) return rc2;

@@ -617,6 +617,10 @@ __device__ static __forceinline__ void hand_slice(HandLds& H, const uint32_t* __
         }
 #if HAND_ABL == 2      /* timing-only ablation: no stores */
         if (out[0] == 0x12345u) out_p[0] = out[1] ^ out[NR - 1];
+#elif defined(SQG_ABL_HANDOVER)   /* timing-only ablation (round 5, results wrong): 16 B per slot -- the state with the stream's pore-table row -- as the
+                                     hand-over of round 4's review would write them (the row itself is NOT looked up: what is priced is the traffic) */
+#pragma unroll
+        for (int r = 0; r < NR; r++) if (FULL || (uint32_t)(64 * r + lane) < left) reinterpret_cast<uint4*>(state_out)[(size_t)(out_p - state_out) + 64 * r] = make_uint4(out[r], cur[r], n[r], out[r] ^ cur[r]);
 #else
 #pragma unroll
         for (int r = 0; r < NR; r++) if (FULL || (uint32_t)(64 * r + lane) < left) out_p[64 * r] = out[r];

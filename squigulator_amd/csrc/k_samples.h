@@ -314,6 +314,24 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
 #pragma unroll
             for (int q = 0; q < LEAN_EPL; q++) if (e0 + q < ne) er[q].x = (stv[q] + er[q].x) | 1u;
         }
+#elif defined(SQG_ABL_HANDOVER)  /* timing-only ablation (round 5, results wrong): ONE 16-B gather per event -- state and pore-table row handed over by the
+                                    hand-out kernel -- instead of the row's look-up and the 4-B state gather */
+        if (P.part_state && !P.one) {
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) {
+                uint4 sv = make_uint4(1u, 0u, 0u, 0u);
+                if (e0 + q < ne) sv = reinterpret_cast<const uint4*>(P.part_state)[er[q].x];
+                er[q].x = sv.x;
+                md[q] = (e0 + q < ne) ? make_float2(90.0f + (float)(sv.y & 31u), 1.5f + 0.125f * (float)(sv.z & 7u)) : make_float2(0.f, 0.f);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) md[q] = (e0 + q < ne) ? P.model[er[q].y] : make_float2(0.f, 0.f);
+            if (P.part_state) {
+#pragma unroll
+                for (int q = 0; q < LEAN_EPL; q++) if (e0 + q < ne) er[q].x = P.part_state[er[q].x];
+            }
+        }
 #else
 #pragma unroll
         for (int q = 0; q < LEAN_EPL; q++) md[q] = (e0 + q < ne) ? P.model[er[q].y] : make_float2(0.f, 0.f);
