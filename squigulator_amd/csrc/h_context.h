@@ -36,6 +36,21 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->fix_stream) (void)hipStreamSynchronize(ctx->fix_stream);
+#if defined(SQG_LEAN_TRACE)
+    {   // (timing-only build) where an item of k_samples_lean spends its time: k_samples.h
+        std::vector<unsigned long long> all((size_t)LEAN_TRACE_SHARDS * 16, 0ull);
+        unsigned long long t[16] = {0};
+        if (hipMemcpyFromSymbol(all.data(), HIP_SYMBOL(g_lean_trace), all.size() * sizeof(unsigned long long)) == hipSuccess)
+            for (size_t i = 0; i < all.size(); i++) t[i & 15] += all[i];
+        if (t[0]) {
+            static const char* nm[] = {"drain of the previous item's stores", "first-level loads", "second-level gathers", "tables", "sample loop", "item end", "between items", "workgroup prologue"};
+            fprintf(stderr, "[sqg] lean trace (build %d): %llu items, %.1f steps per item; shader-clock ticks per item:", (int)SQG_LEAN_TRACE, t[0], (double)t[1] / (double)t[0]);
+            double tot = 0; for (int i = 2; i <= 9; i++) tot += (double)t[i] / (double)t[0];
+            for (int i = 2; i <= 9; i++) fprintf(stderr, " %s %.0f (%.1f %%);", nm[i - 2], (double)t[i] / (double)t[0], 100.0 * (double)t[i] / (double)t[0] / tot);
+            fprintf(stderr, " total %.0f; loop ticks per step %.1f\n", tot, (double)t[6] / (double)t[1]);
+        }
+    }
+#endif
     delete ctx->draw_ahead; ctx->draw_ahead = nullptr;
     (void)hipFree(ctx->d_pcnt[0]); (void)hipFree(ctx->d_pcnt[1]); (void)hipFree(ctx->d_slice); (void)hipFree(ctx->d_phist);
     (void)hipFree(ctx->d_rows); (void)hipFree(ctx->d_link_rows); (void)hipFree(ctx->d_scan_part); (void)hipFree(ctx->d_xcounts); (void)hipFree(ctx->d_model); (void)hipFree(ctx->d_samp_scratch); (void)hipFree(ctx->d_pow); (void)hipFree(ctx->d_err); (void)hipFree(ctx->d_mid_done); (void)hipFree(ctx->d_zero); if (ctx->h_samp) (void)hipHostFree(ctx->h_samp);

@@ -9,6 +9,11 @@
 #define SQG_LEAN_ITEMS4 1                  // k_items prepares the descriptors of 256-event items as well: one scalar look-up per item instead of a dependent chain of three
                                            // (round 4, A/B in one call: k_samples_lean 2.43-2.46 -> 2.38-2.39 ms, step -0.08 ms with k_items' own 15 us included; 0: the chain)
 #endif
+#ifndef SQG_LEAN_NOBAR
+#define SQG_LEAN_NOBAR 0                   // A/B (round 5): 1 -- the jump table reaches LDS without a workgroup barrier.  The prologue shrinks from 5600 to 3400
+                                           // cycles per wavefront, more wavefronts of a SIMD are in their sample loops at once, a step of the loop
+                                           // takes 543 instead of 490 cycles -- the loop is bound by VALU issue -- and the kernel 2.47 instead of 2.43 ms
+#endif
 #ifndef SQG_LEAN_NT
 #define SQG_LEAN_NT 0                      // A/B: non-temporal sample stores
 #endif
@@ -126,6 +131,26 @@ __device__ static inline T sload(const T* p) {
     return v;
 }
 
+// (timing-only build, -DSQG_LEAN_TRACE=1) where an item's time goes inside k_samples_lean: shader-clock stamps per wavefront at the
+// item's phases, summed per phase into a device array the context prints when it is destroyed (tools/runs/r5k.sh):
+//   [0] items  [1] steps  [2] draining the previous item's stores  [3] first-level loads (event records, dwells, partition bases)
+//   [4] second-level gathers (pore-table rows, stream states)  [5] tables (FP64 per-event constants, start map)  [6] the sample loop
+//   [7] the item's end (parked samples)  [8] between items (the descriptor's scalar loads)  [9] the workgroup's prologue (jump table -> LDS, barrier)
+#if defined(SQG_LEAN_TRACE)
+#define LEAN_TRACE_SHARDS 4096
+__device__ unsigned long long g_lean_trace[LEAN_TRACE_SHARDS * 16];      // (a row of 16 words per shard, 128 B: atomics on ONE line serialise the kernel)
+#define LEAN_T(var_) const unsigned long long var_ = __builtin_amdgcn_s_memtime()
+#define LEAN_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#if SQG_LEAN_TRACE == 1
+#define LEAN_DRAIN0() LEAN_DRAIN()                                    /* 1: the stores are drained BEFORE the item's first loads are issued (what they cost alone) */
+#else
+#define LEAN_DRAIN0()                                                 /* 2: as in production, the first wait for a load is what waits for them */
+#endif
+#else
+#define LEAN_T(var_)
+#define LEAN_DRAIN()
+#define LEAN_DRAIN0()
+#endif
 template <int EPL>
 struct LeanWaveLds {
     uint4 rec[64 * EPL];                // {c_ev, (4*first sample) << 16 | I (16 bits), F - 1/2, sdk}
@@ -159,11 +184,23 @@ struct LeanLds {
 // pipeline registers alternate instead of being copied, and the position registers advance once per four steps).
 template <bool RNA, int LEAN_EPL>
 __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const int n_stiles) {
+    LEAN_T(tr_k0);
     __shared__ LeanLds<LEAN_EPL> L;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if SQG_LEAN_NOBAR
+    // The jump table (2 KiB, doubled: lcg_mul_dbl) without a workgroup barrier (round 5): EVERY wavefront requests the whole table here, in
+    // front of its item's own loads, and writes it to LDS once those have come back (a wavefront's loads return in order) -- the four copies
+    // are the same bytes at the same addresses, and a wavefront's own LDS writes are visible to it in program order.  The load + barrier
+    // in front of everything is 12 % of a wavefront's life (profiles/r05_lean_trace.md): 5600 cycles before its item's first load is issued.
+    uint32_t mt_[MULT_N / 64];
+#pragma unroll
+    for (int q = 0; q < MULT_N / 64; q++) mt_[q] = P.pw[64 * q + lane];
+    bool mult_filled = false;
+#else
     for (int i = tid; i < MULT_N; i += 256) L.mult[i] = P.pw[i] << 1;        // doubled: lcg_mul_dbl
     __syncthreads();
+#endif
     LeanWaveLds<LEAN_EPL>& W = L.w[wid];
     const float thr = P.thr_all;
     const char* mult_b = reinterpret_cast<const char*>(L.mult);
@@ -177,6 +214,9 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         const unsigned q = gridDim.x >> 3, rem = gridDim.x & 7u, x = blockIdx.x & 7u;
         wg0 = x * q + min(x, rem) + (blockIdx.x >> 3);
     }
+#endif
+#if defined(SQG_LEAN_TRACE)
+    unsigned long long tr_prev = 0;
 #endif
     for (int g = (int)wg0 * 4 + wid; g < n_stiles; g += gridDim.x * 4) {
         // the item's descriptor -- what the read, its 64-event tiles and the scanned read offsets say about this item -- is
@@ -230,6 +270,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         const int ne = it.n_ev;                                         // events of this item
         if (ne == 0) continue;                                         // not taken, or empty
         const int wave_total = it.n_samples;
+        LEAN_T(tr_a); LEAN_DRAIN0(); LEAN_T(tr_b);                     // (trace build 1: the previous item's stores have retired)
         const int e0 = lane * LEAN_EPL;                                // my first event (within the item)
         const long long gev = it.ev_first + e0;
         // ---- set-up: LEAN_EPL consecutive events per lane ----
@@ -303,6 +344,14 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
                 sps[q] = v ? (P.dwell ? (int)P.dwell[gev + q] : P.const_sps) : 0;
             }
         }
+        LEAN_DRAIN(); LEAN_T(tr_c);
+#if SQG_LEAN_NOBAR
+        if (!mult_filled) {                                            // (wave-uniform; the first-level loads above were requested behind the table's)
+#pragma unroll
+            for (int q = 0; q < MULT_N / 64; q++) L.mult[64 * q + lane] = mt_[q] << 1;
+            mult_filled = true;
+        }
+#endif
         float2 md[LEAN_EPL];
 #if defined(SQG_ABL_NODEP)       /* timing-only ablation (results are wrong): the set-up's second-level look-ups do not depend on the first */
 #pragma unroll
@@ -340,6 +389,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
             for (int q = 0; q < LEAN_EPL; q++) if (e0 + q < ne) er[q].x = P.part_state[er[q].x];
         }
 #endif
+        LEAN_DRAIN(); LEAN_T(tr_d);
         int lane_total = 0;
 #pragma unroll
         for (int q = 0; q < LEAN_EPL; q++) lane_total += sps[q];
@@ -446,6 +496,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
 #else
         #define LEAN_ARITH(RA, MU) const uint32_t c1 = lcg_mul_dbl(RA.x, MU); const float x = box_muller_fast(c1);
 #endif
+        LEAN_T(tr_e);
         uint4 ra, rb, tqa, tqb; uint32_t ma, mb; int eva, evb;
         const uint4* tbp = W.tb;                                        // table entry of the current pair's first step
         {
@@ -485,6 +536,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         #undef LEAN_STORE_VAL
         #undef LEAN_NEARONE_TEST
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        LEAN_T(tr_f);
         // the item's parked samples (every other item has one: 4.5e-4 of the samples) join one of the batch's FIX_SHARDS lists for k_fixup: ONE returning
         // atomic per such item, at its end (per-item lists walked by a kernel of their own cost that kernel 0.28 ms and 0.4 GB per
         // batch of scattered look-ups next to the following batch's event pass; ONE list, 9e4 atomics on one address, 3.4 ms)
@@ -509,6 +561,19 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
                 dst[lane] = fe;
             }
         }
+#if defined(SQG_LEAN_TRACE)
+        {
+            LEAN_T(tr_g);
+            if (lane == 0) {
+                unsigned long long* const T = g_lean_trace + (size_t)((blockIdx.x * 4 + wid) & (LEAN_TRACE_SHARDS - 1)) * 16;
+                atomicAdd(&T[0], 1ull); atomicAdd(&T[1], (unsigned long long)((wave_total + 63) >> 6));
+                atomicAdd(&T[2], tr_b - tr_a); atomicAdd(&T[3], tr_c - tr_b); atomicAdd(&T[4], tr_d - tr_c);
+                atomicAdd(&T[5], tr_e - tr_d); atomicAdd(&T[6], tr_f - tr_e); atomicAdd(&T[7], tr_g - tr_f);
+                if (tr_prev) atomicAdd(&T[8], tr_a - tr_prev); else atomicAdd(&T[9], tr_a - tr_k0);
+            }
+            tr_prev = tr_g;
+        }
+#endif
     }
 }
 
