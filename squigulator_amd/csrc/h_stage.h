@@ -414,7 +414,7 @@ struct Staging {
         // few workers: what the context's draw-ahead thread has ready (h_common.h, DrawAhead) comes first -- a prefix of every worker chain
         std::vector<long long> pre_off((size_t)n_wchains, 0), pre_med((size_t)n_wchains, 0);   // ... and the streams' states behind them
         int n_pre = 0;
-        const bool ahead = !ideal && c->nw <= 4 && n > 0 && usable_cpus() >= 2 && !SQG_DEV_ENV("SQG_NO_DRAW_AHEAD");
+        const bool ahead = !ideal && c->nw <= 16 && n > 0 && usable_cpus() >= 2 && !SQG_DEV_ENV("SQG_NO_DRAW_AHEAD");
         if (ahead) {
             if (!c->draw_ahead) c->draw_ahead = new DrawAhead(c->nw, p);
             off_d.resize((size_t)n); med_d.resize((size_t)n);
