@@ -885,39 +885,36 @@ def main():
                      "ms_per_step": te / nb_e * 1e3,
                      "what": "a leg of its own behind the timed region: every batch carries the phase events (barrier packets: ~1 % of a step)"}
 
-    # the reference's default batch size, streaming (src/sim.c:208-209: -t 8 -K 1000): nothing staged ahead
+    # the reference's default batch size, streaming (src/sim.c:208-209: -t 8 -K 1000): nothing staged ahead.  The -t 1 leg runs on the bench's
+    # context; the -t 8 leg needs a context of its own and runs LAST, when the bench's context is closed: two live contexts of one process on
+    # one GPU share the hardware queues (seven streams on four queues), and the second one's staging stream then waits behind the first one's
+    # idle queues' turn -- its 1000-read batches staged in 0.51 instead of 0.25 ms (tools/two_ctx_probe.py)
     small = None
-    if args.small_batch_seconds > 0 and world == 1 and not range_mode and not args.digest and W == 1:
+    small_on = args.small_batch_seconds > 0 and world == 1 and not range_mode and not args.digest and W == 1
+
+    def small_leg(g2, t_small):
+        g2.set_phase_timing(0)
+        g2.set_stage_threads(0)                                # (automatic: a 1000-read batch's draws are not worth waking helpers for)
+        wk = (np.arange(1000, dtype=np.int32) // (1000 // t_small)).clip(0, t_small - 1).astype(np.int32)
+        st1 = lambda: g2.sample(1000, wk)
+        warm = st1().run(); warm.wait(); warm.free()
+        sync_all()
+        trial = pipeline_leg(st1, lambda b: b.run(), 64)       # (size the leg from a short trial: ~0.35 ms per batch)
+        n_small = int(min(max(args.small_batch_seconds / max(trial[2] / 65, 1e-6), 64), 40000))
+        sync_all()
+        r = pipeline_leg(st1, lambda b: b.run(), n_small)
+        sync_all()
+        return {"value": r[0] / r[2], "unit": "samples/s", "reads_per_s": r[1] / r[2], "seconds": r[2], "batches": n_small + 1,
+                "ms_per_batch": r[2] / (n_small + 1) * 1e3, "host_stage_ms_per_batch": r[3] * 1e3}
+
+    if small_on:
         free_all()
         small = {"reads_per_batch": 1000, "what": "streaming (one host thread: sample + stage batch i+2, queue batch i+1, wait for and free batch i), "
-                 "the reference's default -K 1000 (src/sim.c:208-209); -t 8: the static partition of a batch over eight virtual workers"}
-        for t_small in (1, 8):
-            g2 = gen
-            if t_small != T:
-                if genome_dev is None:
-                    continue
-                g2 = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=t_small, device=local_rank, mode=amode)
-                g2.load_genome_device(genome_dev[0].data_ptr(), genome_dev[1], args.rlen, sm)
-            g2.set_phase_timing(0)
-            g2.set_stage_threads(0)                                # (automatic: a 1000-read batch's draws are not worth waking helpers for)
-            wk = (np.arange(1000, dtype=np.int32) // (1000 // t_small)).clip(0, t_small - 1).astype(np.int32)
-            st1 = lambda g2=g2, wk=wk: g2.sample(1000, wk)
-            warm = st1().run(); warm.wait(); ns0 = warm.n_samples; warm.free()
-            sync_all()
-            # (size the leg from a short trial: ~0.35 ms per batch)
-            trial = pipeline_leg(st1, lambda b: b.run(), 64)
-            n_small = int(min(max(args.small_batch_seconds / max(trial[2] / 65, 1e-6), 64), 40000))
-            sync_all()
-            r = pipeline_leg(st1, lambda b: b.run(), n_small)
-            sync_all()
-            small[f"-t {t_small} -K 1000"] = {"value": r[0] / r[2], "unit": "samples/s", "reads_per_s": r[1] / r[2], "seconds": r[2], "batches": n_small + 1,
-                                             "ms_per_batch": r[2] / (n_small + 1) * 1e3, "host_stage_ms_per_batch": r[3] * 1e3}
-            if g2 is not gen:
-                g2.close()
-        gen.set_phase_timing(timing_every)
-        gen.set_stage_threads(stage_threads)
-    genome_dev = None
-    torch.cuda.empty_cache()
+                 "the reference's default -K 1000 (src/sim.c:208-209); -t 8: the static partition of a batch over eight virtual workers, a context of its own"}
+        if T == 1:
+            small["-t 1 -K 1000"] = small_leg(gen, 1)
+            gen.set_phase_timing(timing_every)
+            gen.set_stage_threads(stage_threads)
 
     # the streaming leg: the same job with nothing staged ahead (the sampler's and the staging kernels share the GPU with the generator)
     pipe = None
@@ -942,6 +939,20 @@ def main():
         wf = workers[:Kf] if not W else np.minimum(w_lo + np.arange(Kf, dtype=np.int32) // max(Kf // W, 1), w_hi - 1).astype(np.int32)
         e2e.update({k2: v for k2, v in e2e_legs(gen, prof, flags, lambda: gen.sample(Kf, wf), Kf, args.e2e_seconds, kinds=("blow5_fast",)).items() if k2 == "blow5_fast"})
         sync_all()
+
+    store_peak_GBps = None
+    if rank == 0 and not args.no_store_probe:
+        store_peak_GBps = gen.probe_store_bandwidth(1 << 30, 10) / 1e9
+    if small_on and genome_dev is not None:
+        free_all()
+        gen.close()
+        gen = None
+        g8 = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=8, device=local_rank, mode=amode)
+        g8.load_genome_device(genome_dev[0].data_ptr(), genome_dev[1], args.rlen, sm)
+        small["-t 8 -K 1000"] = small_leg(g8, 8)
+        g8.close()
+    genome_dev = None
+    torch.cuda.empty_cache()
 
     ptot = torch.tensor(list(pipe[:3]) if pipe else [0.0, 0.0, 1.0], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
     hst = torch.tensor([pipe[3] if pipe else 0.0, -(pipe[3] if pipe else 0.0)], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
@@ -1039,8 +1050,8 @@ def main():
             # all the HBM traffic of a step (PMC, every kernel of the timed region) over the step's time: how busy the memory is
             out["roofline"]["step_traffic"] = st
             out["roofline"]["step_traffic_frac"] = st / (ms_per_step * 1e-3) / HBM_PEAK_BYTES_PER_S
-        if not args.no_store_probe:
-            out["roofline"]["measured_store_peak_GBps"] = gen.probe_store_bandwidth(1 << 30, 10) / 1e9
+        if store_peak_GBps is not None:
+            out["roofline"]["measured_store_peak_GBps"] = store_peak_GBps
         # what the kernel occupies besides HBM bytes (the profile's counters priced with this run's time); `bound` in `resources` names
         # the largest share -- roofline.bound stays "hbm": that is the roofline this line's frac is quoted against
         out["roofline"]["resources"] = pmc_resources(wkey, k_ms, samples / steps, out["roofline"].get("measured_store_peak_GBps"))
@@ -1068,7 +1079,8 @@ def main():
         print(json.dumps(out))
     for b in batches[:args.warmup] + [b for b in timed if b is not None] + tail:
         b.free()
-    gen.close()
+    if gen is not None:
+        gen.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
