@@ -493,7 +493,8 @@ def e2e_legs(gen, prof, flags, sample_batch, reads_per_batch, seconds, kinds=("p
     `pinned_int16` -- sqg_fetch_signal into sqg_host_alloc memory (raw int16 over PCIe); `pinned_svb` -- sqg_batch_compress (svb-zd on
     the device, the signal field of a BLOW5 record), then batch i+1 queued, then sqg_fetch_svb; `blow5` -- sqg_blow5_write_batch into /dev/shm (record framing +
     zlib on the host's threads: the bytes the reference writes); `blow5_fast` -- the same call on a writer opened with SQG_BLOW5_STORED (records
-    framed on the device in stored-block zlib streams: a valid BLOW5 file with the reference's records, not its bytes).  Never `value`: PCIe and zlib are 20x and 1500x below the kernels."""
+    framed on the device in stored-block zlib streams: a valid BLOW5 file with the reference's records, not its bytes); `blow5_fast_4files` --
+    the same on four files (SQG_BLOW5_SHARDS(4): one file of a tmpfs takes 6.9 GB/s whatever the writers, four take four times that).  Never `value`: PCIe and zlib are 20x and 1500x below the kernels."""
     import torch
     probe = sample_batch().run().wait()
     cap = int(probe.n_samples * 1.4) + 65536
@@ -508,7 +509,8 @@ def e2e_legs(gen, prof, flags, sample_batch, reads_per_batch, seconds, kinds=("p
         path = os.path.join(shm, f"sqg_bench_e2e_{os.getpid()}.blow5")
         # blow5: the reference's bytes (deflate on the host's threads); blow5_fast: SQG_BLOW5_STORED -- the same records in stored-block
         # zlib streams, framed on the device, one PCIe copy and one pwrite() behind the next batch (include/sqg.h)
-        w = api.Blow5Writer(path, prof, flags, threads=0, stored=(kind == "blow5_fast")) if kind.startswith("blow5") else None
+        w = api.Blow5Writer(path, prof, flags, threads=0, stored=kind.startswith("blow5_fast"), shards=4 if kind == "blow5_fast_4files" else 1) if kind.startswith("blow5") else None
+        w_paths = list(w.paths) if w is not None else [path]
         samples = nb = nbytes = 0
 
         def drain(b):
@@ -525,7 +527,7 @@ def e2e_legs(gen, prof, flags, sample_batch, reads_per_batch, seconds, kinds=("p
             t0 = time.perf_counter()
             while True:
                 last = nb >= 1 and time.perf_counter() - t0 >= seconds
-                if kind in ("pinned_svb", "blow5_fast"):       # the encoder first (the context has ONE buffer of encodings: it cannot run ahead),
+                if kind in ("pinned_svb", "blow5_fast", "blow5_fast_4files"):       # the encoder first (the context has ONE buffer of encodings: it cannot run ahead),
                     cur.compress(fetch=False)                  # the next batch's kernels behind it -- they run while the bytes cross PCIe
                 nxt = None if last else sample_batch().run()
                 cur.wait()
@@ -541,10 +543,11 @@ def e2e_legs(gen, prof, flags, sample_batch, reads_per_batch, seconds, kinds=("p
         finally:
             if w is not None:
                 w.close()
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
+            for q in w_paths:
+                try:
+                    os.unlink(q)
+                except OSError:
+                    pass
         out[kind] = {"value": samples / dt, "unit": "samples/s", "seconds": dt, "batches": nb, "bytes_per_sample": nbytes / max(samples, 1),
                      "reads_per_batch": reads_per_batch, "GBps": nbytes / dt / 1e9}
     return out
@@ -937,7 +940,7 @@ def main():
         # system is what bounds it (tools/io_probe.cpp: 6.9 GB/s into ONE file of a tmpfs on the pool's boxes), so per-batch overheads count
         Kf = min(args.e2e_fast_batch_reads, K)
         wf = workers[:Kf] if not W else np.minimum(w_lo + np.arange(Kf, dtype=np.int32) // max(Kf // W, 1), w_hi - 1).astype(np.int32)
-        e2e.update({k2: v for k2, v in e2e_legs(gen, prof, flags, lambda: gen.sample(Kf, wf), Kf, args.e2e_seconds, kinds=("blow5_fast",)).items() if k2 == "blow5_fast"})
+        e2e.update({k2: v for k2, v in e2e_legs(gen, prof, flags, lambda: gen.sample(Kf, wf), Kf, args.e2e_seconds, kinds=("blow5_fast", "blow5_fast_4files")).items() if k2.startswith("blow5_fast")})
         sync_all()
 
     store_peak_GBps = None

@@ -229,7 +229,13 @@ typedef struct sqg_blow5 sqg_blow5_t;
  * (sqg_batch_blow5_records) and the host's part is one PCIe copy and one pwrite(), made behind the caller while the next batch is fetched.  (A deflate block with the fixed Huffman
  * code would be larger, not smaller: svb-zd bytes are nearly uniform, and that code spends 8-9 bits on a literal.) */
 #define SQG_BLOW5_STORED 0x10000u
-int  sqg_blow5_open(const char *path, const sqg_profile_t *profile, uint32_t flags /* SQG_RNA | SQG_R10 | SQG_ONT | SQG_BLOW5_STORED */,
+/* ... on n files instead of one (with SQG_BLOW5_STORED; n <= 255): `path` x.blow5 names x.0.blow5 ... x.<n-1>.blow5, each a BLOW5 file of its own
+ * (header, records, end marker); every batch's reads are dealt out to them in n contiguous ranges, read_number and start_time stay the
+ * job's.  What bounds the stored mode is the file: one file of a tmpfs takes 6.9 GB/s from any number of writers, n files n times that
+ * (tools/io_probe.cpp) -- the way a run that writes many BLOW5 files (as the sequencers do) scales its sink.  sqg_blow5_close reports the
+ * files' sizes added up. */
+#define SQG_BLOW5_SHARDS(n) (((uint32_t)(n) & 0xffu) << 24)
+int  sqg_blow5_open(const char *path, const sqg_profile_t *profile, uint32_t flags /* SQG_RNA | SQG_R10 | SQG_ONT | SQG_BLOW5_STORED | SQG_BLOW5_SHARDS(n) */,
                     int32_t threads, sqg_blow5_t **out);
 /* The batch's records as SQG_BLOW5_STORED writes them, framed on the device around its svb-zd encodings (compressing the batch first
  * if need be) and copied to pinned host memory of the context: *records (valid until the next-but-one call on this context), *n_bytes, and --

@@ -260,13 +260,15 @@ class Blow5Writer:
     """The library's native BLOW5 writer (sqg_blow5_*): header, record framing and zlib on host threads; the signal field is
     the svb-zd encoding made on the device.  Pure host code: write() works without a GPU."""
 
-    def __init__(self, path: str, profile: P.Profile, flags: int, threads: int = 0, lib_path: str | None = None, stored: bool = False):
-        """stored: SQG_BLOW5_STORED -- the records in zlib streams of stored blocks, framed on the device by write_batch (include/sqg.h)"""
+    def __init__(self, path: str, profile: P.Profile, flags: int, threads: int = 0, lib_path: str | None = None, stored: bool = False, shards: int = 1):
+        """stored: SQG_BLOW5_STORED -- the records in zlib streams of stored blocks, framed on the device by write_batch (include/sqg.h);
+        shards > 1: SQG_BLOW5_SHARDS -- that many files (self.paths), each with a contiguous range of every batch's reads"""
         self.L = load_library(lib_path)
         self.h = C.c_void_p()
         cp = CProfile(*profile.as_tuple())
-        rc = self.L.sqg_blow5_open(os.fsencode(path), C.byref(cp), (flags & (P.SQ_RNA | P.SQ_R10 | P.SQ_ONT)) | (BLOW5_STORED if stored else 0),
-                                   threads, C.byref(self.h))
+        self.paths = [path] if shards <= 1 else [(path[:-6] + f".{i}.blow5") if path.endswith(".blow5") else f"{path}.{i}" for i in range(shards)]
+        rc = self.L.sqg_blow5_open(os.fsencode(path), C.byref(cp), (flags & (P.SQ_RNA | P.SQ_R10 | P.SQ_ONT)) | (BLOW5_STORED if stored else 0)
+                                   | ((shards & 0xff) << 24 if shards > 1 else 0), threads, C.byref(self.h))
         if rc != 0:
             raise SqgError(rc, "sqg_blow5_open", path)
 

@@ -308,3 +308,83 @@ def test_device_framing_of_a_bench_sized_batch(tmp_path):
             f = lines[i].split("\t")
             assert f[-1] == "fnv1a:%016x" % h and int(f[6]) == b.sig_off[i + 1] - b.sig_off[i] and int(f[9]) == i
     b.free(); gen.close()
+
+
+# ---- SQG_BLOW5_SHARDS: the stored-block records on several files --------------------------------------------------------------------
+def _records_of(paths):
+    """header of the first file, and every file's uncompressed records, all files' in read_number order"""
+    hdrs, recs = [], []
+    for pth in paths:
+        buf = open(pth, "rb").read()
+        _stored_records_are_valid(buf)
+        h, r = parse_blow5(buf)
+        hdrs.append(h); recs += r
+
+    def read_number(rec):
+        (idl,) = struct.unpack_from("<H", rec, 0)
+        q = 2 + idl + 4 + 32
+        (nb,) = struct.unpack_from("<Q", rec, q)
+        return struct.unpack_from("<i", rec, q + 8 + nb + 9 + 8)[0]
+    assert all(h == hdrs[0] for h in hdrs)
+    return hdrs[0], sorted(recs, key=read_number)
+
+
+@pytest.mark.parametrize("cid", ["r9_t1", "r9_two_batches", "r9_ont"])
+@pytest.mark.parametrize("shards", [2, 3])
+def test_sharded_files_hold_the_reference_records(cid, shards, tmp_path):
+    """SQG_BLOW5_SHARDS(n): n valid BLOW5 files whose records, put together in read_number order, are the reference file's; the
+    reference's slow5lib reads every one of them"""
+    o, ids, offset, median, so, sig = _case(cid)
+    gold = os.path.join(GOLD, cid + ".blow5")
+    encs = [orc.svb_zd(sig[so[i]:so[i + 1]]) for i in range(len(ids))]
+    w = api.Blow5Writer(str(tmp_path / "s.blow5"), o.profile, o.flags, threads=2, stored=True, shards=shards)
+    assert [os.path.basename(q) for q in w.paths] == ["s.%d.blow5" % i for i in range(shards)]
+    done = 0
+    while done < len(ids):
+        nb = min(o.batch, len(ids) - done)
+        e = encs[done:done + nb]
+        eo = np.concatenate(([0], np.cumsum([len(x) for x in e]))).astype(np.int64)
+        w.write(ids[done:done + nb], offset[done:done + nb], median[done:done + nb], so[done:done + nb + 1] - so[done], np.concatenate(e), eo)
+        done += nb
+    n = w.close()
+    assert n == sum(os.path.getsize(q) for q in w.paths)
+    hdr, recs = _records_of(w.paths)
+    hdr_w, rec_w = parse_blow5(open(gold, "rb").read())
+    assert hdr == hdr_w and recs == rec_w
+    if os.path.exists(DUMP):
+        lines = []
+        for q in w.paths:
+            d = ref_dump(q).splitlines()
+            lines += [ln for ln in d if not ln.startswith(("@", "num_read_groups", "records"))]
+        want = [ln for ln in ref_dump(gold).splitlines() if not ln.startswith(("@", "num_read_groups", "records"))]
+        assert sorted(lines, key=lambda ln: int(ln.split("\t")[9])) == want
+    with pytest.raises(api.SqgError):
+        api.Blow5Writer(str(tmp_path / "z.blow5"), o.profile, o.flags, shards=2)           # several files: the stored-block mode only
+
+
+@pytest.mark.gpu
+def test_device_framed_records_on_four_files(tmp_path):
+    """write_batch with SQG_BLOW5_SHARDS(4): the device's records dealt out to four files, written side by side behind the caller, three
+    batches; together they are the one-file writer's records"""
+    import bench
+    prof, fl = profiles.get_profile("dna-r10-prom")
+    mean, stdv = model.synthetic_model(9)
+    gen = api.SignalGenerator(prof, fl, 9, mean, stdv, 42, num_workers=1, mode=api.MODE_CERTIFIED)
+    gen.load_genome(bench.synthetic_genome_host(8.0), 10000, api.SAMPLE_DNA)
+    w4 = api.Blow5Writer(str(tmp_path / "q.blow5"), prof, fl, stored=True, shards=4)
+    w1 = api.Blow5Writer(str(tmp_path / "one.blow5"), prof, fl, stored=True)
+    nread = 0
+    for n in (301, 64, 3):
+        b = gen.sample(n).run().wait()
+        ids = [b"S1_%d!c!0!1!+" % (nread + i + 1) for i in range(n)]
+        w4.write_batch(b, ids); w1.write_batch(b, ids)
+        nread += n
+        b.free()
+    n4, n1 = w4.close(), w1.close()
+    gen.close()
+    hdr4, rec4 = _records_of(w4.paths)
+    hdr1, rec1 = _records_of(w1.paths)
+    assert hdr4 == hdr1 and rec4 == rec1 and len(rec1) == nread
+    assert n4 == n1 + 3 * (68 + len(hdr1) + 5)                      # (three more headers and end markers)
+    d = [ref_dump(q, "hash") for q in w4.paths]
+    assert d[0] is None or sum(int(x.strip().splitlines()[-1].split("\t")[1]) for x in d) == nread

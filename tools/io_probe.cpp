@@ -13,6 +13,19 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 int main(int argc, char** argv) {
     const size_t n = (size_t)350 << 20; const int nth = argc > 1 ? atoi(argv[1]) : 16; const int reps = 8;
     std::vector<char> buf(n, 1);
+    for (int nf : {2, 4, 8}) {                                       // one pwrite stream per FILE, nf files side by side
+        std::vector<int> fds;
+        for (int f = 0; f < nf; f++) { char pth[64]; snprintf(pth, sizeof pth, "/dev/shm/wtest.%d.bin", f); unlink(pth); fds.push_back(open(pth, O_RDWR | O_CREAT | O_TRUNC, 0644)); }
+        double t0 = now();
+        for (int r = 0; r < reps; r++) {
+            std::vector<std::thread> th;
+            for (int f = 0; f < nf; f++) th.emplace_back([&, f, r] { size_t lo = n * f / nf, hi = n * (f + 1) / nf; off_t at = (off_t)r * (hi - lo) + 100; while (lo < hi) { ssize_t k = pwrite(fds[f], buf.data() + lo, hi - lo, at); lo += k; at += k; } });
+            for (auto& t : th) t.join();
+        }
+        double dt = now() - t0;
+        printf("%d files, one pwrite stream each: %.2f GB/s\n", nf, reps * n / dt / 1e9);
+        for (int f = 0; f < nf; f++) { close(fds[f]); char pth[64]; snprintf(pth, sizeof pth, "/dev/shm/wtest.%d.bin", f); unlink(pth); }
+    }
     for (int mode = 0; mode < 4; mode++) {
         const char* path = "/dev/shm/wtest.bin"; unlink(path);
         int fd = open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
