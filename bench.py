@@ -31,6 +31,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import shutil
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (multi-process GPU work on these hosts: dmabuf IPC only; must be set before HIP starts)
 import socket
@@ -348,7 +349,7 @@ def pin_to_gpu_numa_node(device_index, local_rank, local_world):
         return {"pinned": False, "why": f"{type(e).__name__}: {e}"}
 
 
-def cpu_reference(prof, flags, k, mean, stdv, fasta_path, rlen, seconds=10.0):
+def cpu_reference(prof, flags, k, mean, stdv, fasta_path, rlen, seconds=10.0, full_fasta=None):
     """The REFERENCE's own gensig.c/genread.c (oracle/_ref/ref_harness, compiled in the build container from the upstream
     sources where they lie), timed mode: every process loads the model and the FASTA, seeds its streams, then generates
     reads for `seconds` of wall time and reports the samples and the time of that read loop alone.
@@ -364,10 +365,10 @@ def cpu_reference(prof, flags, k, mean, stdv, fasta_path, rlen, seconds=10.0):
         mpath = os.path.join(tmp, "m.model")
         model.write_f5c_model(mpath, k, mean, stdv)
 
-        def leg(nproc, secs, blow5):
+        def leg(nproc, secs, blow5, fasta=None):
             cfgs = []
             for i in range(nproc):
-                cfg = {"fasta": fasta_path, "model": mpath, "flags": flags & ~profiles.SQ_ORDER_FREE, "amp_noise": 1.0, "seed": 1000 + 7919 * i,
+                cfg = {"fasta": fasta or fasta_path, "model": mpath, "flags": flags & ~profiles.SQ_ORDER_FREE, "amp_noise": 1.0, "seed": 1000 + 7919 * i,
                        "threads": 1, "batch": 1000, "nreads": 1, "rlen": rlen, "time_s": secs}
                 if blow5:
                     cfg["slow5"] = os.path.join(tmp, f"o{i}.blow5")
@@ -397,16 +398,20 @@ def cpu_reference(prof, flags, k, mean, stdv, fasta_path, rlen, seconds=10.0):
         one = leg(1, min(seconds, 5.0), False)
         allc = leg(cores, seconds, False)
         e2e = leg(cores, seconds, True)
+        # ... and ONE process on the headline genome itself (3.09 Gb: the sampler's look-ups leave the caches; the per-sample work is the same)
+        full = leg(1, min(seconds, 5.0), False, fasta=full_fasta) if full_fasta else None
     if not one or not allc:
         return None
     return {"value": allc[0], "unit": "samples/s", "cores": cores, "kind": "reference",
             "per_core": allc[0] / cores, "t1": one[0], "reads_per_s": allc[1],
-            "to_blow5": (e2e[0] if e2e else None), "cpu": cpu, "physical_cores": phys_cores, "hw_threads": threads,
+            "to_blow5": (e2e[0] if e2e else None), "t1_full_genome": (full[0] if full else None),
+            "full_genome_bases": (os.path.getsize(full_fasta) if full_fasta else None), "cpu": cpu, "physical_cores": phys_cores, "hw_threads": threads,
             "affinity_cpus": aff, "cgroup_cpu_quota": quota,
             "sample": f"reference gensig.c/genread.c (oracle/_ref/ref_harness, gcc -O2 -std=c99 as the reference's Makefile), synthetic "
                       f"pore table, same profile and -r on a {os.path.getsize(fasta_path) / 1e6:.0f} MB genome of the same layout; `value`: "
                       f"{cores} x `-t 1` processes (one per core this container may use), {allc[2]:.1f} s of read loop each, generation only (no "
-                      f"output); `t1`: one process alone; `to_blow5`: the same {cores} processes writing BLOW5 (zlib+svb-zd) through slow5lib"}
+                      f"output); `t1`: one process alone; `to_blow5`: the same {cores} processes writing BLOW5 (zlib+svb-zd) through slow5lib; `t1_full_genome`: one process "
+                      f"alone on the timed run's own genome (the same bytes, copied from HBM to a FASTA in /dev/shm)"}
 
 
 def cpu_port(prof, flags, k, mean, stdv, batches, T, nthreads):
@@ -732,7 +737,7 @@ def main():
         torch.cuda.synchronize()
         gen.load_genome_device(seq.data_ptr(), lens, args.rlen, sm)
         genome_bases = int(sum(lens))
-        genome_dev = (seq, lens) if (args.small_batch_seconds > 0 and world == 1 and not args.digest) else None   # (the -t 8 leg's context loads it again)
+        genome_dev = (seq, lens) if ((args.small_batch_seconds > 0 or not args.no_cpu_baseline) and world == 1 and not args.digest) else None   # (the -t 8 leg's context loads it again)
         del seq
         torch.cuda.empty_cache()
     else:
@@ -943,6 +948,9 @@ def main():
         e2e.update({k2: v for k2, v in e2e_legs(gen, prof, flags, lambda: gen.sample(Kf, wf), Kf, args.e2e_seconds, kinds=("blow5_fast", "blow5_fast_4files")).items() if k2.startswith("blow5_fast")})
         sync_all()
 
+    genome_host = None
+    if genome_dev is not None and rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "hg38-r10":
+        genome_host = (genome_dev[0].cpu().numpy(), list(genome_dev[1]))     # (for cpu_baseline.t1_full_genome: the reference on the very genome)
     store_peak_GBps = None
     if rank == 0 and not args.no_store_probe:
         store_peak_GBps = gen.probe_store_bandwidth(1 << 30, 10) / 1e9
@@ -1076,7 +1084,15 @@ def main():
                     with open(fa, "wb") as f:
                         for i, c in enumerate(host_contigs):
                             f.write(b">c%d\n" % i + c + b"\n")
-                    ref = cpu_reference(prof, flags, k, mean, stdv, fa, args.rlen, seconds=args.cpu_seconds)
+                    fa_full = None
+                    if genome_host is not None and shutil.disk_usage(tmp).free > 2 * genome_host[0].size:
+                        fa_full = os.path.join(tmp, "full.fa")
+                        with open(fa_full, "wb") as f:
+                            at = 0
+                            for i, n_c in enumerate(genome_host[1]):
+                                f.write(b">c%d\n" % i); f.write(memoryview(genome_host[0][at:at + n_c])); f.write(b"\n")
+                                at += n_c
+                    ref = cpu_reference(prof, flags, k, mean, stdv, fa, args.rlen, seconds=args.cpu_seconds, full_fasta=fa_full)
             out["cpu_baseline"] = ref or {"value": port_rate, "unit": "samples/s", "cores": 1 if one_worker else min(os.cpu_count() or 1, 64),
                                           "kind": "port", "sample": f"oracle restatement on the {n_chk} reads of parity_check"}
         print(json.dumps(out))
