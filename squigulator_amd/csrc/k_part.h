@@ -157,6 +157,26 @@ __global__ __launch_bounds__(256) void k_part_slice_bounds(const uint32_t* __res
 #ifndef PART_HIST_V4
 #define PART_HIST_V4 1
 #endif
+#ifndef PART_NT
+#define PART_NT 0                // A/B (round 5): part[] read with non-temporal loads in k_part_hist / the hand-out (each record is read once per kernel)
+#endif
+typedef uint32_t part_u32x4 __attribute__((ext_vector_type(4)));
+__device__ static inline uint32_t part_ld(const uint32_t* p) {
+#if PART_NT
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ static inline uint4 part_ld(const uint4* p) {
+#if PART_NT
+    const part_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const part_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+#define PART_LD(p_) part_ld(p_)
 // Workgroups from `first_items` on (round 5) prepare the lean sample kernel's work items instead (items_body, k_samples.h: they need the
 // scan's offsets and the scatter pass' tile links, both complete before this launch, and nothing of this kernel): k_items as a launch of
 // its own was 15 us of work behind a launch gap.
@@ -178,10 +198,10 @@ __global__ __launch_bounds__(256) void k_part_hist(const uint32_t* __restrict__ 
     const uint4* in = reinterpret_cast<const uint4*>(part + lo4) + tid;
     uint4 rec[2], nxt[2];
 #pragma unroll
-    for (int q = 0; q < 2; q++) rec[q] = in[256 * q];                        // (unconditional: PART_SLACK entries behind the last slice)
+    for (int q = 0; q < 2; q++) rec[q] = PART_LD(in + 256 * q);              // (unconditional: PART_SLACK entries behind the last slice)
     for (uint32_t b = lo4; b < hi; b += 2048) {
 #pragma unroll
-        for (int q = 0; q < 2; q++) nxt[q] = in[512 + 256 * q];
+        for (int q = 0; q < 2; q++) nxt[q] = PART_LD(in + 512 + 256 * q);
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const uint32_t w[4] = {rec[q].x, rec[q].y, rec[q].z, rec[q].w};
@@ -544,14 +564,14 @@ __device__ static __forceinline__ void hand_slice(HandLds& H, const uint32_t* __
     uint32_t* out_p = state_out + lo + lane;
     uint32_t cur[NR], nxt[NR];
 #pragma unroll
-    for (int r = 0; r < NR; r++) cur[r] = in[64 * r];               // (unconditional: PART_SLACK entries behind the last slice)
+    for (int r = 0; r < NR; r++) cur[r] = PART_LD(in + 64 * r);     // (unconditional: PART_SLACK entries behind the last slice)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // one step: event 64 r + lane is the lane's r-th -- instruction order, then lane order
     auto step = [&](auto full_tag, auto check_tag, const uint32_t left) {
         constexpr bool FULL = decltype(full_tag)::value, CHECK = decltype(check_tag)::value;
 #pragma unroll
-        for (int r = 0; r < NR; r++) nxt[r] = in[HAND_STEP + 64 * r];
+        for (int r = 0; r < NR; r++) nxt[r] = PART_LD(in + HAND_STEP + 64 * r);
         uint32_t n[NR], out[NR];
         if (CHECK && fault) {                                       // (test hook) rows 0 and 1 in the wrong order
             const uint32_t t = cur[0]; cur[0] = cur[1]; cur[1] = t;
