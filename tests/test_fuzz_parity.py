@@ -141,8 +141,8 @@ def test_random_few_worker_configuration_matches_oracle(seed, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(36, 48))
+@pytest.mark.parametrize("seed", range(36, 52))
 @pytest.mark.parametrize("variant", [v for v in VARIANTS if v != "default"])
 def test_few_worker_fallback_paths_match_oracle(variant, seed, monkeypatch):
-    """(seeds of their own: twelve more random cases per fall-back, every k of the bucketed hand-out and of its one-partition case)"""
+    """(seeds of their own: sixteen more random cases per fall-back, every k of the bucketed hand-out and of its one-partition case)"""
     _few_worker_case(seed, monkeypatch, variant)
