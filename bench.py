@@ -201,9 +201,7 @@ def pmc_step_traffic(workload_key):
         ks = doc["kernels"]
         # with the next batch staged ahead (the timed region: everything is) a step's hand-out and the next step's counting pass are ONE
         # launch (k_part_hand_count); the two kernels it replaces only run for the first batch and are not part of a steady-state step
-        fused = any(k.startswith("k_part_hand_count") for k in ks)
-        skip = ("k_part_hand_ord", "k_part_events<1, 0>", "k_part_events<2, 0>") if fused else ()
-        return float(sum(v["hbm_bytes_per_launch"] for k, v in ks.items() if k.startswith(STEP_KERNELS) and not k.startswith(skip)))
+        return step_traffic_of(ks)
     except (KeyError, ValueError):
         return None
 
@@ -211,8 +209,8 @@ def pmc_step_traffic(workload_key):
 def pmc_traffic(workload_key):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes of the same command
     (tools/prof_pmc.sh -> profiles/traffic_latest.json); None when no profile of this workload and this build exists.
-    The counters cannot be read from inside the process being timed, so the bench quotes the committed
-    measurement of the identical configuration and the identical sources."""
+    The counters cannot be read from inside the process being timed: the default run measures them in two child passes behind its
+    own legs (live_traffic); this is the committed measurement of the identical configuration and sources, quoted when that did not run."""
     doc = _traffic_doc(workload_key)
     try:
         return None if doc is None else float(doc["kernels"]["k_samples_lean"]["hbm_bytes_per_launch"])
@@ -255,6 +253,108 @@ def pmc_resources(workload_key, kernel_ms, samples_per_launch, store_peak_GBps):
         return out
     except (KeyError, ValueError, ZeroDivisionError, TypeError):
         return None
+
+
+def _pmc_short(kn):
+    """kernel name of a rocprofv3 CSV row -> the key profiles/*_traffic.json uses (template arguments kept for the event passes only)"""
+    short = kn.split("(")[0].split("<")[0].replace("void ", "").strip()
+    if short in ("k_events", "k_part_events"):
+        short = kn.split("(")[0].replace("void ", "").strip()
+    return short
+
+
+def parse_pmc_csv(path, counter):
+    """{kernel: [value per launch]} of ONE counter from a rocprofv3 `*_counter_collection.csv` (a launch's row per counter; rocprofv3
+    sums the counter's instances)"""
+    import csv
+    acc = {}
+    with open(path, newline="") as f:
+        for r in csv.DictReader(f):
+            if r.get("Counter_Name") == counter:
+                acc.setdefault(_pmc_short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+    return acc
+
+
+def traffic_from_pmc(fetch_kib, write_kib):
+    """HBM bytes per launch and kernel from the two passes' per-launch lists: FETCH_SIZE and WRITE_SIZE are KiB, FETCH_SIZE is doubled
+    (the gfx950 correction of MI355X_MICROARCH.md's HBM section, as tools/make_traffic.py); a kernel needs both counters"""
+    out = {}
+    for k in set(fetch_kib) & set(write_kib):
+        f = sum(fetch_kib[k]) / len(fetch_kib[k])
+        w = sum(write_kib[k]) / len(write_kib[k])
+        out[k] = {"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0,
+                  "launches": min(len(fetch_kib[k]), len(write_kib[k]))}
+    return out
+
+
+def step_traffic_of(ks):
+    """HBM bytes of one steady-state step from per-kernel averages: every kernel of the timed region, one launch each.  With the next
+    batch staged ahead (the timed region: everything is) a step's hand-out and the next step's counting pass are ONE launch
+    (k_part_hand_count); the two kernels it replaces only run for a run's first batch and are not part of a steady-state step"""
+    fused = any(k.startswith("k_part_hand_count") for k in ks)
+    skip = ("k_part_hand_ord", "k_part_events<1, 0>", "k_part_events<2, 0>") if fused else ()
+    return float(sum(v["hbm_bytes_per_launch"] for k, v in ks.items() if k.startswith(STEP_KERNELS) and not k.startswith(skip)))
+
+
+def under_profiler():
+    """is this process already a profiler's child (rocprofv3 preloads its tool library and exports ROCP_* / ROCPROF*)?"""
+    return (any(k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER")) for k in os.environ)
+            or "rocprof" in os.environ.get("LD_PRELOAD", ""))
+
+
+def live_traffic(args, limit_s=150.0):
+    """roofline.traffic as a measurement of THIS box and THESE libraries: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE -- one
+    counter per pass, counters only, as MI355X_MICROARCH.md prescribes) of this script in its shortest form (3 timed steps behind one
+    warm-up step of the same workload, no other leg), each a child process behind this run's own legs.  The WRITE_SIZE pass keeps the
+    store probe: k_store_probe writes exactly 1 GiB per launch, which checks the counter's unit.  None when rocprofv3 is not there, the
+    run is itself profiled, or a pass fails or exceeds its time limit (the line then quotes the hash-matched profile, as before)."""
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or under_profiler():
+        return None
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--pipeline-seconds", "0",
+             "--e2e-seconds", "0", "--small-batch-seconds", "0", "--every-batch-launches", "0", "--live-traffic", "off",
+             "--workload", args.workload, "--rlen", str(args.rlen), "--mode", args.mode]
+    if args.batch_reads is not None:
+        child += ["--batch-reads", str(args.batch_reads)]
+    if args.genome_mb is not None:
+        child += ["--genome-mb", str(args.genome_mb)]
+    if args.profile is not None:
+        child += ["--profile", args.profile]
+    if args.order_free:
+        child += ["--order-free"]
+    if args.lib is not None:
+        child += ["--lib", args.lib]
+    if args.workers_per_gpu is not None:
+        child += ["--workers-per-gpu", str(args.workers_per_gpu)]
+    t0 = time.perf_counter()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    got = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp" if os.path.isdir("/tmp") else None) as tmp:
+            env["TMPDIR"] = tmp
+            for counter, extra in (("FETCH_SIZE", ["--no-store-probe"]), ("WRITE_SIZE", [])):
+                left = limit_s - (time.perf_counter() - t0)
+                if left < 10:
+                    return None
+                cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", counter.lower(), "--"] + child + extra
+                p = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=left)
+                path = os.path.join(tmp, counter.lower() + "_counter_collection.csv")
+                if p.returncode != 0 or not os.path.exists(path):
+                    print(f"[bench] live traffic: the {counter} pass failed (rc {p.returncode}): {p.stderr[-300:]}", file=sys.stderr)
+                    return None
+                got[counter] = parse_pmc_csv(path, counter)
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
+        print(f"[bench] live traffic: {type(e).__name__}: {e}", file=sys.stderr)
+        return None
+    ks = traffic_from_pmc(got["FETCH_SIZE"], got["WRITE_SIZE"])
+    if "k_samples_lean" not in ks and "k_samples" not in ks:
+        return None
+    probe = got["WRITE_SIZE"].get("k_store_probe")
+    return {"kernels": ks, "seconds": time.perf_counter() - t0,
+            # 1.0 = WRITE_SIZE counts KiB (k_store_probe writes 2^30 bytes per launch)
+            "write_size_unit_check": None if not probe else (sum(probe) / len(probe)) / float(1 << 20),
+            "what": "two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of `bench.py --steps 3 --warmup 1` on this box, this workload and this "
+                    "library, run behind the line's own legs; per launch, averaged over the pass' launches; FETCH_SIZE doubled (gfx950)"}
 
 
 def host_info():
@@ -585,6 +685,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall time of each multi-process CPU leg")
     ap.add_argument("--no-store-probe", action="store_true")
+    ap.add_argument("--live-traffic", default="auto", choices=["auto", "on", "off"],
+                    help="roofline.traffic measured by two rocprofv3 --pmc child passes of this script on this box (auto: with the CPU legs, "
+                         "i.e. the default single-GPU run; the hash-matched profiles/traffic_latest.json is quoted otherwise)")
     ap.add_argument("--timing-every", type=int, default=3,
                     help="phase events (kernel_ms) on every n-th batch: each is a barrier packet between the kernels, 1.2 %% of a step "
                          "when every batch carries them (1: every batch; odd: the timed launches alternate between the context's two slots)")
@@ -1058,6 +1161,18 @@ def main():
                          "workload_key": wkey},
         }
         st = pmc_step_traffic(wkey)
+        out["roofline"]["traffic_source"] = None if out["roofline"]["traffic"] is None else "profiles/traffic_latest.json (PMC passes of the same sources and workload)"
+        want_live = args.live_traffic == "on" or (args.live_traffic == "auto" and not args.no_cpu_baseline and not args.digest)
+        if want_live and world == 1:
+            lt = live_traffic(args)
+            if lt is not None:
+                kk = lt["kernels"].get("k_samples_lean") or lt["kernels"].get("k_samples")
+                out["roofline"]["traffic_profile"] = out["roofline"]["traffic"]          # (the committed profile's figure, for comparison)
+                out["roofline"]["traffic"] = kk["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "live"
+                out["roofline"]["traffic_live"] = {"FETCH_SIZE_KiB": kk["FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": kk["WRITE_SIZE_KiB"], "launches": kk["launches"],
+                                                   "seconds": lt["seconds"], "write_size_unit_check": lt["write_size_unit_check"], "what": lt["what"]}
+                st = step_traffic_of(lt["kernels"])
         if st is not None:
             # all the HBM traffic of a step (PMC, every kernel of the timed region) over the step's time: how busy the memory is
             out["roofline"]["step_traffic"] = st

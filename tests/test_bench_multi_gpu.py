@@ -176,6 +176,47 @@ def test_bench_line_carries_the_contract():
     for leg in ("-t 1 -K 1000", "-t 8 -K 1000"):
         assert sb[leg]["unit"] == "samples/s" and sb[leg]["value"] > 0 and sb[leg]["seconds"] >= 0.9 and sb[leg]["batches"] >= 65, (leg, sb[leg])
     assert "resources" in r and (r["resources"] is None or r["resources"]["bound"] in ("valu", "l2_requests", "stores", "hbm"))
+    # round 5, last session: roofline.traffic measured by the run itself (two rocprofv3 --pmc child passes on this box) where rocprofv3 exists
+    import shutil
+    if shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"):
+        assert r["traffic_source"] == "live", (r.get("traffic_source"), p.stderr[-2000:])
+        lv = r["traffic_live"]
+        assert lv["launches"] >= 3 and lv["WRITE_SIZE_KiB"] * 1024 >= 0.95 * 2 * d["samples_per_step_per_gpu"]      # (the int16 stream at least)
+        assert r["traffic"] == pytest.approx((2 * lv["FETCH_SIZE_KiB"] + lv["WRITE_SIZE_KiB"]) * 1024, rel=1e-9)
+        assert r["traffic"] >= r["algorithmic_bytes_per_launch"] * 0.95 and r["step_traffic"] > r["traffic"]
+        assert lv["write_size_unit_check"] == pytest.approx(1.0, rel=0.05)                                          # k_store_probe's 1 GiB reads as 2^20 KiB
+
+
+def test_live_traffic_parsing(tmp_path):
+    """the per-kernel HBM bytes bench.py makes of rocprofv3's counter CSVs: one row per launch and counter, KiB, FETCH_SIZE doubled, the
+    step's sum over its kernels (the fused hand-out replaces the first batch's two launches)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    hdr = "Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,Accum_VGPR_Count,SGPR_Count,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n"
+
+    def row(kernel, counter, value):
+        return f'1,1,1,1,1,1,64,1,"{kernel}",256,0,0,60,0,88,{counter},{value},0,1\n'
+    names = {"lean": "void k_samples_lean<false, 4>(SigParams, int)", "ev10": "void k_part_events<1, 0>(SigParams, int, unsigned int)",
+             "ev01": "void k_part_events<0, 1>(SigParams, int, unsigned int)", "hc": "void k_part_hand_count<1, 0>(unsigned int const*, unsigned int*)",
+             "hist": "k_part_hist(unsigned int const*, unsigned int const*)", "probe": "k_store_probe(HIP_vector_type<unsigned int, 4u>*, unsigned long, unsigned int)",
+             "other": "k_sample_try(GenomeParams, unsigned int const*)"}
+    f = tmp_path / "fetch_size_counter_collection.csv"
+    f.write_text(hdr + row(names["lean"], "FETCH_SIZE", 1000) + row(names["lean"], "FETCH_SIZE", 3000) + row(names["ev10"], "FETCH_SIZE", 10)
+                 + row(names["ev01"], "FETCH_SIZE", 100) + row(names["hc"], "FETCH_SIZE", 200) + row(names["hist"], "FETCH_SIZE", 300)
+                 + row(names["other"], "FETCH_SIZE", 7) + row(names["lean"], "SQ_WAVES", 5))
+    w = tmp_path / "write_size_counter_collection.csv"
+    w.write_text(hdr + row(names["lean"], "WRITE_SIZE", 4000) + row(names["lean"], "WRITE_SIZE", 4000) + row(names["ev10"], "WRITE_SIZE", 20)
+                 + row(names["ev01"], "WRITE_SIZE", 1500) + row(names["hc"], "WRITE_SIZE", 1000) + row(names["hist"], "WRITE_SIZE", 100)
+                 + row(names["probe"], "WRITE_SIZE", 1048576) + row(names["other"], "WRITE_SIZE", 9))
+    fe, wr = bench.parse_pmc_csv(str(f), "FETCH_SIZE"), bench.parse_pmc_csv(str(w), "WRITE_SIZE")
+    assert fe["k_samples_lean"] == [1000.0, 3000.0] and "k_part_events<1, 0>" in fe and wr["k_store_probe"] == [1048576.0]
+    ks = bench.traffic_from_pmc(fe, wr)
+    assert ks["k_samples_lean"]["hbm_bytes_per_launch"] == (2 * 2000 + 4000) * 1024 and ks["k_samples_lean"]["launches"] == 2
+    assert "k_store_probe" not in ks                                       # (no FETCH_SIZE row: the fetch pass runs without the probe)
+    # a step: lean + scatter pass + fused hand-out + hist; not the first batch's counting pass, not the sampler
+    want = sum(ks[k]["hbm_bytes_per_launch"] for k in ("k_samples_lean", "k_part_events<0, 1>", "k_part_hand_count", "k_part_hist"))
+    assert bench.step_traffic_of(ks) == want
+    assert bench.under_profiler() is False
 
 
 def test_resources_are_priced_from_the_profile_of_the_same_sources(tmp_path, monkeypatch):
