@@ -218,30 +218,28 @@ def pmc_traffic(workload_key):
         return None
 
 
-def pmc_resources(workload_key, kernel_ms, samples_per_launch, store_peak_GBps):
-    """What the dominant kernel occupies besides HBM bytes, from the hash-matched PMC passes (tools/prof_pmc.sh ->
-    profiles/traffic_latest.json: SQ_ACTIVE_INST_VALU, SQ_INSTS_VALU, GRBM_GUI_ACTIVE, TCP_TCC_READ/WRITE_REQ, FETCH/WRITE_SIZE per launch)
-    priced with THIS run's kernel time: `valu_busy` = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs (quad-cycles
-    -> cycles); `l2_req_frac` = the kernel's TCP -> L2 requests per cycle over what `cal_rgather8` (tools/pmc_calib.hip: random 8-B
-    look-ups in an L2-resident table) sustains; `store_frac` = written bytes per second over the box's int16 streaming-store rate;
-    `hbm_frac` = all HBM bytes per second over 8 TB/s.  `bound` names the largest.  None without a matching profile."""
-    doc = _traffic_doc(workload_key)
+def resources_from(kk, cal, kernel_ms, samples_per_launch, store_peak_GBps, source):
+    """What the dominant kernel occupies besides HBM bytes, from its PMC counters per launch (`kk`: SQ_ACTIVE_INST_VALU, SQ_INSTS_VALU,
+    GRBM_GUI_ACTIVE, TCP_TCC_READ/WRITE_REQ_sum, FETCH/WRITE_SIZE_KiB, hbm_bytes_per_launch, kernel_us of the GRBM pass) priced with THIS
+    run's kernel time: `valu_busy` = SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs (quad-cycles -> cycles);
+    `l2_req_frac` = the kernel's TCP -> L2 requests per cycle over what `cal_rgather8` (tools/pmc_calib.hip: random 8-B look-ups in an
+    L2-resident table, `cal` requests per cycle) sustains; `store_frac` = written bytes per second over the box's int16 streaming-store
+    rate; `hbm_frac` = all HBM bytes per second over 8 TB/s.  `bound` names the largest."""
     try:
-        if doc is None or not kernel_ms:
-            return None
-        kk = doc["kernels"]["k_samples_lean"]
-        if "SQ_ACTIVE_INST_VALU" not in kk:
+        if not kernel_ms or "SQ_ACTIVE_INST_VALU" not in kk or "GRBM_GUI_ACTIVE" not in kk:
             return None
         cyc = kk["GRBM_GUI_ACTIVE"] / 8.0
-        out = {"source": "profiles/traffic_latest.json (PMC passes of the same sources and workload), priced with this run's kernel_ms",
+        out = {"source": source,
                "valu_busy": kk["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc,
                "valu_inst_per_sample": kk["SQ_INSTS_VALU"] * 64.0 / samples_per_launch if samples_per_launch else None,
                "kernel_cycles_pmc": cyc, "kernel_clock_GHz_pmc": cyc / (kk.get("kernel_us", 0) * 1e3) if kk.get("kernel_us") else None}
-        req = kk.get("TCP_TCC_READ_REQ_sum", 0.0) + kk.get("TCP_TCC_WRITE_REQ_sum", 0.0)
-        cal = (doc.get("calib") or {}).get("rgather8_l2_req_per_cycle")
-        out["l2_req_per_sample"] = req / samples_per_launch if samples_per_launch else None
-        out["l2_req_per_cycle"] = req / cyc
-        out["l2_req_frac"] = (req / cyc / cal) if cal else None
+        if "TCP_TCC_READ_REQ_sum" in kk or "TCP_TCC_WRITE_REQ_sum" in kk:
+            req = kk.get("TCP_TCC_READ_REQ_sum", 0.0) + kk.get("TCP_TCC_WRITE_REQ_sum", 0.0)
+            out["l2_req_per_sample"] = req / samples_per_launch if samples_per_launch else None
+            out["l2_req_per_cycle"] = req / cyc
+            out["l2_req_frac"] = (req / cyc / cal) if cal else None
+        else:
+            out["l2_req_per_sample"] = out["l2_req_per_cycle"] = out["l2_req_frac"] = None
         out["l2_req_calibrated_peak_per_cycle"] = cal
         wbytes = kk["WRITE_SIZE_KiB"] * 1024.0
         out["store_GBps"] = wbytes / (kernel_ms * 1e-3) / 1e9
@@ -252,6 +250,30 @@ def pmc_resources(workload_key, kernel_ms, samples_per_launch, store_peak_GBps):
         out["bound"] = max(cands, key=cands.get)
         return out
     except (KeyError, ValueError, ZeroDivisionError, TypeError):
+        return None
+
+
+def stored_calibration():
+    """requests per cycle `cal_rgather8` sustained when profiles/traffic_latest.json was measured: a property of the chip, not of the
+    library's sources (quoted whatever the file's hash)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
+            return (json.load(f).get("calib") or {}).get("rgather8_l2_req_per_cycle")
+    except (OSError, ValueError):
+        return None
+
+
+def pmc_resources(workload_key, kernel_ms, samples_per_launch, store_peak_GBps):
+    """resources_from() on the hash-matched PMC passes (tools/prof_pmc.sh -> profiles/traffic_latest.json); None without a matching
+    profile"""
+    doc = _traffic_doc(workload_key)
+    try:
+        if doc is None:
+            return None
+        return resources_from(doc["kernels"]["k_samples_lean"], (doc.get("calib") or {}).get("rgather8_l2_req_per_cycle"), kernel_ms,
+                              samples_per_launch, store_peak_GBps,
+                              "profiles/traffic_latest.json (PMC passes of the same sources and workload), priced with this run's kernel_ms")
+    except (KeyError, ValueError, TypeError):
         return None
 
 
@@ -302,12 +324,23 @@ def under_profiler():
             or "rocprof" in os.environ.get("LD_PRELOAD", ""))
 
 
-def live_traffic(args, limit_s=150.0):
-    """roofline.traffic as a measurement of THIS box and THESE libraries: two `rocprofv3 --pmc` passes (FETCH_SIZE, WRITE_SIZE -- one
-    counter per pass, counters only, as MI355X_MICROARCH.md prescribes) of this script in its shortest form (3 timed steps behind one
-    warm-up step of the same workload, no other leg), each a child process behind this run's own legs.  The WRITE_SIZE pass keeps the
-    store probe: k_store_probe writes exactly 1 GiB per launch, which checks the counter's unit.  None when rocprofv3 is not there, the
-    run is itself profiled, or a pass fails or exceeds its time limit (the line then quotes the hash-matched profile, as before)."""
+LIVE_PASSES = (            # (name, counters of ONE rocprofv3 --pmc pass, extra arguments of the child): combinations tools/prof_pmc.sh has run all round
+    ("fetch", ("FETCH_SIZE",), ("--no-store-probe",)),
+    ("write", ("WRITE_SIZE",), ()),                                              # (with the store probe: 1 GiB per launch checks the unit)
+    ("valu", ("GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU"), ("--no-store-probe",)),
+    ("l2req", ("TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum"), ("--no-store-probe",)),
+)
+
+
+def live_traffic(args, limit_s=180.0):
+    """roofline.traffic and roofline.resources as measurements of THIS box and THESE libraries: `rocprofv3 --pmc` passes (counters only;
+    FETCH_SIZE and WRITE_SIZE each alone, as MI355X_MICROARCH.md prescribes; then the VALU issue counters with the launch's cycles, then the
+    TCP -> L2 requests) of this script in its shortest form (3 timed steps behind one warm-up step of the same workload, no other leg), each
+    a child process behind this run's own legs, ~2.5 s apiece.  The WRITE_SIZE pass keeps the store probe: k_store_probe writes exactly
+    1 GiB per launch, which checks the counter's unit.  If tools/bin/pmc_calib is there (__graft_entry__.build() compiles it), its random
+    8-B look-ups are counted too: the L2 request rate this chip sustains.  None when rocprofv3 is not there, the run is itself profiled, or
+    one of the two traffic passes fails or exceeds the time limit (the line then quotes the hash-matched profile, as before); a failing
+    later pass only leaves its counters out."""
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None or under_profiler():
         return None
@@ -328,33 +361,74 @@ def live_traffic(args, limit_s=150.0):
         child += ["--workers-per-gpu", str(args.workers_per_gpu)]
     t0 = time.perf_counter()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    got = {}
+    got, dur, calib, failed = {}, {}, None, []
+
+    def one_pass(tmp, name, counters, cmd_tail):
+        left = limit_s - (time.perf_counter() - t0)
+        if left < 10:
+            return None
+        cmd = [exe, "--pmc"] + list(counters) + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", name, "--"] + cmd_tail
+        p = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=left)
+        path = os.path.join(tmp, name + "_counter_collection.csv")
+        if p.returncode != 0 or not os.path.exists(path):
+            print(f"[bench] live counters: the {name} pass failed (rc {p.returncode}): {p.stderr[-300:]}", file=sys.stderr)
+            return None
+        return path
+
     try:
         with tempfile.TemporaryDirectory(dir="/tmp" if os.path.isdir("/tmp") else None) as tmp:
             env["TMPDIR"] = tmp
-            for counter, extra in (("FETCH_SIZE", ["--no-store-probe"]), ("WRITE_SIZE", [])):
-                left = limit_s - (time.perf_counter() - t0)
-                if left < 10:
-                    return None
-                cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", counter.lower(), "--"] + child + extra
-                p = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=left)
-                path = os.path.join(tmp, counter.lower() + "_counter_collection.csv")
-                if p.returncode != 0 or not os.path.exists(path):
-                    print(f"[bench] live traffic: the {counter} pass failed (rc {p.returncode}): {p.stderr[-300:]}", file=sys.stderr)
-                    return None
-                got[counter] = parse_pmc_csv(path, counter)
-    except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
-        print(f"[bench] live traffic: {type(e).__name__}: {e}", file=sys.stderr)
+            for name, counters, extra in LIVE_PASSES:
+                try:
+                    path = one_pass(tmp, name, counters, child + list(extra))
+                except subprocess.SubprocessError as e:
+                    print(f"[bench] live counters: the {name} pass: {type(e).__name__}", file=sys.stderr)
+                    path = None
+                if path is None:
+                    if name in ("fetch", "write"):
+                        return None
+                    failed.append(name)
+                    continue
+                for c in counters:
+                    got[c] = parse_pmc_csv(path, c)
+                if name == "valu":                                   # the launch durations of the pass whose cycles are quoted: the clock
+                    import csv
+                    kt = os.path.join(tmp, name + "_kernel_trace.csv")
+                    if os.path.exists(kt):
+                        with open(kt, newline="") as f:
+                            for r in csv.DictReader(f):
+                                dur.setdefault(_pmc_short(r["Kernel_Name"]), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+            cal_bin = os.path.join(ROOT, "tools", "bin", "pmc_calib")
+            if os.access(cal_bin, os.X_OK) and "l2req" not in failed:
+                try:
+                    path = one_pass(tmp, "cal", ("TCP_TCC_READ_REQ_sum", "GRBM_GUI_ACTIVE"), [cal_bin, "2"])
+                    if path is not None:
+                        rq = parse_pmc_csv(path, "TCP_TCC_READ_REQ_sum"); cy = parse_pmc_csv(path, "GRBM_GUI_ACTIVE")
+                        k = next((k for k in rq if "cal_rgather8" in k), None)
+                        if k and cy.get(k):
+                            calib = (sum(rq[k]) / len(rq[k])) / (sum(cy[k]) / len(cy[k]) / 8.0)
+                except subprocess.SubprocessError:
+                    pass
+    except (OSError, ValueError, KeyError) as e:
+        print(f"[bench] live counters: {type(e).__name__}: {e}", file=sys.stderr)
         return None
     ks = traffic_from_pmc(got["FETCH_SIZE"], got["WRITE_SIZE"])
+    for c in ("GRBM_GUI_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum"):
+        for k, v in got.get(c, {}).items():
+            if k in ks and v:
+                ks[k][c] = sum(v) / len(v)
+    for k, v in dur.items():
+        if k in ks and v:
+            ks[k]["kernel_us"] = sum(v) / len(v)
     if "k_samples_lean" not in ks and "k_samples" not in ks:
         return None
     probe = got["WRITE_SIZE"].get("k_store_probe")
-    return {"kernels": ks, "seconds": time.perf_counter() - t0,
+    return {"kernels": ks, "seconds": time.perf_counter() - t0, "calib_rgather8_l2_req_per_cycle": calib, "failed_passes": failed,
             # 1.0 = WRITE_SIZE counts KiB (k_store_probe writes 2^30 bytes per launch)
             "write_size_unit_check": None if not probe else (sum(probe) / len(probe)) / float(1 << 20),
-            "what": "two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of `bench.py --steps 3 --warmup 1` on this box, this workload and this "
-                    "library, run behind the line's own legs; per launch, averaged over the pass' launches; FETCH_SIZE doubled (gfx950)"}
+            "what": "rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; GRBM_GUI_ACTIVE + SQ_ACTIVE_INST_VALU + SQ_INSTS_VALU; TCP_TCC_READ/WRITE_REQ_sum) of "
+                    "`bench.py --steps 3 --warmup 1` on this box, this workload and this library, run behind the line's own legs; per launch, "
+                    "averaged over the pass' launches; FETCH_SIZE doubled (gfx950)"}
 
 
 def host_info():
@@ -1163,16 +1237,16 @@ def main():
         st = pmc_step_traffic(wkey)
         out["roofline"]["traffic_source"] = None if out["roofline"]["traffic"] is None else "profiles/traffic_latest.json (PMC passes of the same sources and workload)"
         want_live = args.live_traffic == "on" or (args.live_traffic == "auto" and not args.no_cpu_baseline and not args.digest)
-        if want_live and world == 1:
-            lt = live_traffic(args)
-            if lt is not None:
-                kk = lt["kernels"].get("k_samples_lean") or lt["kernels"].get("k_samples")
-                out["roofline"]["traffic_profile"] = out["roofline"]["traffic"]          # (the committed profile's figure, for comparison)
-                out["roofline"]["traffic"] = kk["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "live"
-                out["roofline"]["traffic_live"] = {"FETCH_SIZE_KiB": kk["FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": kk["WRITE_SIZE_KiB"], "launches": kk["launches"],
-                                                   "seconds": lt["seconds"], "write_size_unit_check": lt["write_size_unit_check"], "what": lt["what"]}
-                st = step_traffic_of(lt["kernels"])
+        lt = live_traffic(args) if (want_live and world == 1) else None
+        if lt is not None:
+            kk = lt["kernels"].get("k_samples_lean") or lt["kernels"].get("k_samples")
+            out["roofline"]["traffic_profile"] = out["roofline"]["traffic"]              # (the committed profile's figure, for comparison)
+            out["roofline"]["traffic"] = kk["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "live"
+            out["roofline"]["traffic_live"] = {"FETCH_SIZE_KiB": kk["FETCH_SIZE_KiB"], "WRITE_SIZE_KiB": kk["WRITE_SIZE_KiB"], "launches": kk["launches"],
+                                               "seconds": lt["seconds"], "write_size_unit_check": lt["write_size_unit_check"],
+                                               "failed_passes": lt["failed_passes"], "what": lt["what"]}
+            st = step_traffic_of(lt["kernels"])
         if st is not None:
             # all the HBM traffic of a step (PMC, every kernel of the timed region) over the step's time: how busy the memory is
             out["roofline"]["step_traffic"] = st
@@ -1182,6 +1256,15 @@ def main():
         # what the kernel occupies besides HBM bytes (the profile's counters priced with this run's time); `bound` in `resources` names
         # the largest share -- roofline.bound stays "hbm": that is the roofline this line's frac is quoted against
         out["roofline"]["resources"] = pmc_resources(wkey, k_ms, samples / steps, out["roofline"].get("measured_store_peak_GBps"))
+        if lt is not None:
+            kk = lt["kernels"].get("k_samples_lean") or lt["kernels"].get("k_samples")
+            cal = lt["calib_rgather8_l2_req_per_cycle"]
+            live_res = resources_from(kk, cal or stored_calibration(), k_ms, samples / steps, out["roofline"].get("measured_store_peak_GBps"),
+                                      "live: rocprofv3 --pmc child passes of this run (roofline.traffic_live), priced with this run's kernel_ms; cal_rgather8 "
+                                      + ("counted in the same run" if cal else "from profiles/traffic_latest.json (tools/bin/pmc_calib not built)"))
+            if live_res is not None:
+                out["roofline"]["resources_profile"] = out["roofline"]["resources"]
+                out["roofline"]["resources"] = live_res
         if digests:
             out["digest"] = digests
         if args.no_cpu_baseline or world > 1:

@@ -185,6 +185,11 @@ def test_bench_line_carries_the_contract():
         assert r["traffic"] == pytest.approx((2 * lv["FETCH_SIZE_KiB"] + lv["WRITE_SIZE_KiB"]) * 1024, rel=1e-9)
         assert r["traffic"] >= r["algorithmic_bytes_per_launch"] * 0.95 and r["step_traffic"] > r["traffic"]
         assert lv["write_size_unit_check"] == pytest.approx(1.0, rel=0.05)                                          # k_store_probe's 1 GiB reads as 2^20 KiB
+        # ... and what the kernel occupies besides bytes, from the same run's passes (a failed pass leaves its counters out, never the line)
+        rs = r["resources"]
+        assert rs is not None and rs["source"].startswith("live") and lv["failed_passes"] == [], lv
+        assert 0.2 < rs["valu_busy"] <= 1.05 and 20 < rs["valu_inst_per_sample"] < 80 and 1.0 < rs["kernel_clock_GHz_pmc"] < 2.6
+        assert rs["l2_req_per_cycle"] > 0 and rs["bound"] in ("valu", "l2_requests", "stores", "hbm")
 
 
 def test_live_traffic_parsing(tmp_path):
