@@ -1129,6 +1129,12 @@ def main():
     genome_host = None
     if genome_dev is not None and rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "hg38-r10":
         genome_host = (genome_dev[0].cpu().numpy(), list(genome_dev[1]))     # (for cpu_baseline.t1_full_genome: the reference on the very genome)
+    # which stream hand-out the timed steps used: the one that relies on lane-ordered LDS atomics (probed at create time, re-checked on a
+    # sample of every slice of every batch) or -- a device that fails the probe, or --order-free -- the claim protocol (1.3 ms per step slower)
+    lds_order = None
+    if rank == 0:
+        bad_, used_ = gen.probe_lds_order(256, 4)
+        lds_order = {"in_use": used_, "probe_mismatches": bad_}
     store_peak_GBps = None
     if rank == 0 and not args.no_store_probe:
         store_peak_GBps = gen.probe_store_bandwidth(1 << 30, 10) / 1e9
@@ -1191,6 +1197,7 @@ def main():
                             f"({int(tot_reads)} reads)",
                 "genome_bases": genome_bases,
                 "reads_per_step_per_gpu": K, "kmer_size": k, "mode": args.mode, "order_free": bool(args.order_free),
+                "lds_ordered_hand_out": lds_order,
                 "reads": "gen_read on the device-resident genome (library sampler), as the reference with these options",
                 "pore_model": "synthetic stand-in table (built-in ONT tables absent from the reference mount)",
             },

@@ -139,6 +139,7 @@ def test_bench_line_carries_the_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["data"] == "synthetic"
     assert d["vs_baseline"] is None and d["value"] > 0 and d["ms_per_step"] > 0 and isinstance(d["dtype"], str)
     assert "workload" in d["config"] and "dna-r10-prom" in d["config"]["workload"] and "model" not in d["config"]
+    assert d["config"]["lds_ordered_hand_out"] == {"in_use": True, "probe_mismatches": 0}      # (the fast hand-out ran; a device that fails the probe says so here)
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert "traffic" in r and r["kernel"] == "k_samples_lean" and r["kernel_ms"] > 0 and 0 < r["step_frac"] < r["frac"]
