@@ -368,7 +368,19 @@ def live_traffic(args, limit_s=180.0):
         if left < 10:
             return None
         cmd = [exe, "--pmc"] + list(counters) + ["--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", name, "--"] + cmd_tail
-        p = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=left)
+        # (a process group of its own: a pass that exceeds its limit is ended with its children -- the profiled python -- not just the profiler)
+        with subprocess.Popen(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True) as pr:
+            try:
+                _, err_txt = pr.communicate(timeout=left)
+            except subprocess.TimeoutExpired:
+                import signal
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                pr.communicate()
+                raise
+        p = subprocess.CompletedProcess(cmd, pr.returncode, "", err_txt)
         path = os.path.join(tmp, name + "_counter_collection.csv")
         if p.returncode != 0 or not os.path.exists(path):
             print(f"[bench] live counters: the {name} pass failed (rc {p.returncode}): {p.stderr[-300:]}", file=sys.stderr)
