@@ -233,6 +233,13 @@ def resources_from(kk, cal, kernel_ms, samples_per_launch, store_peak_GBps, sour
                "valu_busy": kk["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc,
                "valu_inst_per_sample": kk["SQ_INSTS_VALU"] * 64.0 / samples_per_launch if samples_per_launch else None,
                "kernel_cycles_pmc": cyc, "kernel_clock_GHz_pmc": cyc / (kk.get("kernel_us", 0) * 1e3) if kk.get("kernel_us") else None}
+        # the kernel at single issue: one 4-cycle pass per VALU wave-instruction and SIMD, a second pass for each of the loop's three transcendentals
+        # per 64 samples (gfx950 pairs VALU instructions only in streams without transcendentals: profiles/r04_ubench.md) -- at the clock the
+        # counters were taken at.  Next to kernel_ms it says how much of the kernel's time is anything BUT its instruction count
+        if out["kernel_clock_GHz_pmc"] and samples_per_launch:
+            cyc_issue = (kk["SQ_INSTS_VALU"] * 4.0 + 3.0 * (samples_per_launch / 64.0) * 4.0) / 1024.0
+            out["valu_single_issue_ms"] = cyc_issue / (out["kernel_clock_GHz_pmc"] * 1e9) * 1e3
+            out["kernel_ms_over_valu_single_issue"] = kernel_ms / out["valu_single_issue_ms"]
         if "TCP_TCC_READ_REQ_sum" in kk or "TCP_TCC_WRITE_REQ_sum" in kk:
             req = kk.get("TCP_TCC_READ_REQ_sum", 0.0) + kk.get("TCP_TCC_WRITE_REQ_sum", 0.0)
             out["l2_req_per_sample"] = req / samples_per_launch if samples_per_launch else None

@@ -240,6 +240,10 @@ def test_resources_are_priced_from_the_profile_of_the_same_sources(tmp_path, mon
     assert res["valu_busy"] == pytest.approx(1.2e9 * 4 / 1024 / 5.0e6) and res["valu_inst_per_sample"] == pytest.approx(9.6e8 * 64 / 2.13e9)
     assert res["l2_req_frac"] == pytest.approx(2.9e8 / 5.0e6 / 100.0) and res["store_frac"] == pytest.approx(4.2e6 * 1024 / 2.4e-3 / 1e9 / 5000.0)
     assert res["hbm_frac"] == pytest.approx(6.9e9 / 2.4e-3 / 8e12) and res["bound"] == "valu"
+    # the kernel at single issue: 4 cycles per VALU wave-instruction and SIMD + a second pass per transcendental (3 per 64 samples), at the counters' clock
+    clk = 5.0e6 / 2400.0e3
+    want_ms = (9.6e8 * 4 + 3 * (2.13e9 / 64) * 4) / 1024 / (clk * 1e9) * 1e3
+    assert res["valu_single_issue_ms"] == pytest.approx(want_ms) and res["kernel_ms_over_valu_single_issue"] == pytest.approx(2.4 / want_ms)
     assert bench.pmc_resources("other workload", 2.4, 2.13e9, 5000.0) is None
     doc["source_hash"] = "0" * 16
     (tmp_path / "profiles" / "traffic_latest.json").write_text(json.dumps(doc))
