@@ -162,7 +162,7 @@ def pack(reads):
 
 WORKLOADS = {
     # name: (profile, extra flags, sampler mode, workers per GPU (0: one per read), reads per step per GPU, description)
-    "hg38-r10": ("dna-r10-prom", 0, "dna", 1, 16384,
+    "hg38-r10": ("dna-r10-prom", 0, "dna", 1, 32768,
                  "synthetic hg38-scale genome (24 contigs, hg38's chromosome lengths, 3.09 Gb) -x dna-r10-prom (BASELINE.json configs[2]; "
                  "configs[3] at N=8)"),
     "ncov-r9": ("dna-r9-prom", 0, "dna", 0, 32768, "nCoV-2019.reference.fasta -x dna-r9-prom (BASELINE.json configs[1])"),
