@@ -1243,6 +1243,9 @@ def main():
             # samples the fp32 path left to FP64, over the batches whose counters were still theirs when they were waited for
             "fp64_fixup_frac": (fallback / fallback_of if fallback_of else None) if args.mode == "certified" else None,
             "samples_per_step_per_gpu": samples / steps,
+            # the step of rounds 1-4's lines was 16384 reads per GPU: this line's step time at that size, for comparing rounds (the headline workload runs 32768
+            # reads per batch since the last session of round 5 -- `-t 1` does not know the batch size, tests/batchsize_hg38.py -- and 3.5-7 % faster per read)
+            "ms_per_16384_reads": ms_per_step * 16384.0 / max(reads / steps, 1.0),
             "kernel_ms": {"k_samples_lean": k_ms,
                           # from the end of the event side to the batch's last kernel; the fix-ups run on their own stream next to
                           # the NEXT batch's event kernels and are stretched by them, so this span is longer than the kernels in it
