@@ -244,6 +244,7 @@ struct Staging {
                 if (!part_ok) target = std::min<long long>(target, std::max<long long>(8, (long long)(((size_t)1 << 30) / row_bytes)));
                 std::vector<int> link_off(1, 0);
                 b->pieces = wave_links;
+                const bool whole_links = !SQG_DEV_ENV("SQG_NO_WHOLE_LINKS");           // A/B (development library)
                 for (int q = 0; q < n_wchains && wave_links; q++) {
                     // a link of k_part_events is a run of PIECES: whole reads, and the pieces (whole 512-event segments) of reads longer
                     // than a link should be -- one wavefront walks a link, and a read of 10^5 events would keep it busy ten times as
@@ -263,6 +264,13 @@ struct Staging {
                         if (ne <= per + per / 4 || ne <= PEV_SEG) {
                             pieces.push_back(Piece{r, 0, (int)ne, 0});
                             if ((acc += ne) >= per) close();
+                        } else if (whole_links && ne < (1 << EVR_REL_BITS) - PEV_SEG) {
+                            // a read that is longer than a link should be but fits one: a link of its own, whole (round 5: at the headline size the
+                            // cap above is what sets `per` -- 7281 events -- and every 10-kb read, 9992 events, was cut into 7168 + 2824: twice the
+                            // links, half of them short, and the cut reads' tile offsets patched by k_part_tile_bases)
+                            if (acc > 0) close();
+                            pieces.push_back(Piece{r, 0, (int)ne, 0});
+                            close();
                         } else {
                             for (long long e = 0; e < ne; e += chunk) {
                                 const long long e_hi = std::min(e + chunk, ne);
