@@ -253,7 +253,8 @@ struct Staging {
                     const long long lq = std::max<long long>(1, nev > 0 ? (target * wchain_ev[(size_t)q] + nev - 1) / nev : 1);
                     // (a link stays below 2^14 events -- an event's record for the sample kernels carries its slot within the (link,
                     // partition) in EVR_REL_BITS bits, k_common.h: a link closes at less than per + (per + per / 4) events)
-                    const long long per = std::min<long long>(std::max<long long>(1, (wchain_ev[(size_t)q] + lq - 1) / lq), ((1 << EVR_REL_BITS) - 1) * 4 / 9);
+                    const long long per_cap = ((1 << EVR_REL_BITS) - 1) * 4 / 9;
+                    const long long per = std::min<long long>(std::max<long long>(1, (wchain_ev[(size_t)q] + lq - 1) / lq), per_cap);
                     const long long chunk = std::max<long long>(PEV_SEG, per / PEV_SEG * PEV_SEG);
                     long long acc = 0;
                     auto close = [&]() { link_off.push_back((int)pieces.size()); acc = 0; };
@@ -264,10 +265,11 @@ struct Staging {
                         if (ne <= per + per / 4 || ne <= PEV_SEG) {
                             pieces.push_back(Piece{r, 0, (int)ne, 0});
                             if ((acc += ne) >= per) close();
-                        } else if (whole_links && ne < (1 << EVR_REL_BITS) - PEV_SEG) {
-                            // a read that is longer than a link should be but fits one: a link of its own, whole (round 5: at the headline size the
-                            // cap above is what sets `per` -- 7281 events -- and every 10-kb read, 9992 events, was cut into 7168 + 2824: twice the
-                            // links, half of them short, and the cut reads' tile offsets patched by k_part_tile_bases)
+                        } else if (whole_links && per == per_cap && ne < (1 << EVR_REL_BITS) - PEV_SEG) {
+                            // a large batch -- the cap above, not the link target, sets `per` -- and a read that is longer than that but fits a link:
+                            // a link of its own, whole (round 5: at the headline size every 10-kb read, 9992 events, was cut into 7168 + 2824: twice the
+                            // links, half of them short, and the cut reads' tile offsets patched by k_part_tile_bases).  A small batch keeps cutting:
+                            // there the pieces are what fills the machine
                             if (acc > 0) close();
                             pieces.push_back(Piece{r, 0, (int)ne, 0});
                             close();
