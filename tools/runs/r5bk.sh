@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/../.."
 OUT=$PWD/gpurun_out/r5bk; mkdir -p $OUT
 export TMPDIR=/tmp
-for what in none part evrec state lbase items; do
+for what in ${WHATS:-none part evrec state lbase items}; do
   rm -rf $OUT/kt; mkdir -p $OUT/kt
   ( cd /tmp && SQG_REALLOC_WHAT=$what timeout 600 rocprofv3 --kernel-trace -d $OUT/kt -o kt --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --lib $GRAFT_REPO_ROOT/tools/var_x_realloc.so --no-cpu-baseline --no-store-probe --pipeline-seconds 0 --e2e-seconds 0 --small-batch-seconds 0 --every-batch-launches 0 --live-traffic off --steps 130 --warmup 14 > $OUT/bench_$what.log 2>&1 )
   python - $what <<'PY'
@@ -24,3 +24,4 @@ for k in ('k_part_events<0, 1>', 'k_samples_lean<false, 4>'):
 PY
 done 2>&1 | tee $OUT/windows.log
 rm -rf $OUT/kt
+grep -h "^\[sqg\] run" $OUT/bench_evrec.log $OUT/bench_part.log 2>/dev/null | head -60
