@@ -658,17 +658,20 @@ def parity_check(prof, flags, k, mean, stdv, contigs, rlen, n_reads, one_worker,
     return out, rate
 
 
-def pipeline_leg(stage_one, run, n_batches):
+def pipeline_leg(stage_one, run, n_batches, seconds=None, max_batches=40000):
     """Nothing staged ahead but the batch behind the one being queued: ONE host thread samples + stages batch i+2 (device-side gen_read,
     descriptors, links), queues batch i+1 -- the library lets the first event pass of the staged batch behind it ride along with its
     hand-out (include/sqg.h, sqg_batch_run) --, waits for batch i and frees it.  Two batches in flight, one staged, results left in HBM.
-    Returns (samples, reads, seconds, host seconds spent in the sampler + staging call per batch)."""
+    With `seconds` the leg runs on the clock -- at least n_batches, then until `seconds` have elapsed (at most max_batches) -- and the batch
+    count it did is the fifth element; without, exactly n_batches (range sharding has a collective per batch: every rank the same count).
+    Returns (samples, reads, seconds, host seconds spent in the sampler + staging call per batch, batches run)."""
     cur = run(stage_one())
     nxt = stage_one()
     samples = reads = 0
     t_stage = 0.0
     t0 = time.perf_counter()
-    for _ in range(n_batches):
+    done = 0
+    while done < n_batches or (seconds is not None and done < max_batches and time.perf_counter() - t0 < seconds):
         a = time.perf_counter()
         nn = stage_one()
         t_stage += time.perf_counter() - a
@@ -677,12 +680,13 @@ def pipeline_leg(stage_one, run, n_batches):
         samples += cur.n_samples; reads += cur.n_reads
         cur.free()
         cur, nxt = nxt, nn
+        done += 1
     cur.wait()
     samples += cur.n_samples; reads += cur.n_reads
     dt = time.perf_counter() - t0
     cur.free()
     nxt.free()                                                   # (staged, never run)
-    return samples, reads, dt, t_stage / max(n_batches, 1)
+    return samples, reads, dt, t_stage / max(done, 1), done + 1
 
 
 def e2e_legs(gen, prof, flags, sample_batch, reads_per_batch, seconds, kinds=("pinned_int16", "pinned_svb", "blow5", "blow5_fast")):
@@ -1104,13 +1108,10 @@ def main():
         st1 = lambda: g2.sample(1000, wk)
         warm = st1().run(); warm.wait(); warm.free()
         sync_all()
-        trial = pipeline_leg(st1, lambda b: b.run(), 64)       # (size the leg from a short trial: ~0.35 ms per batch)
-        n_small = int(min(max(args.small_batch_seconds / max(trial[2] / 65, 1e-6), 64), 40000))
+        r = pipeline_leg(st1, lambda b: b.run(), 64, seconds=args.small_batch_seconds)      # (on the clock: >= 64 batches, then until the time is up)
         sync_all()
-        r = pipeline_leg(st1, lambda b: b.run(), n_small)
-        sync_all()
-        return {"value": r[0] / r[2], "unit": "samples/s", "reads_per_s": r[1] / r[2], "seconds": r[2], "batches": n_small + 1,
-                "ms_per_batch": r[2] / (n_small + 1) * 1e3, "host_stage_ms_per_batch": r[3] * 1e3}
+        return {"value": r[0] / r[2], "unit": "samples/s", "reads_per_s": r[1] / r[2], "seconds": r[2], "batches": r[4],
+                "ms_per_batch": r[2] / r[4] * 1e3, "host_stage_ms_per_batch": r[3] * 1e3}
 
     if small_on:
         free_all()
@@ -1283,7 +1284,9 @@ def main():
         if store_peak_GBps is not None:
             out["roofline"]["measured_store_peak_GBps"] = store_peak_GBps
         # what the kernel occupies besides HBM bytes (the profile's counters priced with this run's time); `bound` in `resources` names
-        # the largest share -- roofline.bound stays "hbm": that is the roofline this line's frac is quoted against
+        # the largest share, and roofline.bound says the same thing when resources were measured (the line says ONE
+        # thing about its bound).  `achieved`/`peak`/`frac` are quoted against the HBM roofline whatever the bound:
+        # `quoted_against` says so.
         out["roofline"]["resources"] = pmc_resources(wkey, k_ms, samples / steps, out["roofline"].get("measured_store_peak_GBps"))
         if lt is not None:
             kk = lt["kernels"].get("k_samples_lean") or lt["kernels"].get("k_samples")
@@ -1294,6 +1297,9 @@ def main():
             if live_res is not None:
                 out["roofline"]["resources_profile"] = out["roofline"]["resources"]
                 out["roofline"]["resources"] = live_res
+        out["roofline"]["quoted_against"] = "hbm"
+        if out["roofline"]["resources"] is not None:
+            out["roofline"]["bound"] = out["roofline"]["resources"]["bound"]
         if digests:
             out["digest"] = digests
         if args.no_cpu_baseline or world > 1:

@@ -65,23 +65,5 @@ def test_certified_equals_exact_over_whole_batches(T, tmp_path):
         assert len(s0) > 1.0e7
 
 
-@pytest.mark.gpu
-def test_full_size_genome_t1():
-    """3.09 Gb resident, `-t 1 -K 1024`: what the driver's bench line runs, at a batch size the oracle finishes in seconds
-    (tests/fullsize_hg38.py, in a process of its own)"""
-    import subprocess
-    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fullsize_hg38.py")],
-                       capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
-    assert "full-size ok" in p.stdout
-
-
-@pytest.mark.gpu
-def test_t1_does_not_know_the_batch_size():
-    """3.09 Gb resident, `-t 1`: one 32768-read batch (bench.py's headline size) == two of 16384 == (its first 2048 reads) two of 1024, the size
-    the test above compares with the oracle -- 4.3e9 int16, bit for bit (tests/batchsize_hg38.py, in a process of its own)"""
-    import subprocess
-    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "batchsize_hg38.py")],
-                       capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
-    assert "batch-size ok" in p.stdout
+# the two full-size checks (3.09 Gb resident: tests/fullsize_hg38.py against the oracle, tests/batchsize_hg38.py across batch sizes) are
+# tests/test_00_configs.py::test_config2_hg38_r10_* -- collected first, named after the config
