@@ -19,6 +19,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -32,6 +33,8 @@ struct sqg_ctx {
     unsigned long long next_stage = 0, next_run = 0;
     sqg_timing_t timing = {0, 0, 0, 0, 0, 0, 0, 0};
     std::string err;
+    // (h_blow5.h's stored-mode writer registers itself with the context whose records its background write reads: same fields as the HIP library's context)
+    void* b5_reader = nullptr; int b5_reader_buf = -1; void (*b5_reader_drain)(void* writer, bool unbind) = nullptr; int b5_flip = 0;
 };
 
 struct sqg_batch {
@@ -72,6 +75,7 @@ extern "C" int32_t sqg_worker_of(int32_t i, int32_t n_rec, int32_t T) { return (
 
 extern "C" void sqg_destroy(sqg_ctx_t* c) {
     if (!c) return;
+    if (c->b5_reader_drain) c->b5_reader_drain(c->b5_reader, true);
     if (c->core) orc_core_free(c->core);
     if (c->ref) orc_ref_free(c->ref);
     delete c;
@@ -314,6 +318,7 @@ extern "C" int sqg_batch_blow5_records(sqg_ctx_t* c, sqg_batch_t* b, const sqg_p
                                        const uint8_t** records, int64_t* n_bytes, const int64_t** rec_off) {
     if (!c || !b || !b->ran || !profile || !records || !n_bytes || (b->n > 0 && (!read_ids || !id_off))) return SQG_EINVAL;
     if (b->svb_off.empty()) { sqg_svb_t sv; const int rc = sqg_batch_compress(c, b, &sv); if (rc) return rc; }
+    if (c->b5_reader_drain) c->b5_reader_drain(c->b5_reader, false);     // (ONE buffer here: a writer's background write of the previous call's records finishes first)
     sqg_blow5 w; w.profile = *profile; w.flags = flags;
     static thread_local std::vector<uint8_t> out, raw;
     static thread_local std::vector<int64_t> ro;

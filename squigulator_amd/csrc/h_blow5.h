@@ -25,6 +25,9 @@
 #include <zlib.h>
 #include <unistd.h>
 
+#ifndef B5_ID_MAX
+#define B5_ID_MAX 4096                    // (k_blow5.h's: the framing kernel's LDS header; repeated for the CPU backend, which compiles this file without the kernels)
+#endif
 struct sqg_blow5 {
     struct Shard { FILE* fp = nullptr; unsigned long long n_bytes = 0; };
     std::vector<Shard> sh;               // the files: one, or -- SQG_BLOW5_SHARDS(n), stored mode -- n of them (path.0.blow5 ...), each a BLOW5 file of its own
@@ -40,6 +43,7 @@ struct sqg_blow5 {
     int bg_bad = 0;                      // ... and whether it failed (read after the join)
     bool failed = false;                 // a write came up short: records of an unfinished batch are on disk, nothing more is written
     std::string err;
+    sqg_ctx* bound = nullptr;            // the context whose pinned records the background write reads (registered there: sqg_destroy and the next filler of that buffer drain it)
 };
 
 extern "C" const char* sqg_blow5_last_error(const sqg_blow5_t* w) { return w ? w->err.c_str() : ""; }
@@ -194,6 +198,17 @@ static bool blow5_drain(sqg_blow5* w) {
     if (w->bg.joinable()) w->bg.join();
     return w->bg_bad == 0;
 }
+// what a context calls before it refills (or frees) the pinned buffer this writer's background write reads
+static void blow5_ctx_hook(void* w_, bool unbind) {
+    sqg_blow5* w = static_cast<sqg_blow5*>(w_);
+    if (!w) return;
+    if (!blow5_drain(w)) w->failed = true;
+    if (unbind && w->bound) { w->bound->b5_reader = nullptr; w->bound->b5_reader_drain = nullptr; w->bound->b5_reader_buf = -1; w->bound = nullptr; }
+}
+static void blow5_unbind(sqg_blow5* w) {
+    if (w->bound && w->bound->b5_reader == w) { w->bound->b5_reader = nullptr; w->bound->b5_reader_drain = nullptr; w->bound->b5_reader_buf = -1; }
+    w->bound = nullptr;
+}
 // stored mode: the batch's records -- record i at data + ro[i] - ro[0] -- dealt out to the files by ranges of reads, one stream of pwrite()s
 // per file, side by side (different files do not share a lock: 11.6 / 22 / 37 GB/s into 2 / 4 / 8 files of a tmpfs, tools/io_probe.cpp)
 static bool blow5_append_records(sqg_blow5* w, const uint8_t* data, const int64_t* ro, const int n, const bool async) {
@@ -212,12 +227,17 @@ static bool blow5_append_records(sqg_blow5* w, const uint8_t* data, const int64_
     auto run = [w, jobs]() {
         std::vector<int> bad(jobs.size(), 0);
         std::vector<std::thread> th;
-        for (size_t j = 1; j < jobs.size(); j++) th.emplace_back([&jobs, &bad, j] { if (!blow5_copy_out(jobs[j].fd, jobs[j].p, jobs[j].n, jobs[j].base)) bad[j] = 1; });
+        for (size_t j = 1; j < jobs.size(); j++) {
+            auto one = [&jobs, &bad, j] { if (!blow5_copy_out(jobs[j].fd, jobs[j].p, jobs[j].n, jobs[j].base)) bad[j] = 1; };
+            try { th.emplace_back(one); } catch (const std::system_error&) { one(); }       // (no thread to be had: this one does it)
+        }
         if (!jobs.empty() && !blow5_copy_out(jobs[0].fd, jobs[0].p, jobs[0].n, jobs[0].base)) bad[0] = 1;
         for (auto& t : th) t.join();
         for (int x : bad) if (x) w->bg_bad = 1;
     };
-    if (async) { w->bg = std::thread(run); return true; }
+    if (async) {
+        try { w->bg = std::thread(run); return true; } catch (const std::system_error&) {}  // (no thread to be had: the write happens here and now)
+    }
     run();
     return w->bg_bad == 0;
 }
@@ -260,7 +280,7 @@ extern "C" int sqg_blow5_write(sqg_blow5_t* w, int32_t n, const char* read_ids, 
         if (nth == 1) frame(0);
         else {
             std::vector<std::thread> th;
-            for (int t = 0; t < nth; t++) th.emplace_back(frame, t);
+            for (int t = 0; t < nth; t++) { try { th.emplace_back(frame, t); } catch (const std::system_error&) { frame(t); } }
             for (auto& t : th) t.join();
         }
         if (!blow5_append_records(w, all.data(), ro.data(), n, /*async=*/false)) {
@@ -289,7 +309,7 @@ extern "C" int sqg_blow5_write(sqg_blow5_t* w, int32_t n, const char* read_ids, 
     if (nth == 1) work(0);
     else {
         std::vector<std::thread> th;
-        for (int t = 0; t < nth; t++) th.emplace_back(work, t);
+        for (int t = 0; t < nth; t++) { try { th.emplace_back(work, t); } catch (const std::system_error&) { work(t); } }
         for (auto& t : th) t.join();
     }
     for (int t = 0; t < nth; t++) if (bad[(size_t)t]) { w->err = "sqg_blow5_write: zlib failed"; return SQG_EINVAL; }   // (nothing written yet)
@@ -314,8 +334,14 @@ extern "C" int sqg_blow5_write_batch(sqg_blow5_t* w, sqg_ctx_t* c, sqg_batch_t* 
     sqg_result_t res;
     int rc = sqg_batch_wait(c, b, &res);
     if (rc) { w->err = sqg_last_error(c); return rc; }
-    if (w->stored) {
+    bool device_frames = w->stored;
+    if (device_frames && read_ids && id_off)
+        for (int i = 0; i < res.n_reads; i++) if (id_off[i + 1] - id_off[i] > B5_ID_MAX) { device_frames = false; break; }
+    // (a read id longer than the framing kernel's LDS header, 4096 bytes: this batch is framed on the host below -- sqg_blow5_write takes ids
+    // up to 65535 bytes in stored mode as well -- instead of failing mid-file)
+    if (device_frames) {
         // the records come framed from the device (sqg_batch_blow5_records): one copy over PCIe, one write
+        if (w->bound && w->bound != c) { blow5_ctx_hook(w, false); blow5_unbind(w); }      // (the writer moves to another context: nothing of the old one is read any more)
         const uint8_t* recs = nullptr; int64_t nb = 0; const int64_t* ro = nullptr;
         unsigned long long run = w->n_samples;
         for (int i = 0; i < res.n_reads; i++) run += (unsigned long long)(res.sig_off[i + 1] - res.sig_off[i]);
@@ -325,6 +351,7 @@ extern "C" int sqg_blow5_write_batch(sqg_blow5_t* w, sqg_ctx_t* c, sqg_batch_t* 
             w->err = std::string("sqg_blow5_write_batch: short write (") + strerror(errno) + "): the file is incomplete";
             return SQG_EIO;
         }
+        if (nb > 0) { w->bound = c; c->b5_reader = w; c->b5_reader_buf = c->b5_flip; c->b5_reader_drain = &blow5_ctx_hook; }
         w->n_bytes += (unsigned long long)nb; w->n_reads += res.n_reads; w->n_samples = run;
         return SQG_OK;
     }
@@ -342,6 +369,7 @@ extern "C" int sqg_blow5_write_batch(sqg_blow5_t* w, sqg_ctx_t* c, sqg_batch_t* 
 extern "C" int sqg_blow5_close(sqg_blow5_t* w, int64_t* n_bytes) {
     if (!w) return SQG_EINVAL;
     if (!blow5_drain(w)) w->failed = true;                            // (stored mode: the last batch's records may still be on their way)
+    blow5_unbind(w);
     int rc = w->failed ? SQG_EIO : SQG_OK;                            // (a failed writer leaves no end marker: the file is not a valid BLOW5)
     unsigned long long total = 0;
     for (size_t q = 0; q < w->sh.size(); q++) {

@@ -199,6 +199,10 @@ struct sqg_ctx {
     int b5_flip = 0;                                           //     them used alternately: a result stays valid over the NEXT call (a writer copies it out behind that call)
     uint8_t* h_b5meta = nullptr; size_t h_b5meta_cap = 0;      // ... pinned staging of the upload
     std::vector<int64_t> b5_rec_off;
+    // a stored-mode writer whose background write still reads h_b5out[b5_reader_buf] (h_blow5.h registers itself here): drained before that
+    // buffer is filled again by anybody, and before the context goes (the thread read memory the writer did not own)
+    void* b5_reader = nullptr; int b5_reader_buf = -1; void (*b5_reader_drain)(void* writer, bool unbind) = nullptr;
+    hipStream_t b5_stream = nullptr;                           // the records' upload, framing kernel and copy back: a stream of their own (not behind the next batch's kernels)
     std::string err;
 };
 

@@ -32,7 +32,9 @@ extern "C" int32_t sqg_worker_of(int32_t i, int32_t n_rec, int32_t T) {
 
 extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
     if (!ctx) return;
+    if (ctx->b5_reader_drain) ctx->b5_reader_drain(ctx->b5_reader, true);       // a writer's background write still reads this context's pinned records: let it finish, unbind
     (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->b5_stream) { (void)hipStreamSynchronize(ctx->b5_stream); (void)hipStreamDestroy(ctx->b5_stream); ctx->b5_stream = nullptr; }
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     if (ctx->fix_stream) (void)hipStreamSynchronize(ctx->fix_stream);
@@ -92,7 +94,7 @@ static int cu_split_streams(sqg_ctx* c, int n_ev, const bool same) {
     if (hipExtStreamCreateWithCUMask(&s_smp, (uint32_t)words, m_smp.data()) != hipSuccess) return SQG_EDEVICE;
     if (same) { c->stream = s_smp; c->stream2 = s_smp; c->num_cu = n_s; }
     else {
-        if (hipExtStreamCreateWithCUMask(&s_ev, (uint32_t)words, m_ev.data()) != hipSuccess) return SQG_EDEVICE;
+        if (hipExtStreamCreateWithCUMask(&s_ev, (uint32_t)words, m_ev.data()) != hipSuccess) { (void)hipStreamDestroy(s_smp); return SQG_EDEVICE; }
         c->stream = s_ev; c->stream2 = s_smp; c->num_cu = n_e;       // (num_cu: what the persistent event-side grids are sized by)
     }
     if (old) { (void)hipStreamSynchronize(old); (void)hipStreamDestroy(old); }

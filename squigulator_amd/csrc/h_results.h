@@ -203,6 +203,11 @@ extern "C" int sqg_batch_blow5_records(sqg_ctx_t* c, sqg_batch_t* b, const sqg_p
         c->h_b5meta_cap = meta + meta / 2;
     }
     const int fl = c->b5_flip ^= 1;
+    if (c->b5_reader_drain && c->b5_reader_buf == fl) c->b5_reader_drain(c->b5_reader, false);   // (a writer's background write still reads this buffer: only when somebody else called in between)
+    if (!c->b5_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->b5_stream, hipStreamNonBlocking));
+    // the encodings are complete (sqg_batch_compress synchronises) and so is the slot's sig_off (the batch was waited for): the framing needs nothing of
+    // the main stream, where the NEXT batch's kernels are queued by now -- a stream of its own, and only that one is waited for
+    const hipStream_t bs = c->b5_stream;
     if (c->h_b5out_cap[fl] < total) {
         if (c->h_b5out[fl]) (void)hipHostFree(c->h_b5out[fl]);
         c->h_b5out[fl] = nullptr; c->h_b5out_cap[fl] = 0;
@@ -217,7 +222,7 @@ extern "C" int sqg_batch_blow5_records(sqg_ctx_t* c, sqg_batch_t* b, const sqg_p
         memcpy(c->h_b5meta + o_md, b->median.data(), (size_t)n * 8);
         memcpy(c->h_b5meta + o_id, read_ids + id_off[0], id_bytes);
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_b5meta, c->h_b5meta, meta, hipMemcpyHostToDevice, c->stream2));
+    HIPCHK(c, hipMemcpyAsync(c->d_b5meta, c->h_b5meta, meta, hipMemcpyHostToDevice, bs));
     Blow5Params P;
     P.svb = c->d_svb; P.svb_off = c->d_svb_off; P.sig_off = c->slot[b->slot].d_sigoff;
     P.id_off = reinterpret_cast<const long long*>(c->d_b5meta + o_io); P.rec_off = reinterpret_cast<const long long*>(c->d_b5meta + o_ro);
@@ -225,10 +230,10 @@ extern "C" int sqg_batch_blow5_records(sqg_ctx_t* c, sqg_batch_t* b, const sqg_p
     P.ids = c->d_b5meta + o_id; P.out = c->d_b5out;
     P.digitisation = profile->digitisation; P.range = profile->range; P.sample_rate = profile->sample_rate;
     P.read_number0 = read_number0; P.start_time0 = start_time0; P.ont = ont ? 1 : 0; P.n = n;
-    hipLaunchKernelGGL(k_blow5_frame, dim3((unsigned)n), dim3(256), 0, c->stream2, P);
+    hipLaunchKernelGGL(k_blow5_frame, dim3((unsigned)n), dim3(256), 0, bs, P);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_b5out[fl], c->d_b5out, total, hipMemcpyDeviceToHost, c->stream2));
-    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    HIPCHK(c, hipMemcpyAsync(c->h_b5out[fl], c->d_b5out, total, hipMemcpyDeviceToHost, bs));
+    HIPCHK(c, hipStreamSynchronize(bs));
     *records = c->h_b5out[fl];
     return SQG_OK;
 }

@@ -62,6 +62,15 @@ __device__ static inline void push_fix_one(const SigParams& P, long long at, uin
 #ifndef SQG_LEAN_XCD
 #define SQG_LEAN_XCD 1                     // A/B: XCD-contiguous item map of k_samples_lean
 #endif
+#ifndef SQG_LEAN_PAIR
+#define SQG_LEAN_PAIR 0                    // round 6: k_samples_lean with TWO consecutive samples per lane -- one aligned dword of the output per lane and step, the
+                                           // arithmetic in v_pk_* fp32 (see "two consecutive samples per lane" in the kernel)
+#endif
+#ifndef SQG_PAIR_ABL
+#define SQG_PAIR_ABL 0                     // timing-only ablations of the pair loop (results are wrong): 1 no drain in front of the last phase, 2 no last phase, 3 no parking
+#endif
+#define PAIR_TB 36                         // steps of 64 pairs an item of <= LEAN_MAX_SAMPLES samples has (33) + the entries read ahead
+typedef float f2_t __attribute__((ext_vector_type(2)));
 #define LEAN_EPL_MAX 4                     // events per lane of the lean kernel: 4, 2 or 1 (SigParams.lean_epl, chosen per profile so
                                            // that a work item -- 64*epl consecutive events of a read -- stays below LEAN_MAX_SAMPLES)
 #define FIX_SLOTS 8                        // parked undecided samples per super tile (expected ~0.5); overflow -> global list
@@ -154,11 +163,18 @@ __device__ unsigned long long g_lean_trace[LEAN_TRACE_SHARDS * 16];      // (a r
 template <int EPL>
 struct LeanWaveLds {
     uint4 rec[64 * EPL];                // {c_ev, (4*first sample) << 16 | I (16 bits), F - 1/2, sdk}
+#if SQG_LEAN_PAIR
+    uint4 tb[PAIR_TB];                  // per step of 64 PAIRS: {x,y: bit p-1-64c set: the event index goes up at pair p; z: the index before the step; w: tb2 != 0}
+#else
     uint4 tb[66];                       // per 64-sample step c: {x,y: bit s-1-64c set: an event (other than the item's first) starts at
                                         // sample s; z: events begun before the step; w: 0}; entries 64, 65 are read ahead, never used
+#endif
     int nfix;                           // undecided samples of the item so far
     int pad[3];
     uint4 park[FIX_SLOTS];              // ... parked here {index in read, c1, event in read, in the level-shift window} until the item is done
+#if SQG_LEAN_PAIR
+    uint2 tb2[PAIR_TB];                 // per step of 64 pairs: the pairs at which the event index advances by TWO (a one-sample event in between)
+#endif
 #if !SQG_LB_BPERM
     uint32_t lb[PART_MAX];              // evrec32: first slot of every partition of the item's link
 #endif
@@ -394,6 +410,175 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
 #pragma unroll
         for (int q = 0; q < LEAN_EPL; q++) lane_total += sps[q];
         const int incl = wave_incl_scan_dpp(lane_total);
+#if SQG_LEAN_PAIR
+        // ---- two consecutive samples per lane (round 6) ----
+        // A lane owns one ALIGNED dword of the output per step: pair p = 64 c + lane holds the samples g0 = 2 p - sh and g1 = g0 + 1 of the item
+        // (generation order; sh: whether the item's first sample sits in the second half of its dword -- then pair 0's first half is not
+        // the item's).  Both samples are computed from the record of the event g0 belongs to: one sample -> event look-up, one record, one
+        // ds_read2 of the jump table, the fp32 arithmetic in v_pk_* (two values per 4-cycle pass), one global_store_dword.  Where an event
+        // STARTS at g1 the second half is wrong (it is the "sample sps" of the event before): the item's last phase recomputes the first sample
+        // of every event that starts on a second half and writes it over, behind an s_waitcnt vmcnt(0) (a wavefront's stores to one
+        // address are then in order).  rec[] here is {F - 1/2, state, sdk, (4 * first sample) << 16 | I}: F and sdk each in the low
+        // half of a 64-bit register pair (v_pk_fma's broadcast form), no copy.
+        static_assert(SQG_NEARONE == 0 && SQG_U2 == 1, "the pair loop restates box_muller_fast's default form");
+        unsigned long long dbl_steps;
+        const uint32_t H_ = (uint32_t)it.sig_base + it.at0;            // (low bits of) the index in sig[] of the item's first sample
+        const int sh = RNA ? (int)(~H_ & 1u) : (int)(H_ & 1u);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // previous item's LDS reads are done
+        if (lane < PAIR_TB) { W.tb[lane] = make_uint4(0u, 0u, 0u, 0u); W.tb2[lane] = make_uint2(0u, 0u); }
+        if (lane == 0) W.nfix = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        {
+            int run = incl - lane_total;
+#pragma unroll
+            for (int q = 0; q < LEAN_EPL; q++) {
+                const int so = run; run += sps[q];
+                const double mk = (double)md[q].x * P.kd - it.offset;
+                const double fl0 = floor(mk);
+                const float Fh = (float)(mk - fl0 - 0.5);
+                const float sdk = (float)((double)md[q].y * P.kd);
+                W.rec[lane * LEAN_EPL + q] = make_uint4(__float_as_uint(Fh), er[q].x, __float_as_uint(sdk),
+                                                        ((uint32_t)so << 18) | ((uint32_t)(int)fl0 & 0xffffu));     // so < 4096
+                if ((e0 + q < ne) && (lane | q) != 0) {
+                    // the first pair whose g0 is in this event or behind it: there the event index of the pairs goes up by one -- by two
+                    // when a one-sample event sits on the second half in front (it is nobody's g0): the second mask
+                    const uint32_t bit = (uint32_t)((so + sh + 1) >> 1) - 1u, m_ = 1u << (bit & 31u);
+                    const uint32_t old_ = atomicOr(reinterpret_cast<unsigned int*>(W.tb) + ((bit >> 6) << 2) + ((bit >> 5) & 1u), m_);
+                    if (old_ & m_) atomicOr(reinterpret_cast<unsigned int*>(W.tb2) + ((bit >> 6) << 1) + ((bit >> 5) & 1u), m_);
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        {   // the event index before each step
+            const uint4 mine = lane < PAIR_TB ? W.tb[lane] : make_uint4(0u, 0u, 0u, 0u);
+            const uint2 m2 = lane < PAIR_TB ? W.tb2[lane] : make_uint2(0u, 0u);
+            const int pc = __builtin_popcount(mine.x) + __builtin_popcount(mine.y) + __builtin_popcount(m2.x) + __builtin_popcount(m2.y);
+            const uint32_t z_ = (uint32_t)(wave_incl_scan_dpp(pc) - pc);
+            if (lane < PAIR_TB) W.tb[lane].z = z_;
+            dbl_steps = __builtin_amdgcn_ballot_w64((m2.x | m2.y) != 0u);       // (bit c: step c has a pair at which the index goes up by two -- an SGPR pair: the loop's test is scalar)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        char* const out_b = reinterpret_cast<char*>(P.sig + it.sig_base);               // wave-uniform: global_store saddr + 32-bit lane offset
+        const int n_s = wave_total;
+        const int np_ = (n_s + sh + 1) >> 1;                           // pairs of the item
+        // byte offset (from out_b) of my dword of step 0: DNA 2 (at0 - sh) + 4 p, g0 in the low half; RNA 2 (at0 + sh - 1) - 4 p, g0 in the high half
+        uint32_t voff = RNA ? 2u * (it.at0 + (uint32_t)sh - 1u) - 4u * (uint32_t)lane : 2u * (it.at0 - (uint32_t)sh) + 4u * (uint32_t)lane;
+        uint32_t idx4 = 4u * (2u * (uint32_t)lane - (uint32_t)sh);    // 4 * g0 of the current group's first step
+        const uint32_t near_lim = LCG_M - (1u << NEAR_ONE_BITS);
+        #define PAIR_EVOF(tq_, t2p_, step_) ({ int e__ = (int)__builtin_amdgcn_mbcnt_hi((tq_).y, __builtin_amdgcn_mbcnt_lo((tq_).x, (tq_).z));       \
+            if ((dbl_steps >> (step_)) & 1ull) { const uint2 m2__ = *(t2p_);                                                                      \
+                e__ = (int)__builtin_amdgcn_mbcnt_hi(m2__.y, __builtin_amdgcn_mbcnt_lo(m2__.x, (uint32_t)e__)); }                                \
+            e__; })
+        // an undecided sample (g_, c1_) of event EV_ joins the item's parked samples (as in the one-sample loop)
+        #define PAIR_PARK(cond_, g_, c1_, shf_, EV_) if (cond_) {                                                                                 \
+                const unsigned long long am = __builtin_amdgcn_ballot_w64(true);                                                                  \
+                const int n0 = W.nfix;                                                                                                            \
+                const int slot = n0 + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));          \
+                const uint32_t at_ = RNA ? it.at0 - (uint32_t)(g_) : it.at0 + (uint32_t)(g_);                                                     \
+                if (slot < FIX_SLOTS) W.park[slot] = make_uint4(at_, c1_, (uint32_t)(EV_), (shf_) ? 1u : 0u);                                      \
+                else push_fix_one(P, it.sig_base + at_, c1_, it.ev_first + (EV_), it.read, (shf_) ? 1 : 0);                                       \
+                if (slot + 1 == n0 + __popcll(am)) W.nfix = slot + 1;                                                                             \
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");                                                                            \
+            }
+        // one step of 64 pairs: the loads of the next step into (RN, N0, N1, EN) and the table entry behind it into TQN, then the arithmetic of
+        // this one from (RA, M0, M1, EV).  DI: the step's place in its group of two (idx4, voff and the table pointers advance once per group).
+        // EDGE: the item's first step when sh (pair 0's first half is not the item's) and its last, partial one.
+        #define PAIR_STEP(SH, EDGE, DI, RA, M0, M1, EV, RN, N0, N1, EN, TQ, TQN) {                                                                 \
+            EN = PAIR_EVOF(TQ, tb2p + 1 + (DI), c + 1 + (DI));                                                                                                \
+            RN = W.rec[EN];                                                                                                                       \
+            TQN = tbp[2 + (DI)];                                                                                                                  \
+            const uint32_t c1a = lcg_mul_dbl(RA.y, M0), c1b = lcg_mul_dbl(RA.y, M1);                                                              \
+            const f2_t uf0 = {(float)c1a, (float)c1b};                                                                                            \
+            const f2_t uf = uf0 * 4.656612873077393e-10f;                                                                                         \
+            const f2_t lg = {__builtin_amdgcn_logf(uf.x), __builtin_amdgcn_logf(uf.y)};                                                           \
+            const f2_t yy = __builtin_elementwise_fma(lg, (f2_t)(-1.3862943611198906f), (f2_t)(-9.313225750491594e-10f));                          \
+            const f2_t rr = {__builtin_amdgcn_sqrtf(yy.x), __builtin_amdgcn_sqrtf(yy.y)};                                                         \
+            const f2_t pf = {(float)(int)(c1a * 16807u), (float)(int)(c1b * 16807u)};                                                             \
+            const f2_t t2 = __builtin_elementwise_fma(pf, (f2_t)(4.656612873077393e-10f), uf * 7.826369259425611e-06f);                            \
+            const f2_t cs = {__builtin_amdgcn_cosf(t2.x), __builtin_amdgcn_cosf(t2.y)};                                                           \
+            const f2_t xx = rr * cs;                                                                                                              \
+            const f2_t vh = __builtin_elementwise_fma(xx, (f2_t)(__uint_as_float(RA.z)), (f2_t)(__uint_as_float(RA.x)));                          \
+            const f2_t tt = vh + LEAN_MAGIC;                                                                                                      \
+            const f2_t dd = vh - (tt - LEAN_MAGIC);                                                                                               \
+            const bool okp = fmaxf(fabsf(dd.x), fabsf(dd.y)) < thr && max(c1a, c1b) <= near_lim;                                                  \
+            const int g0 = ((EDGE) || (SH)) ? ((int)idx4 >> 2) + 128 * (DI) : 2 * (64 * (c + (DI)) + lane) - sh;   /* (the second form: scalars + lane, only the rare branch uses it) */ \
+            const bool shfa = (SH) && (uint32_t)(g0 - it.shift_lo) < (uint32_t)(it.shift_hi - it.shift_lo);                                       \
+            const bool shfb = (SH) && (uint32_t)(g0 + 1 - it.shift_lo) < (uint32_t)(it.shift_hi - it.shift_lo);                                   \
+            const uint32_t va = __float_as_uint(tt.x) + RA.w - (shfa ? (uint32_t)P.shift : 0u);                                                   \
+            const uint32_t vb = __float_as_uint(tt.y) + RA.w - (shfb ? (uint32_t)P.shift : 0u);                                                   \
+            const uint32_t pk = RNA ? __builtin_amdgcn_perm(va, vb, 0x05040100u) : __builtin_amdgcn_perm(vb, va, 0x05040100u);                    \
+            char* const dst_b = out_b + (RNA ? -256 * (DI) : 256 * (DI));                                                                         \
+            bool real_a = true, real_b = true;                                                                                                    \
+            if (EDGE) {                                                                                                                           \
+                real_a = g0 >= 0 && g0 < n_s; real_b = g0 >= 0 && g0 + 1 < n_s;                                                                   \
+                if (real_b) *reinterpret_cast<uint32_t*>(dst_b + voff) = pk;                                                                      \
+                else if (real_a) *reinterpret_cast<uint16_t*>(out_b + 2u * (RNA ? it.at0 - (uint32_t)g0 : it.at0 + (uint32_t)g0)) = (uint16_t)va; \
+            } else *reinterpret_cast<uint32_t*>(dst_b + voff) = pk;                                                                               \
+            if (SQG_PAIR_ABL != 3 && !okp && (real_a || real_b)) { /* ~2 % of the steps: which half, and is it mine */                            \
+                const int ev_ = EV;                                                                                                               \
+                const bool bad_a = real_a && !(fabsf(dd.x) < thr && c1a <= near_lim);                                                             \
+                bool bad_b = real_b && !(fabsf(dd.y) < thr && c1b <= near_lim);                                                                   \
+                if (bad_b && ev_ + 1 < ne && (int)(W.rec[ev_ + 1].w >> 18) <= g0 + 1) bad_b = false;   /* the next event's: the last phase makes it */ \
+                PAIR_PARK(bad_a, g0, c1a, shfa, ev_)                                                                                              \
+                PAIR_PARK(bad_b, g0 + 1, c1b, shfb, ev_)                                                                                          \
+            }                                                                                                                                     \
+            if ((DI) == 1) { idx4 += 1024u; voff = RNA ? voff - 512u : voff + 512u; tbp += 2; tb2p += 2; }                                        \
+            { const uint32_t* mp_ = reinterpret_cast<const uint32_t*>(mult_b + ((DI) == 1 ? 0 : 512) + (idx4 - (RN.w >> 16)));                    \
+              N0 = mp_[0]; N1 = mp_[1]; } }
+        #define PAIR_B_TO_A { ra = rb; ma0 = mb0; ma1 = mb1; eva = evb; tqa = tqb; idx4 += 512u; voff = RNA ? voff - 256u : voff + 256u; tbp += 1; tb2p += 1; }
+        LEAN_T(tr_e);
+        uint4 ra, rb, tqa, tqb; uint32_t ma0, ma1, mb0, mb1; int eva, evb;
+        const uint4* tbp = W.tb;                                        // table entry of the current group's first step
+        const uint2* tb2p = W.tb2;
+        {
+            const uint4 tq0 = tbp[0];
+            eva = PAIR_EVOF(tq0, tb2p, 0);
+        }
+        ra = W.rec[eva];
+        tqa = tbp[1];
+        { const uint32_t* mp_ = reinterpret_cast<const uint32_t*>(mult_b + (idx4 - (ra.w >> 16))); ma0 = mp_[0]; ma1 = mp_[1]; }
+        int c = 0;                                                     // the current group's first step (scalar)
+        const int nfull = (np_ - 1) >> 6, rem = np_ - 64 * nfull;      // the last step (1..64 pairs) always runs as EDGE: its last pair's second half may be the next item's
+        #define PAIR_LOOP(SH)                                                                                       \
+            if (sh && nfull > 0) { PAIR_STEP(SH, true, 0, ra, ma0, ma1, eva, rb, mb0, mb1, evb, tqa, tqb) PAIR_B_TO_A c = 1; }   \
+            for (; c + 2 <= nfull; c += 2) {                                                                        \
+                PAIR_STEP(SH, false, 0, ra, ma0, ma1, eva, rb, mb0, mb1, evb, tqa, tqb)                             \
+                PAIR_STEP(SH, false, 1, rb, mb0, mb1, evb, ra, ma0, ma1, eva, tqb, tqa)                             \
+            }                                                                                                       \
+            if (c < nfull) { PAIR_STEP(SH, false, 0, ra, ma0, ma1, eva, rb, mb0, mb1, evb, tqa, tqb) PAIR_B_TO_A c++; }           \
+            if (rem) PAIR_STEP(SH, true, 0, ra, ma0, ma1, eva, rb, mb0, mb1, evb, tqa, tqb)
+        if (RNA && it.shift_hi > it.shift_lo) { PAIR_LOOP(true) } else { PAIR_LOOP(false) }
+        #undef PAIR_LOOP
+        #undef PAIR_STEP
+        #undef PAIR_B_TO_A
+        #undef PAIR_EVOF
+        // the last phase: the first sample of every event that starts on the second half of a dword (for the item's first event: when sh) --
+        // one sample as the one-sample loop makes it, a short store over the pair's second half once the dword stores have landed
+#if SQG_PAIR_ABL != 1 && SQG_PAIR_ABL != 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#pragma unroll
+        for (int q = 0; q < LEAN_EPL; q++) {
+            const int e = lane + 64 * q;
+            if (SQG_PAIR_ABL != 2 && e < ne) {
+                const uint4 r_ = W.rec[e];
+                const int so = (int)(r_.w >> 18);
+                if ((so + sh) & 1) {
+                    const uint32_t c1 = lcg_mul_dbl(r_.y, L.mult[0]);
+                    const float x = box_muller_fast(c1);
+                    const float vh = __builtin_fmaf(x, __uint_as_float(r_.z), __uint_as_float(r_.x));
+                    const float t = vh + LEAN_MAGIC;
+                    const float d = vh - (t - LEAN_MAGIC);
+                    const bool shf = RNA && (uint32_t)(so - it.shift_lo) < (uint32_t)(it.shift_hi - it.shift_lo);
+                    const uint32_t at_ = RNA ? it.at0 - (uint32_t)so : it.at0 + (uint32_t)so;
+                    if (fabsf(d) < thr && c1 <= near_lim)
+                        *reinterpret_cast<uint16_t*>(out_b + 2u * at_) = (uint16_t)((__float_as_uint(t) + r_.w - (shf ? (uint32_t)P.shift : 0u)) & 0xffffu);
+                    else push_fix_one(P, it.sig_base + at_, c1, it.ev_first + e, it.read, shf ? 1 : 0);
+                }
+            }
+        }
+        #undef PAIR_PARK
+#else
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // previous item's LDS reads are done
         W.tb[lane] = make_uint4(0u, 0u, 0u, 0u);
         if (lane == 0) W.nfix = 0;
@@ -535,6 +720,7 @@ __global__ __launch_bounds__(256) void k_samples_lean(const SigParams P, const i
         #undef LEAN_STORE_STMT
         #undef LEAN_STORE_VAL
         #undef LEAN_NEARONE_TEST
+#endif
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         LEAN_T(tr_f);
         // the item's parked samples (every other item has one: 4.5e-4 of the samples) join one of the batch's FIX_SHARDS lists for k_fixup: ONE returning

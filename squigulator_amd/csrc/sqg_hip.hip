@@ -22,6 +22,7 @@
 #include <new>
 #include <set>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 

@@ -388,3 +388,37 @@ def test_device_framed_records_on_four_files(tmp_path):
     assert n4 == n1 + 3 * (68 + len(hdr1) + 5)                      # (three more headers and end markers)
     d = [ref_dump(q, "hash") for q in w4.paths]
     assert d[0] is None or sum(int(x.strip().splitlines()[-1].split("\t")[1]) for x in d) == nread
+
+
+# ---- the stored-mode writer and the context it reads from ----------------------------------------------------------------
+@pytest.mark.gpu
+def test_stored_writer_takes_a_batch_with_an_over_long_id_and_survives_its_context(tmp_path):
+    """(1) a read id longer than the framing kernel's 4096-byte header does not fail the batch mid-file: that batch is framed on the host
+    (sqg_blow5_write's stored path, ids up to 65535 bytes), the file holds the same records as an all-host stored file;
+    (2) the context may be destroyed before the writer is closed -- the background write of the last batch reads the CONTEXT's pinned
+    buffer: sqg_destroy drains and unbinds the writer first -- and the file is complete"""
+    import bench
+    prof, fl = profiles.get_profile("dna-r10-prom")
+    mean, stdv = model.synthetic_model(9)
+    gen = api.SignalGenerator(prof, fl, 9, mean, stdv, 42, num_workers=1, mode=api.MODE_CERTIFIED)
+    gen.load_genome(bench.synthetic_genome_host(8.0), 4000, api.SAMPLE_DNA)
+    pd, ph = str(tmp_path / "d.blow5"), str(tmp_path / "h.blow5")
+    wd = api.Blow5Writer(pd, prof, fl, threads=2, stored=True)
+    wh = api.Blow5Writer(ph, prof, fl, threads=2, stored=True)
+    for bi in range(3):
+        b = gen.sample(96).run().wait()
+        ids = [b"S1_%d_%d!c!0!1!+" % (bi, i) for i in range(b.n_reads)]
+        if bi == 1:
+            ids[7] = b"L" * 5000                                  # > B5_ID_MAX: this batch goes through the host framing
+        enc, eo = b.compress()
+        wh.write(ids, b.offset, b.median_before, b.sig_off, enc, eo)
+        wd.write_batch(b, ids)
+        b.free()
+    gen.close()                                                   # the context goes first: the last batch's records are still being written
+    nd = wd.close()
+    wh.close()
+    dev, host = open(pd, "rb").read(), open(ph, "rb").read()
+    assert nd == len(dev) and dev == host
+    _stored_records_are_valid(dev)
+    _, recs = parse_blow5(dev)
+    assert len(recs) == 3 * 96 and struct.unpack_from("<H", recs[96 + 7], 0)[0] == 5000
