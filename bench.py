@@ -29,6 +29,7 @@ physical core, read loop only (kind "reference"); the oracle restatement (kind "
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import shutil
@@ -658,6 +659,34 @@ def parity_check(prof, flags, k, mean, stdv, contigs, rlen, n_reads, one_worker,
     return out, rate
 
 
+def parity_check_rank(prof, flags, k, mean, stdv, contigs, rlen, T, w_lo, w_hi, per_worker, mode, device):
+    """N > 1: THIS rank's shard against the oracle's run of the WHOLE job, so that the first real multi-GPU run certifies itself.
+    A small job of the bench's regime -- T virtual workers, two batches of per_worker * T host-drawn reads, the reference's static partition
+    (src/thread.c:84-101) -- goes through the oracle with all T workers on every rank (the same seeded reads everywhere); a fresh context that owns
+    the workers [w_lo, w_hi) of T, as this rank's bench context does, generates their reads; every int16 compared, two batches (carried state).
+    Returns [reads differing, reads, samples, a 62-bit digest of the rank's signals]."""
+    rng = np.random.default_rng(4321)
+    n_b = per_worker * T
+    batches = [sample_reads_host(contigs, n_b, rlen, rng) for _ in range(2)]
+    res, _ = cpu_port(prof, flags & ~profiles.SQ_ORDER_FREE, k, mean, stdv, batches, T, nthreads=max(1, min(4, (os.cpu_count() or 1))))
+    gen = api.SignalGenerator(prof, flags, k, mean, stdv, seed=42, num_workers=T, device=device, mode=mode, worker_lo=w_lo, worker_hi=w_hi)
+    bad = n = ns = 0
+    h = hashlib.sha256()
+    for reads, want in zip(batches, res):
+        mine = [i for i, r in enumerate(want) if w_lo <= r.tid < w_hi]
+        b = gen.stage([reads[i] for i in mine], np.array([want[i].tid for i in mine], np.int32)).run().wait()
+        sig = b.signal()
+        for j, i in enumerate(mine):
+            got = sig[b.sig_off[j]:b.sig_off[j + 1]]
+            if len(got) != len(want[i].sig) or not np.array_equal(got, want[i].sig):
+                bad += 1
+        h.update(sig.tobytes())
+        n += len(mine); ns += int(b.n_samples)
+        b.free()
+    gen.close()
+    return [bad, n, ns, int.from_bytes(h.digest()[:8], "little") >> 2]
+
+
 def pipeline_leg(stage_one, run, n_batches, seconds=None, max_batches=40000):
     """Nothing staged ahead but the batch behind the one being queued: ONE host thread samples + stages batch i+2 (device-side gen_read,
     descriptors, links), queues batch i+1 -- the library lets the first event pass of the staged batch behind it ride along with its
@@ -782,6 +811,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall time of each multi-process CPU leg")
     ap.add_argument("--no-store-probe", action="store_true")
+    ap.add_argument("--no-rank-parity", action="store_true", help="N > 1: skip the per-rank comparison of every rank's shard with the oracle (`parity_check_ranks` in the line)")
     ap.add_argument("--live-traffic", default="auto", choices=["auto", "on", "off"],
                     help="roofline.traffic measured by two rocprofv3 --pmc child passes of this script on this box (auto: with the CPU legs, "
                          "i.e. the default single-GPU run; the hash-matched profiles/traffic_latest.json is quoted otherwise)")
@@ -1179,6 +1209,19 @@ def main():
         dist.all_reduce(hst, op=dist.ReduceOp.MAX)                  # the slowest and (negated) the fastest rank's host time per batch
     host_stage_max, host_stage_min = float(hst[0]), -float(hst[1])
 
+    # N > 1: every rank checks its own shard against the oracle (worker sharding; range sharding's exchange is tests/test_range_sharding.py's)
+    rank_parity = None
+    if use_dist and world > 1 and not range_mode and not args.no_rank_parity:
+        pc_contigs = host_contigs if host_contigs is not None else synthetic_genome_host(8.0)
+        per_worker = 4 if W else 1
+        Tp = T if W else 16 * world                                # (T = K: sixteen one-read workers per rank instead of K)
+        lo_p, hi_p = (w_lo, w_hi) if W else shard.worker_range(rank, world, Tp)
+        mine = parity_check_rank(prof, flags, k, mean, stdv, pc_contigs, min(args.rlen, 4000), Tp, lo_p, hi_p, per_worker, amode, local_rank)
+        t_me = torch.tensor(mine, dtype=torch.int64, device="cuda" if (on_gpu and args.backend == "nccl") else "cpu")
+        t_all = [torch.zeros_like(t_me) for _ in range(world)]
+        dist.all_gather(t_all, t_me)
+        rank_parity = [[int(x) for x in t.cpu().tolist()] for t in t_all]
+
     if rank == 0:
         steps = max(args.steps, 1)
         alg_bytes = (2 * samples + bases + 24 * reads) / steps           # per k_samples_lean launch (this rank)
@@ -1302,6 +1345,11 @@ def main():
             out["roofline"]["bound"] = out["roofline"]["resources"]["bound"]
         if digests:
             out["digest"] = digests
+        if rank_parity is not None:
+            out["parity_check_ranks"] = {"equal": all(r[0] == 0 and r[1] > 0 for r in rank_parity), "reads_differing": [r[0] for r in rank_parity],
+                                         "reads": [r[1] for r in rank_parity], "samples": [r[2] for r in rank_parity], "digest": ["%016x" % r[3] for r in rank_parity],
+                                         "what": "every rank: its own workers' reads of a small job of this regime (two batches, carried state) against the oracle's run of "
+                                                 "the whole job, every int16 (bench.parity_check_rank)"}
         if args.no_cpu_baseline or world > 1:
             out["cpu_baseline"] = None                       # the CPU legs: single-GPU run only
         else:

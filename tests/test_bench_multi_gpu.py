@@ -49,6 +49,12 @@ def test_two_ranks_equal_one(name, single, dual):
     n2 = two["value"] * two["ms_per_step"] * 1e-3 * two["steps"]
     assert abs(n1 - n2) <= 1e-6 * n1
     assert two["reads_per_s"] * two["ms_per_step"] * 1e-3 * two["steps"] == pytest.approx(2 * one["config"]["reads_per_step_per_gpu"], rel=1e-6)
+    # every rank checked its own shard against the oracle's run of the whole job (worker sharding; bench.parity_check_rank)
+    if "by_range" not in name:
+        pr = two["parity_check_ranks"]
+        assert pr["equal"] is True and pr["reads_differing"] == [0, 0] and all(n > 0 for n in pr["reads"]) and len(set(pr["digest"])) == 2
+    else:
+        assert "parity_check_ranks" not in two
 
 
 @pytest.mark.gpu
@@ -68,6 +74,9 @@ def test_eight_ranks_equal_one(name, single, eight):
     assert many["n_gpus"] == 8 and many["ranks"]["world_size"] == 8 and len(many["digest"]) == 2 and len(many["digest"][0]) == 8
     assert one["digest"] == many["digest"], (one["digest"], many["digest"])
     assert many["reads_per_s"] * many["ms_per_step"] * 1e-3 * many["steps"] == pytest.approx(2 * 2048, rel=1e-6)
+    if name == "r10_by_worker":
+        pr = many["parity_check_ranks"]                              # eight ranks, each its own worker of -t 8 against the oracle's -t 8 run
+        assert pr["equal"] is True and pr["reads_differing"] == [0] * 8 and pr["reads"] == [8] * 8 and len(set(pr["digest"])) == 8
 
 
 @pytest.mark.gpu
