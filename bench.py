@@ -256,6 +256,12 @@ def resources_from(kk, cal, kernel_ms, samples_per_launch, store_peak_GBps, sour
         cands = {"valu": out["valu_busy"], "l2_requests": out["l2_req_frac"], "stores": out["store_frac"], "hbm": out["hbm_frac"]}
         cands = {k: v for k, v in cands.items() if v is not None}
         out["bound"] = max(cands, key=cands.get)
+        # what `valu_busy` is and is not: cycles in which the SIMDs hold a VALU instruction in flight, over the launch's cycles.  It names the
+        # largest share, not a proven limiter: a build of the same kernel with 21 % fewer VALU instructions per sample (two samples per lane,
+        # -DSQG_LEAN_PAIR=1 without its last phase) takes the same time (profiles/r06_pair.md) -- the memory pipeline (the signal stream at
+        # the box's store rate + one pore-table row and one stream state per event) stands right behind it
+        out["bound_caveat"] = ("largest share of the four, not a proven limiter: 21 % fewer VALU instructions per sample leave the kernel's time "
+                               "unchanged (profiles/r06_pair.md); the memory pipeline -- stores at the box's rate + per-event gathers -- is right behind")
         return out
     except (KeyError, ValueError, ZeroDivisionError, TypeError):
         return None
