@@ -10,13 +10,13 @@ workload `configs` names.  Each config is checked twice:
     of its dwells, `-t 1` does not know the batch size, a rank's shard is the same reads as the whole job's.
 
 No clocks, no rates: deterministic comparisons only (the reference's bar: scripts/test.sh:24-139)."""
-import hashlib
 import os
 import subprocess
 import sys
 
 import numpy as np
 import pytest
+import xxhash
 
 import hiprun
 import orc
@@ -68,7 +68,7 @@ def _job_digest(profile, k, contigs, T, n, K, rlen, gen_mode, sflags=0, mode=api
     mean, stdv = model.synthetic_model(k)
     gen = api.SignalGenerator(prof, fl | sflags, k, mean, stdv, seed, num_workers=T, mode=gen_mode)
     gen.load_genome(contigs, rlen, mode, None)
-    h = hashlib.sha256()
+    h = xxhash.xxh3_128()                                        # (14 GB of int16 per mode at configs[1]'s size: sha256 would be most of the test's time)
     done = samples = 0
     while done < n:
         nb = min(K, n - done)

@@ -139,7 +139,7 @@ def test_bench_line_carries_the_contract():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--genome-mb", "24",
-                        "--batch-reads", "1024", "--cpu-seconds", "1"], capture_output=True, text=True, timeout=900, env=env)
+                        "--batch-reads", "1024", "--cpu-seconds", "1", "--pipeline-seconds", "0.5", "--e2e-seconds", "0.3", "--small-batch-seconds", "0.3"], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -314,7 +314,7 @@ def test_bench_other_workloads(workload, profile, regime):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "3", "--warmup", "1",
-                        "--batch-reads", "2048", "--cpu-seconds", "1", "--pipeline-seconds", "0.2"], capture_output=True, text=True, timeout=900, env=env)
+                        "--batch-reads", "2048", "--cpu-seconds", "1", "--pipeline-seconds", "0.2", "--e2e-seconds", "0", "--small-batch-seconds", "0"], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert profile in d["config"]["workload"] and d["value"] > 0 and d["pipeline"]["value"] > 0
