@@ -168,7 +168,12 @@ int  sqg_batch_stage(sqg_ctx_t *ctx, int32_t n_reads, const char *seqs,
  * run waits for the context's stream (the pass may still be reading the batch's memory); (2) sqg_get_timing attributes that pass to
  * the batch whose launch sequence carried it: events_ms of batch i holds batch i+1's first pass, and batch i+1's own events_ms does
  * not (sqg_timing_t.carried_first_pass / .first_pass_ran_ahead say which batches that applies to).  The pass is best effort: if a
- * buffer it needs cannot be had, the batch behind simply counts for itself. */
+ * buffer it needs cannot be had, the batch behind simply counts for itself.
+ *
+ * Placement calibration: the first twelve batches of a context with >= 2^24 events each are also used to place the event records -- the scatter
+ * pass is timed (one host synchronisation per such batch) on up to three more allocations per buffer set and the fastest is kept; results
+ * are not affected.  A host that times its first batches sees it; run a dozen batches before measuring.
+ */
 int  sqg_batch_run(sqg_ctx_t *ctx, sqg_batch_t *b);
 /* Block until the batch has finished; fills *res. */
 int  sqg_batch_wait(sqg_ctx_t *ctx, sqg_batch_t *b, sqg_result_t *res);

@@ -90,7 +90,7 @@ DEV_KNOBS = ("SQG_SEPARATE_DWELL", "SQG_EVENTS_WIDE_MAX", "SQG_MID_SPLIT", "SQG_
              "SQG_LEAN_DYNLDS", "SQG_FIX_INLINE", "SQG_ABL_NOFIX", "SQG_SAMPLER_SERIAL", "SQG_OVERLAP", "SQG_PART_CLAIMS",
              "SQG_TEST_DELTA_X", "SQG_LEAN_EPL", "SQG_TEST_ROW_TURNS", "SQG_PART_WG_EVENTS", "SQG_SPLIT_CHAINS", "SQG_NO_PART",
              "SQG_PART_SLICE", "SQG_TEST_NO_LEAN", "SQG_STAGE_THREADS", "SQG_NO_PRECOUNT", "SQG_PHC_ABL", "SQG_PHC_GRID", "SQG_NO_DRAW_AHEAD",
-             "SQG_CU_SPLIT", "SQG_NO_FOLD", "SQG_NO_WHOLE_LINKS")
+             "SQG_CU_SPLIT", "SQG_NO_FOLD", "SQG_NO_WHOLE_LINKS", "SQG_NO_PLACE")
 
 _libs = {}                  # absolute path -> loaded library
 LOADED_PATH = None          # the library the last load_library() call opened (bench.py prints it with its hash)

@@ -121,6 +121,10 @@ struct sqg_ctx {
         int* d_tile_link = nullptr; size_t tile_link_cap = 0;       // [n_tiles] the link of every 64-event tile (same)
         uint32_t* d_part_state = nullptr; size_t part_state_cap = 0;   // [n_events] k > 6, split chains (k_part.h): stream state at each
                                                                     // bucketed event; read by the sample kernels like evrec
+        // placement calibration (h_run.h, place_calibrate): the scatter pass of the slot's previous batch between two events, how often `evrec` was
+        // allocated anew, the last measurement
+        hipEvent_t cal_a = nullptr, cal_b = nullptr; bool cal_pending = false; long long cal_events = 0; int cal_tries = 0; float cal_ps = 0.f;
+        uint2* cal_prev = nullptr; float cal_prev_ps = 0.f;   // the allocation before the candidate, until the candidate has been measured
         unsigned long long gen = 0;                // bumped whenever a batch starts writing the slot's buffers
         hipEvent_t done = nullptr;                 // recorded after the slot's last kernel (fix-ups included)
         hipEvent_t sampled = nullptr;              // recorded on stream2 after the slot's sample kernels, before the fix-ups
@@ -201,6 +205,9 @@ struct sqg_ctx {
     std::vector<int64_t> b5_rec_off;
     // a stored-mode writer whose background write still reads h_b5out[b5_reader_buf] (h_blow5.h registers itself here): drained before that
     // buffer is filled again by anybody, and before the context goes (the thread read memory the writer did not own)
+    // placement calibration: the scatter pass runs in one of several modes (825 ... 1130 us per 32768 10-kb reads) for the life of a slot's `evrec` allocation
+    // (profiles/r05_summary.md); the first large batches of a context time the pass itself on three more allocations per slot and keep the best
+    int cal_runs_left = 12;
     void* b5_reader = nullptr; int b5_reader_buf = -1; void (*b5_reader_drain)(void* writer, bool unbind) = nullptr;
     hipStream_t b5_stream = nullptr;                           // the records' upload, framing kernel and copy back: a stream of their own (not behind the next batch's kernels)
     std::string err;

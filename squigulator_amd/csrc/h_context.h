@@ -62,6 +62,9 @@ extern "C" void sqg_destroy(sqg_ctx_t* ctx) {
         (void)hipFree(S.d_fix); (void)hipFree(S.d_fix_count); (void)hipFree(S.d_fix_sh); (void)hipFree(S.d_fix_sh_count);
         (void)hipFree(S.d_evrec); (void)hipFree(S.d_slow);
         (void)hipFree(S.d_items); (void)hipFree(S.d_part_state); (void)hipFree(S.d_part); (void)hipFree(S.d_lbase); (void)hipFree(S.d_tile_link);
+        (void)hipFree(S.cal_prev);
+        if (S.cal_a) (void)hipEventDestroy(S.cal_a);
+        if (S.cal_b) (void)hipEventDestroy(S.cal_b);
         if (S.done) (void)hipEventDestroy(S.done);
         if (S.sampled) (void)hipEventDestroy(S.sampled);
     }

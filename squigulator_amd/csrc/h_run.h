@@ -236,6 +236,50 @@ static void launch_part_events(Run& R, const int dwm, const bool count) {
     else if (dwm == 1) hipLaunchKernelGGL((k_part_events<1, PEV_COUNT>), g, t, 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
     else hipLaunchKernelGGL((k_part_events<2, PEV_COUNT>), g, t, 0, c->stream, P, b->n_chains, (uint32_t)b->n_events);
 }
+// Placement calibration.  The scatter pass writes two arrays at once -- part[] in 64-byte runs at ~4000 places, evrec32 as one
+// stream per link -- and runs in one of several modes (825 / 890 / 1000-1130 us per 32768 10-kb reads) for the life of a slot's buffers: which one is
+// decided by where hipMalloc put `evrec` relative to the slot's part[] (physical pages: nothing a virtual address shows, and no probe kernel
+// reproduces the pass' own mode; profiles/r05_summary.md).  So the pass itself is the probe: over the first twelve large batches of a context it is
+// timed between two events, and each slot tries PLACE_TRIES more allocations of `evrec`, one per run, keeping the one the pass ran fastest on
+// (the previous one stays allocated until the candidate has been measured: never worse than where it started).  Costs those batches a host
+// synchronisation each; changes no result (the scatter pass writes every entry the sample kernels read).  SQG_NO_PLACE=1 (development build) turns it off.
+#define PLACE_TRIES 3
+static int place_calibrate(Run& R) {
+    sqg_ctx* c = R.c; sqg_batch* b = R.b; sqg_ctx::Slot& S = *R.S;
+    static const bool off = SQG_DEV_ENV("SQG_NO_PLACE") != nullptr;
+    if (off || c->cal_runs_left <= 0 || !R.wave_links || !R.P.evrec32 || b->n_events < (1ll << 24)) return SQG_OK;   // (small batches: microseconds, nothing to gain)
+    if (!S.cal_a) { HIPCHK(c, hipEventCreate(&S.cal_a)); HIPCHK(c, hipEventCreate(&S.cal_b)); }
+    if (S.cal_pending) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventSynchronize(S.cal_b));
+        HIPCHK(c, hipEventElapsedTime(&ms, S.cal_a, S.cal_b));
+        S.cal_pending = false;
+        float ps = ms * 1.0e9f / (float)S.cal_events;                // picoseconds per event: ~2.5-2.7 in the fast modes, 3.0-3.4 in the slow ones
+        const char* what = "";
+        if (S.cal_prev) {                                             // a candidate was measured: keep the better of the two
+            if (ps > S.cal_prev_ps) {
+                HIPCHK(c, hipEventSynchronize(S.done));               // (the slot's previous batch has read the candidate)
+                HIPCHK(c, hipFree(S.d_evrec));
+                S.d_evrec = S.cal_prev; ps = S.cal_prev_ps; what = ": slower than the allocation before it, which is taken back";
+                R.P.evrec = S.d_evrec; R.P.evrec32 = reinterpret_cast<uint32_t*>(S.d_evrec);
+            } else { HIPCHK(c, hipFree(S.cal_prev)); what = ": kept"; }
+            S.cal_prev = nullptr;
+        }
+        S.cal_ps = ps;
+        if (getenv("SQG_VERBOSE")) fprintf(stderr, "[sqg] placement: slot %d scatter pass %.0f us = %.3f ps per event%s\n", b->slot, ms * 1.0e3f, ms * 1.0e9f / (float)S.cal_events, what);
+        if (S.cal_tries < PLACE_TRIES && c->cal_runs_left >= 3 && S.d_evrec && S.evrec_cap) {   // (>= 3: this slot runs once more inside the calibration, to measure the candidate)
+            uint2* fresh = nullptr;
+            if (hipMalloc(&fresh, S.evrec_cap * sizeof(uint2)) == hipSuccess) {         // (no memory for a second copy: stay where we are)
+                S.cal_prev = S.d_evrec; S.cal_prev_ps = S.cal_ps;
+                S.d_evrec = fresh; S.cal_tries++;
+                R.P.evrec = S.d_evrec; R.P.evrec32 = reinterpret_cast<uint32_t*>(S.d_evrec);
+            } else (void)hipGetLastError();
+        }
+    }
+    c->cal_runs_left--;
+    return SQG_OK;
+}
+
 // every worker's row moves past the whole batch, all ranges (range sharding)
 static void launch_rows_advance(Run& R) {
     sqg_ctx* c = R.c;
@@ -329,7 +373,14 @@ static void plan_bucketed(Run& R, RunPlan& plan) {
                                        R.d_pcnt + (size_t)b->n_chains * R.n_part, R.n_part, b->n_chains, b->d_wlink_off, R.ptotal, R.pstart, (int)R.n_pairs, b->slice_len,
                                        R.pfirst, R.slice_lo, R.slice_hi, n_off, n_pc, c->d_mid_done, R.SA, n_sc);
                     return SQG_OK; }});
-            plan.push_back({"k_part_events<scatter>: every event to its slot", [&R]() -> int { launch_part_events(R, 0, false); return SQG_OK; }});   // (the dwell is in memory now)
+            plan.push_back({"k_part_events<scatter>: every event to its slot", [&R]() -> int {             // (the dwell is in memory now)
+                const int left = R.c->cal_runs_left;
+                int rc = place_calibrate(R); if (rc) return rc;
+                const bool timed = R.c->cal_runs_left < left;         // a calibration run: the pass between two events
+                if (timed) HIPCHK(R.c, hipEventRecord(R.S->cal_a, R.c->stream));
+                launch_part_events(R, 0, false);
+                if (timed) { HIPCHK(R.c, hipEventRecord(R.S->cal_b, R.c->stream)); R.S->cal_pending = true; R.S->cal_events = R.b->n_events; }
+                return SQG_OK; }});
         }
         plan.push_back({R.fold ? "k_part_hist (+ the lean kernel's work items)" : "k_part_hist", [&R]() -> int {
             const int n_st = R.fold ? (int)R.b->n_stiles : 0;

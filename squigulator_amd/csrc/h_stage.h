@@ -57,6 +57,10 @@ static int grow_slot(sqg_ctx* c, sqg_ctx::Slot& Z, const sqg_batch* b, bool with
         HIPCHK(c, hipMalloc(&Z.d_sigoff, cap * sizeof(long long)));
         Z.reads_cap = cap;
     }
+    if (Z.cal_prev && (size_t)b->n_events + 64 > Z.evrec_cap) {    // (the event records grow: a placement candidate's predecessor is not coming back)
+        HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream2)); HIPCHK(c, hipStreamSynchronize(c->fix_stream));
+        (void)hipFree(Z.cal_prev); Z.cal_prev = nullptr; Z.cal_pending = false;
+    }
     if ((rc2 = ensure(c, (void**)&Z.d_evrec, &Z.evrec_cap, (size_t)b->n_events + 64, sizeof(uint2)))) return rc2;
     if (b->part && (rc2 = ensure(c, (void**)&Z.d_part, &Z.part_cap, (size_t)b->n_events + PART_SLACK, sizeof(uint32_t)))) return rc2;
     if (b->part && b->pieces && !b->one) {
