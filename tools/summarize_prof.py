@@ -40,7 +40,8 @@ if os.path.exists(tr):
     for key, v in per.items():
         v.sort()
         d = [x[1] for x in v]
-        head = (bench_line["warmup"] + bench_line["steps"] + 8) if bench_line else 40   # the streaming leg adds hundreds of launches
+        n_place = int(bench_line["config"].get("placement_batches", 0)) if bench_line else 0     # (round 6: untimed batches in front of the warm-up, bench.py --place-batches)
+        head = (n_place + bench_line["warmup"] + bench_line["steps"] + 8) if bench_line else 40   # the streaming leg adds hundreds of launches
         lines.append(f"* `{key}`: " + ", ".join(f"{x:.0f}" for x in d[:head])
                      + (f", … ({len(d) - head} more: the streaming leg and the CPU leg's parity batch; mean {sum(d[head:]) / len(d[head:]):.0f})" if len(d) > head else ""))
         if key.startswith("k_part_events<1, 0>") or key.startswith("k_part_events<2, 0>"):
@@ -48,8 +49,8 @@ if os.path.exists(tr):
                 lines.append("  * (with the next batch staged ahead -- the timed region -- this pass runs inside `k_part_hand_count`: the launches listed here are "
                              "each run's first batch, the end-to-end legs' 2048-read batches and the parity batch, not the timed steps)")
                 continue
-        if bench_line and len(d) >= bench_line["warmup"] + bench_line["steps"]:
-            w, k = bench_line["warmup"], bench_line["steps"]
+        if bench_line and len(d) >= n_place + bench_line["warmup"] + bench_line["steps"]:
+            w, k = n_place + bench_line["warmup"], bench_line["steps"]
             timed = d[w:w + k]
             lines.append(f"  * launches {w + 1}..{w + k} are the timed steps: mean {sum(timed) / len(timed):.1f} us"
                          + (f"; the bench line of this very run reports kernel_ms = {1e3 * bench_line['roofline']['kernel_ms']:.1f} us (hipEvents)"
