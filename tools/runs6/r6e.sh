@@ -4,6 +4,14 @@
 # then three counter passes for a and b
 cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r6e; mkdir -p $OUT
+# the three variant libraries (development builds; hipcc cross-compiles them anywhere): a = committed loop, b = pair loop, d = pair loop without its last phase
+python - <<'PY'
+import os
+from squigulator_amd import build
+for out, extra in (("tools/var_a_base.so", []), ("tools/var_b_pair.so", ["-DSQG_LEAN_PAIR=1"]), ("tools/var_d_nopost.so", ["-DSQG_LEAN_PAIR=1", "-DSQG_PAIR_ABL=2"])):
+    if not os.path.exists(out) or build.stamped_hash(out) != build.source_hash():
+        build.build_variant(out, dev=True, extra=extra, verbose=False)
+PY
 SQG_LIB=$PWD/tools/var_b_pair.so timeout 1500 python -m pytest tests/test_00_configs.py tests/test_hip_parity.py tests/test_fuzz_parity.py tests/test_config2_hg38.py tests/test_sampler.py tests/test_long_reads.py -m gpu -q -x 2>&1 | tail -4 | tee $OUT/pytest.log
 REPS=12 bash tools/ab_step.sh 2>&1 | tee $OUT/ab.log
 for v in a_base b_pair; do
